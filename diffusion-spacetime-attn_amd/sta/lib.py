@@ -1,0 +1,99 @@
+"""ctypes binding of libsta_xattn.so (C-ABI declared in include/sta_xattn.h).
+
+The library is built in-tree by :func:`build` (hipcc, gfx950 only) and loaded lazily by
+:func:`load`. There is no fallback of any kind: if the shared object is missing or a symbol cannot
+be resolved, :class:`StaLibraryError` is raised — the product path must never run without the HIP
+kernels.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(_HERE)                      # diffusion-spacetime-attn_amd/
+REPO_ROOT = os.path.dirname(PKG_ROOT)
+CSRC = os.path.join(PKG_ROOT, "csrc")
+INCLUDE = os.path.join(REPO_ROOT, "include")
+LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
+SOURCES = [os.path.join(CSRC, "sta_xattn.hip")]
+
+STA_BF16, STA_F16 = 0, 1
+MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
+
+# every symbol include/sta_xattn.h declares: (restype, argtypes)
+_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+SYMBOLS = {
+    "sta_version": (_i, []),
+    "sta_last_error": (ctypes.c_char_p, []),
+    "sta_xattn_packed_kv_bytes": (_sz, [_i, _i, _i]),
+    "sta_xattn_pack_kv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sta_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+}
+
+
+class StaLibraryError(RuntimeError):
+    pass
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile csrc/*.hip for gfx950 into csrc/libsta_xattn.so (cross-compiles without a GPU)."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise StaLibraryError("hipcc not found; cannot build %s" % LIB_PATH)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           "-I", INCLUDE, *SOURCES, "-o", LIB_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise StaLibraryError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library and bind every declared symbol. Raises StaLibraryError if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StaLibraryError(
+            "%s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU or eager fallback for the fused cross-attention)" % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise StaLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in SYMBOLS.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise StaLibraryError("%s does not export %s" % (LIB_PATH, name)) from e
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().sta_last_error().decode()
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, last_error()))

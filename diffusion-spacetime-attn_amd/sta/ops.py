@@ -1,0 +1,160 @@
+"""Host side of the fused spatial-temporal cross-attention: tensors in, C-ABI calls out.
+
+Mirrors (reference paths under attention_optimization/stable-diffusion/):
+  * disc masks                      ldm/modules/attention.py:251-262
+  * K/V re-layout per context       ldm/modules/attention.py:180-183   (-> sta_xattn_pack_kv, once per prompt)
+  * (K+1) x attn2 + masked blend    ldm/modules/attention.py:175-197, 278-294   (-> sta_xattn_fwd)
+  * its gradient w.r.t. x and coef  ldm/modules/diffusionmodules/util.py:132-145 (-> sta_xattn_bwd)
+
+PyTorch is used for device memory, the current HIP stream and autograd plumbing only; all arithmetic
+of the path happens in csrc/sta_xattn.hip. Nothing here falls back to eager PyTorch.
+"""
+import torch
+
+from . import lib as _lib
+
+_DTYPES = {torch.bfloat16: _lib.STA_BF16, torch.float16: _lib.STA_F16}
+
+
+def _dtype_code(t):
+    try:
+        return _DTYPES[t.dtype]
+    except KeyError:
+        raise TypeError("fused cross-attention supports bf16/fp16 tensors, got %s" % t.dtype) from None
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def disc_masks(centres, dim, radius_sq=0.04):
+    """[K, dim*dim] uint8 CPU tensor, 1 where pixel (row r, col c) lies inside object i's disc.
+
+    Bit-exact float32 restatement of attention.py:251-262: ``x`` runs along columns, ``y`` along
+    rows, coordinates are ``arange(dim)/dim`` and the test is ``dx^2 + dy^2 < 0.04`` (r = 0.2).
+    """
+    axis = torch.arange(dim, dtype=torch.float32) / dim
+    out = torch.zeros((len(centres), dim * dim), dtype=torch.uint8)
+    for i, (cx, cy) in enumerate(centres):
+        dx2 = (axis - cx) ** 2
+        dy2 = (axis - cy) ** 2
+        inside = (dx2[None, :] + dy2[:, None]) < radius_sq
+        out[i] = inside.reshape(-1).to(torch.uint8)
+    return out
+
+
+class PackedKV:
+    """Fragment image of the projected keys/values of all contexts of one transformer block."""
+
+    __slots__ = ("buf", "n_ctx", "heads", "M", "C", "dtype")
+
+    def __init__(self, buf, n_ctx, heads, M, C, dtype):
+        self.buf, self.n_ctx, self.heads, self.M, self.C, self.dtype = buf, n_ctx, heads, M, C, dtype
+
+
+def pack_kv(k, v, heads):
+    """k, v: [n_ctx, M, C] (ctx 0 = "", 1 = global prompt, 2+i = local prompt i) -> PackedKV."""
+    if k.shape != v.shape or k.dim() != 3:
+        raise ValueError("k and v must both be [n_ctx, M, C], got %s and %s" % (tuple(k.shape), tuple(v.shape)))
+    if not k.is_cuda:
+        raise RuntimeError("pack_kv needs CUDA/HIP tensors (there is no CPU path)")
+    n_ctx, M, C = k.shape
+    if C % heads:
+        raise ValueError("C=%d is not divisible by heads=%d" % (C, heads))
+    L = _lib.load()
+    k, v = k.contiguous(), v.contiguous()
+    nbytes = L.sta_xattn_packed_kv_bytes(n_ctx, heads, C // heads)
+    if nbytes == 0:
+        raise ValueError("unsupported head dim %d (need d %% 8 == 0 and d <= %d)" % (C // heads, _lib.MAX_HEAD_DIM))
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=k.device)
+    _lib.check(L.sta_xattn_pack_kv(k.data_ptr(), v.data_ptr(), buf.data_ptr(), n_ctx, M, C, heads,
+                                   _dtype_code(k), _stream(k)), "sta_xattn_pack_kv")
+    return PackedKV(buf, n_ctx, heads, M, C, k.dtype)
+
+
+def _check_inputs(q, packed, mask, coef):
+    if q.dim() != 3 or q.shape[0] != 2:
+        raise ValueError("q must be [2, N, C] (uncond row, cond row), got %s" % (tuple(q.shape),))
+    if not q.is_cuda:
+        raise RuntimeError("fused cross-attention needs CUDA/HIP tensors (there is no CPU path)")
+    if q.dtype != packed.dtype:
+        raise TypeError("q is %s but K/V were packed as %s" % (q.dtype, packed.dtype))
+    N, C = q.shape[1], q.shape[2]
+    if C != packed.C:
+        raise ValueError("q has C=%d but K/V were packed with C=%d" % (C, packed.C))
+    K = packed.n_ctx - 2
+    if K < 0:
+        raise ValueError("need at least the unconditional and the global context")
+    if K > 0:
+        if mask is None or coef is None:
+            raise ValueError("mask and coef are required when local contexts are present")
+        if tuple(mask.shape) != (K, N) or mask.dtype != torch.uint8:
+            raise ValueError("mask must be uint8 [K=%d, N=%d], got %s %s" % (K, N, mask.dtype, tuple(mask.shape)))
+        if coef.numel() != K:
+            raise ValueError("coef must have K=%d elements, got %d" % (K, coef.numel()))
+    return N, C, K
+
+
+def xattn_forward(q, packed, mask, coef, scale, want_maps=False):
+    """Raw forward call (no autograd). Returns (out [2,N,C], maps [K+2,heads,N,M] fp32 or None)."""
+    N, C, K = _check_inputs(q, packed, mask, coef)
+    L = _lib.load()
+    q = q.contiguous()
+    coef32 = coef.detach().to(torch.float32).contiguous() if K else None
+    maskc = mask.contiguous() if K else None
+    out = torch.empty_like(q)
+    maps = torch.empty((K + 2, packed.heads, N, packed.M), dtype=torch.float32, device=q.device) if want_maps else None
+    _lib.check(L.sta_xattn_fwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), out.data_ptr(),
+                               _ptr(maps), N, C, packed.heads, packed.M, K, float(scale), _dtype_code(q),
+                               _stream(q)), "sta_xattn_fwd")
+    return out, maps
+
+
+def xattn_backward(q, packed, mask, coef, dout, scale):
+    """Raw backward call. Returns (dq [2,N,C], dcoef [K] fp32)."""
+    N, C, K = _check_inputs(q, packed, mask, coef)
+    L = _lib.load()
+    q, dout = q.contiguous(), dout.to(q.dtype).contiguous()
+    coef32 = coef.detach().to(torch.float32).contiguous() if K else None
+    maskc = mask.contiguous() if K else None
+    dq = torch.empty_like(q)
+    dcoef = torch.empty(K, dtype=torch.float32, device=q.device)
+    ws = torch.empty(L.sta_xattn_bwd_workspace_bytes(N, packed.heads, K), dtype=torch.uint8, device=q.device)
+    _lib.check(L.sta_xattn_bwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), dout.data_ptr(),
+                               dq.data_ptr(), _ptr(dcoef) if K else 0, ws.data_ptr(), N, C, packed.heads,
+                               packed.M, K, float(scale), _dtype_code(q), _stream(q)), "sta_xattn_bwd")
+    return dq, dcoef
+
+
+class _XAttnBlend(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, coef, packed, mask, scale):
+        out, _ = xattn_forward(q, packed, mask, coef, scale)
+        ctx.packed, ctx.mask, ctx.scale = packed, mask, scale
+        ctx.save_for_backward(q, coef if coef is not None else q.new_empty(0))
+        ctx.has_coef = coef is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, coef = ctx.saved_tensors
+        coef_in = coef if ctx.has_coef else None
+        dq, dcoef = xattn_backward(q, ctx.packed, ctx.mask, coef_in, dout, ctx.scale)
+        if ctx.has_coef:
+            dcoef = dcoef.to(coef.dtype).reshape(coef.shape)
+        else:
+            dcoef = None
+        return dq, dcoef, None, None, None
+
+
+def xattn_blend(q, coef, packed, mask, scale):
+    """Differentiable fused op: q [2,N,C], coef [K] -> blended pre-projection output [2,N,C].
+
+    out[0] = A(q[0]; ctx 0);  out[1] = A(q[1]; ctx 1) + sum_i coef[i] mask[i] (A(q[1]; ctx 2+i) - out[0]).
+    Gradients flow to q and coef only (see include/sta_xattn.h).
+    """
+    return _XAttnBlend.apply(q, coef, packed, mask, scale)

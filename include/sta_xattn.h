@@ -1,0 +1,116 @@
+/*
+ * sta_xattn.h — C-ABI of the MI355X (gfx950) spatial-temporal cross-attention library.
+ *
+ * The reference (UCSB-NLP-Chang/Diffusion-SpaceTime-Attn) has no FFI layer: its hot path is the
+ * eager-PyTorch sequence in attention_optimization/stable-diffusion/ldm/modules/attention.py.
+ * Every entry point below therefore cites the Python statements it replaces; INTEGRATION.md shows
+ * the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C types only; every tensor is a raw DEVICE pointer, contiguous, row-major;
+ *   - the caller (PyTorch) owns every buffer; the library never allocates, frees or retains;
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*), never syncs;
+ *   - return 0 on success, a negative STA_E_* code otherwise; sta_last_error() gives the text
+ *     (thread-local). Nothing throws or aborts.
+ *   - dtype: STA_BF16 or STA_F16 for q / k / v / out / dout / dq; coef, dcoef, maps are fp32.
+ *
+ * Context order everywhere ("n_ctx = K + 2"):
+ *   ctx 0      = unconditional prompt ""  — attended by batch row 0 (uncond half of the CFG batch)
+ *   ctx 1      = global prompt             — attended by batch row 1 (cond half)
+ *   ctx 2 + i  = local prompt of object i  — attended by batch row 1, blended inside disc i
+ * This is the set of (row, context) pairs that reach the output of
+ * BasicTransformerBlock._forward (attention.py:278-294); gs_i[0] is computed there and never used.
+ */
+#ifndef STA_XATTN_H
+#define STA_XATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STA_VERSION 0x000100 /* 0.1.0 */
+
+enum { STA_BF16 = 0, STA_F16 = 1 };
+
+enum {
+  STA_OK = 0,
+  STA_E_ARG = -1,     /* bad argument (null pointer, shape out of the supported range) */
+  STA_E_UNSUP = -2,   /* shape/dtype valid but not supported by this build */
+  STA_E_LAUNCH = -3   /* HIP runtime reported an error at launch */
+};
+
+#define STA_MAX_KEYS 80     /* M <= 80 (CLIP: 77)                     */
+#define STA_MAX_HEAD_DIM 160 /* d = C / heads <= 160, d % 8 == 0     */
+#define STA_MAX_OBJECTS 8   /* K <= 8                                 */
+
+/* Library version (STA_VERSION of the build). */
+int sta_version(void);
+
+/* Text of the last error on the calling thread ("" if none). Never NULL. */
+const char* sta_last_error(void);
+
+/*
+ * Bytes of the packed K/V image for n_ctx contexts, `heads` heads of dim d (0 if unsupported).
+ * The image holds, per (ctx, head), the MFMA operand fragments of K and V in the exact lane order
+ * the kernels consume (DESIGN.md §"HBM layout"), for both forward and backward.
+ */
+size_t sta_xattn_packed_kv_bytes(int n_ctx, int heads, int d);
+
+/*
+ * Pack projected keys/values into the fragment image. Replaces the per-call
+ *   k = self.to_k(context); v = self.to_v(context); rearrange(... '(b h) n d')   attention.py:180-183
+ * re-layout (the projections themselves stay a GEMM outside this library). K and V do not depend
+ * on the timestep, so the host calls this once per prompt per block, not once per UNet call.
+ *   k, v   : [n_ctx][M][C]  dtype
+ *   packed : sta_xattn_packed_kv_bytes(n_ctx, heads, C/heads) bytes, 16-byte aligned
+ */
+int sta_xattn_pack_kv(const void* k, const void* v, void* packed,
+                      int n_ctx, int M, int C, int heads, int dtype, void* stream);
+
+/*
+ * Fused forward: for every pixel p and head h
+ *   A_u = softmax(scale * q[0,p,h] K_0^T) V_0          (row 0, ctx 0)
+ *   A_c = softmax(scale * q[1,p,h] K_1^T) V_1          (row 1, ctx 1)
+ *   A_i = softmax(scale * q[1,p,h] K_{2+i}^T) V_{2+i}  (row 1, local i; only needed where mask_i[p])
+ *   out[0,p] = A_u
+ *   out[1,p] = A_c + sum_i coef[i] * mask[i,p] * (A_i - A_u)
+ * i.e. the pre-projection form of attention.py:278-294 (CrossAttention.forward :175-197 for each
+ * context + the masked blend :284-294). Because to_out is affine and mask is per-pixel, applying
+ * to_out once to `out` equals the reference's post-projection blend (bias cancels in the difference).
+ *   q      : [2][N][C] dtype   (to_q(norm2(x)), attention.py:178)
+ *   packed : image from sta_xattn_pack_kv for n_ctx = K + 2
+ *   mask   : [K][N] uint8, 1 inside disc i (attention.py:251-262); may be NULL iff K == 0
+ *   coef   : [K] fp32 device (W[:, step], plms.py:243);      may be NULL iff K == 0
+ *   out    : [2][N][C] dtype
+ *   maps   : NULL, or [K+2][heads][N][M] fp32 — the softmax probabilities ("attn", attention.py:194)
+ *            for parity checks; never passed in timed runs. With maps != NULL no local context is
+ *            skipped outside its disc.
+ *   scale  : dim_head ** -0.5 (attention.py:163)
+ */
+int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const float* coef,
+                  void* out, float* maps,
+                  int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+
+/* Bytes of fp32 workspace sta_xattn_bwd needs for the given shape (deterministic dcoef reduce). */
+size_t sta_xattn_bwd_workspace_bytes(int N, int heads, int K);
+
+/*
+ * Backward of sta_xattn_fwd w.r.t. q and coef (K/V/context gradients are not produced: the text
+ * embeddings and projection weights are constants of the optimisation, plms.py:204-214; the
+ * reference computes and discards them, diffusionmodules/util.py:140-145).
+ *   dout   : [2][N][C] dtype — gradient w.r.t. `out`
+ *   dq     : [2][N][C] dtype
+ *   dcoef  : [K] fp32 (overwritten, not accumulated)
+ *   workspace : sta_xattn_bwd_workspace_bytes(...) bytes (contents undefined on entry and exit)
+ */
+int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const float* coef,
+                  const void* dout, void* dq, float* dcoef, void* workspace,
+                  int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STA_XATTN_H */

@@ -1,0 +1,122 @@
+"""GPU parity of the HIP kernels (through the C-ABI) against the CPU oracle on the same inputs."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import xattn_oracle as orc  # noqa: E402
+
+
+def _case(N, C, heads, K, dtype, seed=0, M=77, centres=None, dev="cuda"):
+    g = torch.Generator().manual_seed(seed)
+    q = torch.randn(2, N, C, generator=g)
+    k = torch.randn(K + 2, M, C, generator=g) * 0.7
+    v = torch.randn(K + 2, M, C, generator=g)
+    dim = int(math.isqrt(N))
+    if dim * dim == N and K > 0:
+        centres = centres or [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)][:K]
+        mask = orc.disc_masks(centres, dim)
+    else:
+        mask = torch.rand(K, N, generator=g) < 0.3
+    coef = torch.rand(K, generator=g) * 3 + 0.5
+    q, k, v = (t.to(dtype) for t in (q, k, v))
+    return q, k, v, mask, coef
+
+
+def _run_fwd(q, k, v, mask, coef, heads, want_maps):
+    from sta import ops
+    dev = "cuda"
+    packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
+    scale = (q.shape[-1] // heads) ** -0.5
+    out, maps = ops.xattn_forward(q.to(dev), packed, mask.to(torch.uint8).to(dev), coef.to(dev), scale, want_maps)
+    torch.cuda.synchronize()
+    return out.float().cpu(), None if maps is None else maps.cpu()
+
+
+SHAPES = [
+    # N, C, heads, K
+    (64, 64, 8, 1),      # d = 8
+    (256, 320, 8, 2),    # d = 40  (level 0 head dim)
+    (64, 640, 8, 2),     # d = 80
+    (64, 1280, 8, 2),    # d = 160
+    (1024, 320, 8, 2),   # 2 waves / WG
+    (4096, 320, 8, 2),   # BASELINE level-0 shape, 4 waves / WG
+    (144, 640, 8, 4),    # 768^2 mid-ish N not multiple of 64, K = 4
+    (100, 128, 4, 3),    # ragged N (not multiple of 16), d = 32
+    (256, 192, 8, 0),    # no objects
+]
+
+
+@pytest.mark.parametrize("N,C,heads,K", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fwd_matches_oracle(N, C, heads, K, dtype):
+    q, k, v, mask, coef = _case(N, C, heads, K, dtype)
+    scale = (C // heads) ** -0.5
+    ref, ref_maps = orc.fused_xattn(q.double(), k.double(), v.double(), mask, coef.double(), heads, scale, want_maps=True)
+    for want_maps in (True, False):
+        out, maps = _run_fwd(q, k, v, mask, coef, heads, want_maps)
+        # outputs are rounded to bf16/fp16 and P is rounded to 16 bits before P.V
+        eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        tol = 4 * eps * (1.0 + ref.abs())
+        err = (out.double() - ref).abs()
+        assert (err <= tol).all(), "max err %.4g (tol %.4g)" % (err.max(), tol.max())
+        if want_maps:
+            # north_star: per-step attention maps within 1e-3 of the CPU reference
+            merr = (maps.double() - ref_maps).abs().max().item()
+            assert merr < 1e-4, merr
+
+
+@pytest.mark.parametrize("N,C,heads,K", SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_bwd_matches_oracle(N, C, heads, K, dtype):
+    from sta import ops
+    q, k, v, mask, coef = _case(N, C, heads, K, dtype, seed=1)
+    scale = (C // heads) ** -0.5
+    g = torch.Generator().manual_seed(7)
+    dout = torch.randn(2, N, C, generator=g).to(dtype)
+    qd = q.double().requires_grad_(True)
+    cd = coef.double().requires_grad_(True)
+    ref = orc.fused_xattn(qd, k.double(), v.double(), mask, cd, heads, scale)
+    ref.backward(dout.double())
+    dev = "cuda"
+    packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
+    dq, dcoef = ops.xattn_backward(q.to(dev), packed, mask.to(torch.uint8).to(dev), coef.to(dev), dout.to(dev), scale)
+    torch.cuda.synchronize()
+    dq, dcoef = dq.float().cpu().double(), dcoef.cpu().double()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    # dS is rounded to 16 bits before the dS.K product: error scales with the gradient magnitude
+    gscale = qd.grad.abs().max().item()
+    err = (dq - qd.grad).abs().max().item()
+    assert err <= 6 * eps * gscale + 1e-6, (err, gscale)
+    if K:
+        rel = ((dcoef - cd.grad).abs() / (cd.grad.abs() + 1e-3 * math.sqrt(N * C))).max().item()
+        assert rel < 2e-2, (dcoef, cd.grad)
+
+
+def test_autograd_function_roundtrip():
+    from sta import ops
+    N, C, heads, K = 256, 320, 8, 2
+    q, k, v, mask, coef = _case(N, C, heads, K, torch.bfloat16, seed=3)
+    dev = "cuda"
+    packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
+    qg = q.to(dev).requires_grad_(True)
+    W = torch.full((K, 50), 2.5, device=dev, requires_grad=True)   # plms.py:204-209 leaf
+    out = ops.xattn_blend(qg, W[:, 7], packed, mask.to(torch.uint8).to(dev), (C // heads) ** -0.5)
+    out.float().square().sum().backward()
+    assert qg.grad is not None and qg.grad.shape == qg.shape
+    assert W.grad is not None and W.grad[:, 7].abs().sum() > 0 and W.grad[:, :7].abs().sum() == 0
+
+
+def test_error_convention():
+    from sta import lib, ops
+    L = lib.load()
+    assert L.sta_version() == 0x000100
+    assert L.sta_xattn_packed_kv_bytes(4, 8, 41) == 0          # d % 8 != 0
+    x = torch.zeros(2, 16, 8 * 168, device="cuda", dtype=torch.bfloat16)
+    rc = L.sta_xattn_fwd(x.data_ptr(), x.data_ptr(), 0, 0, x.data_ptr(), 0, 16, 8 * 168, 8, 77, 0, 1.0, 0, 0)
+    assert rc == -2 and "head dim" in lib.last_error()
+    with pytest.raises(ValueError):
+        ops.pack_kv(torch.zeros(2, 77, 8 * 168, device="cuda", dtype=torch.bfloat16),
+                    torch.zeros(2, 77, 8 * 168, device="cuda", dtype=torch.bfloat16), 8)

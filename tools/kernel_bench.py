@@ -1,0 +1,60 @@
+"""Micro-benchmark of the fused cross-attention kernels at the four SD-v1 UNet level shapes.
+
+Per-launch time by HIP events on the launch stream (torch's current stream); algorithmic flops and
+bytes per SURVEY.md §8(d): F = 4*M*C*N*(K+2), Bt = 8*N*C + 4*(K+2)*M*C + K*N  (bf16).
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd"))
+from sta import ops  # noqa: E402
+
+LEVELS = {512: [(4096, 320), (1024, 640), (256, 1280), (64, 1280)],
+          768: [(9216, 320), (2304, 640), (576, 1280), (144, 1280)]}
+CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]
+
+
+def bench_level(N, C, K, heads=8, M=77, iters=200, dtype=torch.bfloat16, bwd=False):
+    dev = "cuda"
+    g = torch.Generator(device="cpu").manual_seed(0)
+    q = torch.randn(2, N, C, generator=g).to(dtype).to(dev)
+    k = (torch.randn(K + 2, M, C, generator=g) * 0.78).to(dtype).to(dev)
+    v = torch.randn(K + 2, M, C, generator=g).to(dtype).to(dev)
+    dim = int(N ** 0.5)
+    mask = ops.disc_masks(CENTRES[:K], dim).to(dev)
+    coef = torch.full((K,), 5.0 / max(K, 1), device=dev)
+    packed = ops.pack_kv(k, v, heads)
+    scale = (C // heads) ** -0.5
+    dout = torch.randn(2, N, C, generator=g).to(dtype).to(dev)
+    fn = (lambda: ops.xattn_backward(q, packed, mask, coef, dout, scale)) if bwd else \
+         (lambda: ops.xattn_forward(q, packed, mask, coef, scale))
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / iters
+    flops = 4.0 * M * C * N * (K + 2) * (2 if bwd else 1)
+    byts = (12.0 if bwd else 8.0) * N * C + 4.0 * (K + 2) * M * C + K * N
+    return {"N": N, "C": C, "K": K, "bwd": bwd, "us": round(us, 2), "TFLOPs": round(flops / us / 1e6, 1),
+            "GBps": round(byts / us / 1e3, 1)}
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--K", type=int, default=2)
+    ap.add_argument("--bwd", action="store_true")
+    ap.add_argument("--iters", type=int, default=200)
+    a = ap.parse_args()
+    for N, C in LEVELS[a.res]:
+        print(json.dumps(bench_level(N, C, a.K, iters=a.iters, bwd=a.bwd)))
