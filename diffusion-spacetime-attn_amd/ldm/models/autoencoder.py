@@ -1,0 +1,111 @@
+"""KL-VAE decoder of SD-v1 (first_stage_model) — the image end of the loss path
+(reference ldm/models/autoencoder.py:330-333, ldm/modules/diffusionmodules/model.py:462-560).
+Stays on PyTorch-ROCm/MIOpen; parameter names follow the SD-v1-4 state_dict
+(`first_stage_model.post_quant_conv`, `first_stage_model.decoder.*`). Encoder is not needed for
+text-to-image sampling and is not provided."""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ldm.modules.diffusionmodules.util import Normalize
+
+
+class ResnetBlock(nn.Module):
+    def __init__(self, in_channels, out_channels=None):
+        super().__init__()
+        out_channels = in_channels if out_channels is None else out_channels
+        self.norm1 = Normalize(in_channels)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, padding=1)
+        self.norm2 = Normalize(out_channels)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, padding=1)
+        if in_channels != out_channels:
+            self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1)
+
+    def forward(self, x):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = self.conv2(F.silu(self.norm2(h)))
+        return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
+
+
+class AttnBlock(nn.Module):
+    """Single-head spatial self-attention with 1x1-conv projections."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.norm = Normalize(channels)
+        self.q = nn.Conv2d(channels, channels, 1)
+        self.k = nn.Conv2d(channels, channels, 1)
+        self.v = nn.Conv2d(channels, channels, 1)
+        self.proj_out = nn.Conv2d(channels, channels, 1)
+
+    def forward(self, x):
+        b, c, h, w = x.shape
+        n = self.norm(x)
+        q, k, v = (m(n).flatten(2).transpose(1, 2).unsqueeze(1) for m in (self.q, self.k, self.v))   # [b,1,hw,c]
+        o = F.scaled_dot_product_attention(q, k, v, scale=c ** -0.5)
+        return x + self.proj_out(o.squeeze(1).transpose(1, 2).reshape(b, c, h, w))
+
+
+class _Up(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class Decoder(nn.Module):
+    def __init__(self, *, ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=(), dropout=0.0,
+                 in_channels=3, resolution=256, z_channels=4, double_z=True, **ignored):
+        super().__init__()
+        if attn_resolutions:
+            raise NotImplementedError("SD-v1 decoder has no per-level attention")
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        block_in = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z_channels, block_in, 3, padding=1)
+        self.mid = nn.Module()
+        self.mid.block_1 = ResnetBlock(block_in)
+        self.mid.attn_1 = AttnBlock(block_in)
+        self.mid.block_2 = ResnetBlock(block_in)
+        self.up = nn.ModuleList()
+        levels = []
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = nn.Module()
+            lvl.block = nn.ModuleList()
+            lvl.attn = nn.ModuleList()
+            block_out = ch * ch_mult[i_level]
+            for _ in range(num_res_blocks + 1):
+                lvl.block.append(ResnetBlock(block_in, block_out))
+                block_in = block_out
+            if i_level != 0:
+                lvl.upsample = _Up(block_in)
+            levels.insert(0, lvl)
+        self.up.extend(levels)
+        self.norm_out = Normalize(block_in)
+        self.conv_out = nn.Conv2d(block_in, out_ch, 3, padding=1)
+
+    def forward(self, z):
+        h = self.conv_in(z)
+        h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
+        for i_level in reversed(range(self.num_resolutions)):
+            lvl = self.up[i_level]
+            for blk in lvl.block:
+                h = blk(h)
+            if i_level != 0:
+                h = lvl.upsample(h)
+        return self.conv_out(F.silu(self.norm_out(h)))
+
+
+class AutoencoderKL(nn.Module):
+    """Decode-only AutoencoderKL: `decode(z) = decoder(post_quant_conv(z))` (reference autoencoder.py:330-333)."""
+
+    def __init__(self, ddconfig=None, embed_dim=4, lossconfig=None, **ignored):
+        super().__init__()
+        ddconfig = dict(ddconfig or dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                                         ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0))
+        self.decoder = Decoder(**ddconfig)
+        self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
+
+    def decode(self, z):
+        return self.decoder(self.post_quant_conv(z))

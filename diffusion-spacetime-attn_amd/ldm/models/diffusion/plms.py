@@ -1,0 +1,258 @@
+"""PLMS sampler with per-object, per-timestep blend-weight optimisation.
+
+Counterpart of the reference's ldm/models/diffusion/plms.py (PLMSSampler.sample :114-180,
+plms_sampling :182-293, p_sample_plms :296-358, DCLIPLoss :21-61). Same `sample(...)` keyword
+surface and the same numerics:
+  * timesteps flip(1, 21, ..., 981) for S = 50; `index = S-1-i`; CFG batch [uncond, cond];
+  * first step evaluates the UNet twice with the SAME weights column (pseudo improved Euler);
+    Adams-Bashforth orders 2-4 afterwards; DDIM update with eta = 0;
+  * weights W[K, S] start at 5/K, Adam(lr 5e-3), `opt_epochs` (default 3) full trajectories each
+    followed by one optimiser step on the fidelity loss of the decoded image; the image of the last
+    epoch is written to result_outputs/final{E-1}_s{seed}_index_{prompt_idx}.png.
+Generalised where the reference hard-wires a constant: the width of W follows S (reference: 50),
+the crop size follows the decoded image (reference: 512), the first timestep is announced to the
+blocks instead of being compared with 981.
+
+MI355X-specific: with `opt_epochs=0` (fixed weights; BASELINE config 2) the whole CFG UNet call is
+captured once into a hipGraph and replayed for the 51 calls of a trajectory (sta.graphs).
+"""
+import os
+
+import numpy as np
+import torch
+
+from ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
+from sta import prompt_state as _ps
+
+mode = _ps.MODE
+
+
+class DCLIPLoss(torch.nn.Module):
+    """1 - cos(CLIP(image), CLIP(text)) with the reference's two image front-ends:
+    `forward_2` (global): x7 nearest upsample then 16x16 average pool -> 224^2 for a 512^2 image (:36-44);
+    `forward_3` (local crop): bilinear resize to 224^2 (:28-35).
+    The CLIP model is third-party (OpenAI CLIP ViT-B/32, unpinned in the reference) and must be
+    supplied: any object with `encode_image(img[1,3,224,224])` and `encode_text(str)`."""
+
+    def __init__(self, clip_model=None):
+        super().__init__()
+        if clip_model is None:
+            raise RuntimeError("DCLIPLoss needs a CLIP model (encode_image/encode_text); none is bundled. "
+                               "Pass loss_model=... to PLMSSampler, or opt_epochs=0 for fixed weights.")
+        self.model = clip_model
+        self.upsample = torch.nn.Upsample(scale_factor=7)
+        self.avg_pool = torch.nn.AvgPool2d(kernel_size=16)
+
+    def _loss(self, image224, text):
+        fi, ft = self.model.encode_image(image224), self.model.encode_text(text)
+        return 1 - torch.nn.functional.cosine_similarity(fi, ft)
+
+    def forward_2(self, image, text):
+        return self._loss(self.avg_pool(self.upsample(image.unsqueeze(0))), text)
+
+    def forward_3(self, image, text):
+        img = torch.nn.functional.interpolate(image.unsqueeze(0), size=(224, 224), mode="bilinear", antialias=True)
+        return self._loss(img, text)
+
+
+def object_crop_box(centre, height, width, half=0.2):
+    """Pixel box [y1:y2, x1:x2] of the square centre +- 0.2 clipped to the image (reference :256-270)."""
+    cx, cy = centre
+    x1, x2 = max(cx - half, 0), min(cx + half, 1)
+    y1, y2 = max(cy - half, 0), min(cy + half, 1)
+    return int(height * y1), int(height * y2), int(width * x1), int(width * x2)
+
+
+class PLMSSampler(object):
+    def __init__(self, model, schedule="linear", loss_model=None, opt_epochs=3, lr=0.005, weight_init=5.0,
+                 local_loss_weight=5.0, use_graph=True, save_images=True, outdir="result_outputs/", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.clip_loss_model = loss_model
+        self.opt_epochs, self.lr, self.weight_init, self.local_loss_weight = opt_epochs, lr, weight_init, local_loss_weight
+        self.use_graph, self.save_images, self.outdir = use_graph, save_images, outdir
+        self.last_result = None
+        self._graphs = None
+
+    def register_buffer(self, name, attr):
+        if isinstance(attr, np.ndarray):
+            attr = torch.from_numpy(attr)
+        if torch.is_tensor(attr):
+            attr = attr.to(self.model.device)
+        setattr(self, name, attr)
+
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0.0, verbose=True):
+        if ddim_eta != 0:
+            raise ValueError("ddim_eta must be 0 for PLMS")
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discr_method=ddim_discretize, num_ddim_timesteps=ddim_num_steps,
+                                                  num_ddpm_timesteps=self.ddpm_num_timesteps, verbose=verbose)
+        acp = self.model.alphas_cumprod
+        assert acp.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        acp32 = acp.detach().to(torch.float32).cpu().numpy()          # float32 copy, as the reference registers it
+        sig, a, a_prev = make_ddim_sampling_parameters(acp32, self.ddim_timesteps, eta=ddim_eta, verbose=verbose)
+        # host-side float tables: indexing them never touches the device (no sync inside the step loop)
+        self.ddim_sigmas, self.ddim_alphas, self.ddim_alphas_prev = sig, a, a_prev
+        self.ddim_sqrt_one_minus_alphas = np.sqrt(1.0 - a)
+
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0.0, mask=None, x0=None, temperature=1.0, noise_dropout=0.0, score_corrector=None,
+               corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.0,
+               unconditional_conditioning=None, text_index=None, curr_text="", bboxs_curr=None, seed=None,
+               prompt_idx=None, object_names=None, local_conditionings=None, **kwargs):
+        """Same keywords as the reference (:114-143) plus `local_conditionings`: the K embeddings of
+        "a photo of <object>" handed over in memory (the reference passes them through files)."""
+        if mask is not None or x0 is not None or quantize_x0 or score_corrector is not None or noise_dropout:
+            raise NotImplementedError("inpainting / quantisation / score correction are not on this path")
+        if conditioning is not None and conditioning.shape[0] != batch_size:
+            print("Warning: Got %d conditionings but batch-size is %d" % (conditioning.shape[0], batch_size))
+        if batch_size != 1:
+            raise ValueError("the spatial-temporal blocks work on one image per CFG batch (n_samples must be 1)")
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        size = (batch_size, C, H, W)
+        if verbose:
+            print("Data shape for PLMS sampling is %s" % (size,))
+        self.plms_sampling(conditioning, size, x_T=x_T, temperature=temperature,
+                           unconditional_guidance_scale=unconditional_guidance_scale,
+                           unconditional_conditioning=unconditional_conditioning, text_index=text_index,
+                           curr_text=curr_text, bboxs_curr=bboxs_curr, seed=seed, prompt_idx=prompt_idx,
+                           object_names=object_names, local_conditionings=local_conditionings)
+        return None
+
+    # --------------------------------------------------------------------------------------------------
+    def plms_sampling(self, cond, shape, x_T=None, temperature=1.0, unconditional_guidance_scale=1.0,
+                      unconditional_conditioning=None, text_index=None, curr_text="", bboxs_curr=None, seed=None,
+                      prompt_idx=None, object_names=None, local_conditionings=None, **ignored):
+        assert seed is not None
+        bboxs_curr = [] if bboxs_curr is None else bboxs_curr
+        object_names = [] if object_names is None else object_names
+        assert len(bboxs_curr) == len(object_names)
+        device = self.model.device
+        K, b = len(bboxs_curr), shape[0]
+        timesteps = self.ddim_timesteps
+        S = timesteps.shape[0]
+        time_range = np.flip(timesteps)
+        img_input = (torch.randn(shape, device=device) if x_T is None else x_T.to(device)).clone()
+
+        # tell the 16 blocks a new prompt starts (replaces the `time == 981` test + cwd files)
+        _ps.begin_prompt(local_conditionings, first_timestep=int(time_range[0]))
+
+        W = torch.full((K, S), self.weight_init / K if K else 0.0, device=device, dtype=torch.float32)   # :204-209
+        W.requires_grad_(self.opt_epochs > 0 and K > 0)
+        optimizer = torch.optim.Adam([W], lr=self.lr) if W.requires_grad else None
+
+        epochs = max(self.opt_epochs, 1)
+        result = {}
+        for epoch in range(epochs):
+            last = epoch == epochs - 1
+            # Only the image of the last epoch is kept and the weights are discarded afterwards, so the
+            # backward + Adam step of the last epoch cannot change any output (reference :275-288).
+            track = W.requires_grad and not last
+            with torch.set_grad_enabled(track):
+                img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
+                                       time_range, W, bboxs_curr, text_index, graph=self.use_graph and not track)
+                x_img = None
+                if self.model.first_stage_model is not None:
+                    x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
+                if track:
+                    loss = self._fidelity_loss(x_img[0].float(), curr_text, bboxs_curr, object_names)
+                    optimizer.zero_grad()
+                    loss.backward()
+                    optimizer.step()
+                    result.setdefault("losses", []).append(float(loss.detach()))
+            if last:
+                result.update(x0=img.detach(), image=None if x_img is None else x_img.detach(), W=W.detach().clone())
+                if self.save_images and x_img is not None:
+                    self._save(x_img[0], epochs - 1, seed, prompt_idx)
+        self.last_result = result
+        return None
+
+    def _fidelity_loss(self, image, curr_text, bboxs_curr, object_names):
+        if self.clip_loss_model is None:
+            raise RuntimeError("opt_epochs > 0 needs a loss_model (see DCLIPLoss); use opt_epochs=0 for fixed weights")
+        lm = self.clip_loss_model
+        loss = lm.forward_2(image, curr_text)                                                       # :252
+        hgt, wid = image.shape[-2], image.shape[-1]
+        for centre, name in zip(bboxs_curr, object_names):
+            y1, y2, x1, x2 = object_crop_box(centre, hgt, wid)
+            obj = name.lower().replace("the ", "")                                                  # :266-267
+            loss = loss + self.local_loss_weight * lm.forward_3(image[:, y1:y2, x1:x2], "A photo of " + obj)   # :268-273
+        return loss.sum()
+
+    def _save(self, image, epoch, seed, prompt_idx):
+        from PIL import Image
+        arr = (255.0 * image.detach().float().cpu().numpy().transpose(1, 2, 0)).astype(np.uint8)
+        os.makedirs(self.outdir, exist_ok=True)
+        Image.fromarray(arr).save(os.path.join(self.outdir, "final%d_s%d_index_%d.png" % (epoch, seed, prompt_idx)))
+
+    # --------------------------------------------------------------------------------------------------
+    def _trajectory(self, img, cond, uncond, scale, time_range, W, bboxs_curr, text_index, graph=False):
+        S, b, device = len(time_range), img.shape[0], img.device
+        eps_fn = self._make_eps_fn(cond, uncond, scale, bboxs_curr, text_index, graph, img)
+        old_eps = []
+        for i, step in enumerate(time_range):
+            index = S - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            ts_next = torch.full((b,), int(time_range[min(i + 1, S - 1)]), device=device, dtype=torch.long)
+            img, _, e_t = self._plms_update(eps_fn, img, ts, ts_next, index, old_eps, W[:, i])
+            old_eps.append(e_t)
+            if len(old_eps) >= 4:
+                old_eps.pop(0)
+        return img
+
+    def _make_eps_fn(self, cond, uncond, scale, bboxs_curr, text_index, graph, img):
+        """eps(x, t, coef) with classifier-free guidance: batch row 0 = uncond, row 1 = cond (:304-308)."""
+        if uncond is None or scale == 1.0:
+            raise ValueError("the spatial-temporal path needs classifier-free guidance (scale != 1, uc given): "
+                             "the blend subtracts the unconditional row (attention.py:290)")
+        wdtype = next(self.model.model.parameters()).dtype
+        c_in = torch.cat([uncond, cond]).to(wdtype)           # built once per trajectory (the reference: per call)
+        apply_fn = self.model.apply_model_extra
+        if graph and img.is_cuda:
+            from sta.graphs import GraphedEps
+            if self._graphs is None:
+                self._graphs = GraphedEps(self.model)
+            apply_fn = self._graphs.bind(c_in, bboxs_curr, text_index)
+
+        def eps(x, t, coef):
+            x_in = torch.cat([x] * 2)
+            t_in = torch.cat([t] * 2)
+            e_u, e_c = apply_fn(x_in, text_index, t_in, c_in, coef=coef, bboxs_curr=bboxs_curr).chunk(2)
+            return e_u + scale * (e_c - e_u)
+        return eps
+
+    def _x_prev(self, x, e_t, index):
+        """DDIM step with sigma = 0 (:321-338); the tables live on the host as Python floats."""
+        f32 = np.float32                     # the reference evaluates these scalars in float32 on the device
+        a_t, a_prev = f32(self.ddim_alphas[index]), f32(self.ddim_alphas_prev[index])
+        s1m = f32(self.ddim_sqrt_one_minus_alphas[index])
+        pred_x0 = (x - float(s1m) * e_t) / float(np.sqrt(a_t))
+        return float(np.sqrt(a_prev)) * pred_x0 + float(np.sqrt(f32(1.0) - a_prev)) * e_t, pred_x0
+
+    def _plms_update(self, eps_fn, x, t, t_next, index, old_eps, coef):
+        e_t = eps_fn(x, t, coef)
+        n = len(old_eps)
+        if n == 0:      # pseudo improved Euler: second evaluation at t_next with the same coef (:341-345)
+            x_mid, _ = self._x_prev(x, e_t, index)
+            e_prime = (e_t + eps_fn(x_mid, t_next, coef)) / 2
+        elif n == 1:    # Adams-Bashforth 2 (:348)
+            e_prime = (3 * e_t - old_eps[-1]) / 2
+        elif n == 2:    # Adams-Bashforth 3 (:351)
+            e_prime = (23 * e_t - 16 * old_eps[-1] + 5 * old_eps[-2]) / 12
+        else:           # Adams-Bashforth 4 (:354)
+            e_prime = (55 * e_t - 59 * old_eps[-1] + 37 * old_eps[-2] - 9 * old_eps[-3]) / 24
+        x_prev, pred_x0 = self._x_prev(x, e_prime, index)
+        return x_prev, pred_x0, e_t
+
+    def p_sample_plms(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1.0, noise_dropout=0.0, score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1.0, unconditional_conditioning=None, old_eps=None, t_next=None,
+                      text_index=None, coef=None, bboxs_curr=None):
+        """Reference-compatible single step (:296-358) for callers that drive the loop themselves."""
+        if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout:
+            raise NotImplementedError("option not on the spatial-temporal path")
+        eps_fn = self._make_eps_fn(c, unconditional_conditioning, unconditional_guidance_scale,
+                                   [] if bboxs_curr is None else bboxs_curr, text_index, False, x)
+        return self._plms_update(eps_fn, x, t, t_next, index, [] if old_eps is None else old_eps, coef)

@@ -1,0 +1,176 @@
+"""SD-v1 UNet (the `use_spatial_transformer=True, legacy=False` configuration of
+configs/stable-diffusion/v1-inference.yaml) with the reference's hook surface:
+`UNetModel.forward(x, text_index, timesteps, context, y, coef, bboxs_curr)` threads
+`(context, timesteps[0], text_index, coef, bboxs_curr)` to every SpatialTransformer
+(reference openaimodel.py:80-88, :710-743). Module and parameter names follow the reference's
+state_dict (`input_blocks.N.M...`, `middle_block...`, `output_blocks...`, `time_embed`, `out`), so an
+SD-v1-4 checkpoint loads without key remapping. Convolutions / ResBlocks stay on PyTorch-ROCm
+(MIOpen / hipBLASLt); only the cross-attention inside SpatialTransformer is custom HIP.
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ldm.modules.attention import SpatialTransformer
+from ldm.modules.diffusionmodules.util import checkpoint, normalization, timestep_embedding, zero_module
+
+
+class TimestepBlock(nn.Module):
+    """Marker: forward(x, emb)."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Feeds each child what it understands (reference openaimodel.py:74-88)."""
+
+    def forward(self, x, emb, context=None, time=None, text_index=None, coef=None, bboxs_curr=None):
+        for layer in self:
+            if isinstance(layer, SpatialTransformer):
+                x = layer(x, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
+            elif isinstance(layer, TimestepBlock):
+                x = layer(x, emb)
+            else:
+                x = layer(x)
+        return x
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert dims == 2
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
+
+    def forward(self, x):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        return self.conv(x) if self.use_conv else x
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1):
+        super().__init__()
+        assert dims == 2
+        self.channels, self.out_channels, self.use_conv = channels, out_channels or channels, use_conv
+        if use_conv:
+            self.op = nn.Conv2d(self.channels, self.out_channels, 3, stride=2, padding=padding)
+        else:
+            assert self.channels == self.out_channels
+            self.op = nn.AvgPool2d(kernel_size=2, stride=2)
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class ResBlock(TimestepBlock):
+    """GroupNorm-SiLU-conv, + timestep embedding, GroupNorm-SiLU-conv, skip (reference :163-275;
+    the scale-shift-norm and up/down variants are not used by SD-v1)."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False,
+                 use_scale_shift_norm=False, dims=2, use_checkpoint=False, up=False, down=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down or dims != 2:
+            raise NotImplementedError("SD-v1 ResBlock only")
+        self.channels, self.out_channels = channels, out_channels or channels
+        self.use_checkpoint = use_checkpoint
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(), nn.Conv2d(channels, self.out_channels, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+                                        zero_module(nn.Conv2d(self.out_channels, self.out_channels, 3, padding=1)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 3, padding=1)
+        else:
+            self.skip_connection = nn.Conv2d(channels, self.out_channels, 1)
+
+    def forward(self, x, emb):
+        return checkpoint(self._forward, (x, emb), self.parameters(), self.use_checkpoint)
+
+    def _forward(self, x, emb):
+        h = self.in_layers(x)
+        h = h + self.emb_layers(emb).type(h.dtype)[:, :, None, None]
+        return self.skip_connection(x) + self.out_layers(h)
+
+
+class UNetModel(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        if not use_spatial_transformer or context_dim is None:
+            raise NotImplementedError("only the cross-attention (SpatialTransformer) UNet of SD-v1 is provided")
+        if num_classes is not None or n_embed is not None or resblock_updown or use_scale_shift_norm:
+            raise NotImplementedError("option not used by SD-v1")
+        if num_heads == -1 and num_head_channels == -1:
+            raise ValueError("Either num_heads or num_head_channels has to be set")
+        context_dim = list(context_dim)[0] if isinstance(context_dim, (list, tuple)) else context_dim
+        self.image_size, self.in_channels, self.model_channels, self.out_channels = image_size, in_channels, model_channels, out_channels
+        self.num_res_blocks, self.attention_resolutions, self.channel_mult = num_res_blocks, list(attention_resolutions), list(channel_mult)
+        self.use_checkpoint, self.num_heads, self.num_head_channels = use_checkpoint, num_heads, num_head_channels
+        self.num_classes = None
+        self.dtype = torch.float16 if use_fp16 else torch.float32
+
+        def heads_for(ch):
+            return (num_heads, ch // num_heads) if num_head_channels == -1 else (ch // num_head_channels, num_head_channels)
+
+        def res(cin, cout):
+            return ResBlock(cin, emb_dim, dropout, out_channels=cout, use_checkpoint=use_checkpoint)
+
+        def attn(ch):
+            h, dh = heads_for(ch)
+            return SpatialTransformer(ch, h, dh, depth=transformer_depth, context_dim=context_dim)
+
+        emb_dim = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, emb_dim), nn.SiLU(), nn.Linear(emb_dim, emb_dim))
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        skip_chans, ch, ds = [model_channels], model_channels, 1
+        for level, mult in enumerate(self.channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [res(ch, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in self.attention_resolutions:
+                    layers.append(attn(ch))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                skip_chans.append(ch)
+            if level != len(self.channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, out_channels=ch)))
+                skip_chans.append(ch)
+                ds *= 2
+
+        self.middle_block = TimestepEmbedSequential(res(ch, ch), attn(ch), res(ch, ch))
+
+        self.output_blocks = nn.ModuleList()
+        for level, mult in reversed(list(enumerate(self.channel_mult))):
+            for i in range(num_res_blocks + 1):
+                layers = [res(ch + skip_chans.pop(), model_channels * mult)]
+                ch = model_channels * mult
+                if ds in self.attention_resolutions:
+                    layers.append(attn(ch))
+                if level and i == num_res_blocks:
+                    layers.append(Upsample(ch, conv_resample, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(nn.Conv2d(model_channels, out_channels, 3, padding=1)))
+
+    def forward(self, x, text_index=None, timesteps=None, context=None, y=None, coef=None, bboxs_curr=None, **kwargs):
+        if y is not None:
+            raise ValueError("this UNet is not class-conditional")
+        wdtype = self.time_embed[0].weight.dtype
+        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).to(wdtype))
+        time = timesteps[0]
+        h, skips = x.to(wdtype), []
+        for module in self.input_blocks:
+            h = module(h, emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
+            skips.append(h)
+        h = self.middle_block(h, emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
+        for module in self.output_blocks:
+            h = module(torch.cat([h, skips.pop()], dim=1), emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
+        return self.out(h).to(x.dtype)
+
+    def transformer_blocks(self):
+        from ldm.modules.attention import BasicTransformerBlock
+        return [m for m in self.modules() if isinstance(m, BasicTransformerBlock)]

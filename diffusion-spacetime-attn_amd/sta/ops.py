@@ -56,8 +56,10 @@ class PackedKV:
         self.buf, self.n_ctx, self.heads, self.M, self.C, self.dtype = buf, n_ctx, heads, M, C, dtype
 
 
-def pack_kv(k, v, heads):
-    """k, v: [n_ctx, M, C] (ctx 0 = "", 1 = global prompt, 2+i = local prompt i) -> PackedKV."""
+def pack_kv(k, v, heads, out=None):
+    """k, v: [n_ctx, M, C] (ctx 0 = "", 1 = global prompt, 2+i = local prompt i) -> PackedKV.
+
+    `out`: a PackedKV of the same shape to refill in place (keeps its device address stable)."""
     if k.shape != v.shape or k.dim() != 3:
         raise ValueError("k and v must both be [n_ctx, M, C], got %s and %s" % (tuple(k.shape), tuple(v.shape)))
     if not k.is_cuda:
@@ -70,7 +72,11 @@ def pack_kv(k, v, heads):
     nbytes = L.sta_xattn_packed_kv_bytes(n_ctx, heads, C // heads)
     if nbytes == 0:
         raise ValueError("unsupported head dim %d (need d %% 8 == 0 and d <= %d)" % (C // heads, _lib.MAX_HEAD_DIM))
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=k.device)
+    if out is not None and (out.n_ctx, out.heads, out.M, out.C, out.dtype) == (n_ctx, heads, M, C, k.dtype) \
+            and out.buf.device == k.device:
+        buf = out.buf
+    else:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=k.device)
     _lib.check(L.sta_xattn_pack_kv(k.data_ptr(), v.data_ptr(), buf.data_ptr(), n_ctx, M, C, heads,
                                    _dtype_code(k), _stream(k)), "sta_xattn_pack_kv")
     return PackedKV(buf, n_ctx, heads, M, C, k.dtype)

@@ -1,0 +1,63 @@
+"""Deterministic synthetic weights (there is no network: no SD-v1-4 / CLIP checkpoints on disk).
+
+`seeded_fill_` gives every tensor of a state_dict a value that depends only on (seed, key name,
+shape), so two implementations with the same state_dict contract (the reference's modules and
+ours) can be given identical weights without shipping them: fixtures then hold inputs and outputs
+only. Zero-initialised layers of the reference (`SpatialTransformer.proj_out`, the UNet's `out`
+conv, ResBlock out convs) are re-randomised on purpose — with them at zero the cross-attention
+path contributes exactly nothing to the output.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _tensor_for(name, shape, seed):
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(name.encode())]))
+    n = rng.standard_normal(size=tuple(shape), dtype=np.float32)
+    leaf = name.rsplit(".", 1)[-1]
+    if len(shape) >= 2:                       # Linear / Conv weight: variance-preserving
+        fan_in = int(np.prod(shape[1:]))
+        return n * (1.0 / np.sqrt(fan_in))
+    if leaf == "weight":                      # norm gains
+        return 1.0 + 0.1 * n
+    return 0.05 * n                           # biases
+
+
+def seeded_tensor(tag, shape, seed, scale=1.0):
+    """float32 standard-normal tensor that depends only on (seed, tag, shape) — for test inputs that
+    both the golden generator and the tests rebuild instead of storing."""
+    rng = np.random.Generator(np.random.PCG64([seed, zlib.crc32(tag.encode())]))
+    return torch.from_numpy(rng.standard_normal(size=tuple(shape), dtype=np.float32) * np.float32(scale))
+
+
+def seeded_fill_(module, seed=0):
+    """In-place: fill every parameter/buffer of `module` from (seed, name). Returns a checksum."""
+    total = 0.0
+    with torch.no_grad():
+        for name, t in sorted(module.state_dict().items()):
+            if not t.dtype.is_floating_point:
+                continue
+            val = torch.from_numpy(_tensor_for(name, t.shape, seed))
+            t.copy_(val.to(t.dtype))
+            total += float(val.double().abs().sum())
+    return total
+
+
+def device_fill_(module, seed=0):
+    """Fast on-device variant for benchmarking (values differ from seeded_fill_)."""
+    g = torch.Generator(device=next(module.parameters()).device).manual_seed(seed)
+    with torch.no_grad():
+        for name, t in sorted(module.state_dict().items()):
+            if not t.dtype.is_floating_point:
+                continue
+            n = torch.randn(t.shape, generator=g, device=t.device, dtype=torch.float32)
+            leaf = name.rsplit(".", 1)[-1]
+            if t.dim() >= 2:
+                n = n / float(np.sqrt(np.prod(t.shape[1:])))
+            elif leaf == "weight":
+                n = 1.0 + 0.1 * n
+            else:
+                n = 0.05 * n
+            t.copy_(n.to(t.dtype))

@@ -1,0 +1,251 @@
+"""ORACLE tooling — regenerate tests/golden/*.npz by running the REFERENCE's own modules on CPU.
+
+Run in the build container only (needs /root/reference):   python -m oracle.gen_golden
+The fixtures are data: seeded inputs and the reference's outputs. Weights are not stored — both sides
+fill their state_dict with sta.synth.seeded_fill_(module, seed) (same keys, same shapes); the
+fixture records the checksum so a drift of the generator is detected instead of misread as a parity
+failure.
+
+  G1  masks.npz        disc masks for centres x dims                       attention.py:251-262
+  G2  block_*.npz      BasicTransformerBlock: inputs, output, cross-attention section, attention
+                       maps of every (row, context) pair that reaches the output    attention.py:237-300
+  G3  (in block_*.npz) d(0.5*sum(out^2))/dcoef from the reference's autograd
+  G4  unet_eps.npz     one UNetModel call (reduced width, same topology)   openaimodel.py:710-743
+  G5  plms_traj.npz    50-step PLMS trajectory with CFG and per-step coef  plms.py:227-247, 296-358
+  G6  schedule.npz     DDIM timesteps / alpha tables for S = 50 and S = 10  util.py:46-75, plms.py:81-112
+  G7  prompts.json     dataset parsing rules on the first records          scripts/txt2img-{gpt,mscoco,vsr}.py:255-261
+"""
+import json
+import os
+import pickle
+import sys
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "diffusion-spacetime-attn_amd"))
+sys.path.insert(0, REPO)
+
+from oracle import ref_harness as rh  # noqa: E402
+from oracle.golden_inputs import LAT, block_inputs, input_checksum, unet_inputs  # noqa: E402
+from sta.synth import seeded_fill_  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75), (0.05, 0.95), (0.0, 0.0)]
+MASK_DIMS = [8, 12, 16, 32, 64, 96]
+
+BLOCKS = {
+    # name: dim(latent side), C, heads, K, seed
+    "d40": dict(dim=16, C=320, heads=8, K=2, seed=11),
+    "d80": dict(dim=8, C=640, heads=8, K=1, seed=12),
+    "d160": dict(dim=8, C=1280, heads=8, K=2, seed=13),
+    "d8k4": dict(dim=12, C=64, heads=8, K=4, seed=14),
+    "k0": dict(dim=8, C=64, heads=8, K=0, seed=15),
+}
+MAP_PIXELS = 32   # attention maps are stored for this many (seeded) pixels per block
+
+
+def _randn(gen, *shape, scale=1.0):
+    return torch.randn(*shape, generator=gen) * scale
+
+
+def gen_masks():
+    with rh.reference_env() as ref:
+        out = {"centres": np.asarray(CENTRES, dtype=np.float64), "dims": np.asarray(MASK_DIMS)}
+        for dim in MASK_DIMS:
+            # drive the reference's own mask code: a block primed at time == 981 builds self.masks
+            blk = ref.attention.BasicTransformerBlock(dim=8, n_heads=1, d_head=8, context_dim=768, checkpoint=False)
+            blk.eval()
+            cs = [torch.zeros(1, 77, 768) for _ in CENTRES]
+            for i, c in enumerate(cs):
+                torch.save(c, "c%d_fix_radius_0p2_g0.pt" % i)
+            with torch.no_grad():
+                blk(torch.zeros(2, dim * dim, 8), context=torch.zeros(2, 77, 768), time=torch.tensor(981),
+                    coef=torch.zeros(len(CENTRES)), bboxs_curr=[list(c) for c in CENTRES])
+            m = torch.stack([mk[0, :, :, 0] for mk in blk.masks]).numpy()      # [K, dim, dim] bool
+            out["mask_%d" % dim] = np.packbits(m.reshape(len(CENTRES), -1), axis=1)
+    np.savez_compressed(os.path.join(OUT, "masks.npz"), **out)
+    print("masks.npz", {k: v.shape for k, v in out.items()})
+
+
+def gen_block(name, dim, C, heads, K, seed):
+    gen = torch.Generator().manual_seed(seed)
+    N = dim * dim
+    x, context, local_ctx = block_inputs(dim, C, K, seed, rh.load_uncond())
+    centres = [list(c) for c in CENTRES[:K]]
+    coef = (torch.rand(K, generator=gen) * 3 + 1.0)
+    pix = torch.randperm(N, generator=gen)[:MAP_PIXELS].sort().values
+    with rh.reference_env(local_ctx) as ref:
+        blk = ref.attention.BasicTransformerBlock(dim=C, n_heads=heads, d_head=C // heads, context_dim=768, checkpoint=False)
+        blk.eval()
+        checksum = seeded_fill_(blk, seed)
+        for p in blk.parameters():
+            p.requires_grad_(False)
+
+        # the reference's `attn` (attention.py:194) is the first operand of its second einsum (:196)
+        rec = []
+        real_einsum = ref.attention.einsum
+
+        def spy(eq, a, b):
+            if eq.replace(" ", "") == "bij,bjd->bid" and a.shape[-1] == 77:
+                rec.append(a.detach().clone())
+            return real_einsum(eq, a, b)
+
+        ref.attention.einsum = spy
+        grab = {}
+        def grabber(key):          # must return None: a pre-hook's return value would REPLACE the input
+            def hook(m, a):
+                if key not in grab:
+                    grab[key] = a[0].detach().clone()
+            return hook
+
+        h2 = blk.norm2.register_forward_pre_hook(grabber("x1"))
+        h3 = blk.norm3.register_forward_pre_hook(grabber("pre3"))
+        coef_g = coef.clone().requires_grad_(K > 0)
+        out = blk(x.clone(), context=context, time=torch.tensor(981), coef=coef_g, bboxs_curr=centres)
+        h2.remove(), h3.remove()
+        ref.attention.einsum = real_einsum
+        dcoef = np.zeros(0, dtype=np.float32)
+        if K > 0:
+            (0.5 * (out * out).sum()).backward()
+            dcoef = coef_g.grad.numpy().copy()
+        out = out.detach()
+        assert len(rec) == K + 1, len(rec)
+        g_attn = rec[K]                                   # global call: rows (b h) = [uncond heads | cond heads]
+        maps = [g_attn[:heads], g_attn[heads:]] + [rec[i][heads:] for i in range(K)]
+        maps = torch.stack(maps)[:, :, pix, :]            # [K+2, heads, MAP_PIXELS, 77]
+        section = grab["pre3"] - grab["x1"]               # what attention.py:278-294 leaves in x
+    data = dict(
+        dim=dim, C=C, heads=heads, K=K, seed=seed, checksum=checksum,
+        input_checksum=input_checksum(x, context, local_ctx),
+        centres=np.asarray(centres, dtype=np.float64).reshape(K, 2), coef=coef.numpy(),
+        out=out.numpy(), section=section.numpy(), map_pixels=pix.numpy(), maps=maps.numpy(), dcoef=dcoef,
+    )
+    np.savez_compressed(os.path.join(OUT, "block_%s.npz" % name), **data)
+    print("block_%s.npz" % name, "out |mean|=%.4f" % np.abs(data["out"]).mean(), "dcoef", dcoef, "checksum %.6e" % checksum)
+
+
+UNET_CFG = dict(image_size=32, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2,
+                attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=8,
+                use_spatial_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=False, legacy=False)
+UNET_SEED = 21
+
+
+def _unet_inputs(K, seed):
+    uncond = rh.load_uncond()
+    return (uncond,) + unet_inputs(K, seed)
+
+
+def gen_unet():
+    K = 2
+    uncond, c, local_ctx, x = _unet_inputs(K, 31)
+    centres = [list(cc) for cc in CENTRES[:K]]
+    coef = torch.tensor([2.5, 1.7])
+    with rh.reference_env(local_ctx) as ref, torch.no_grad():
+        unet = ref.unet.UNetModel(**UNET_CFG).eval()
+        checksum = seeded_fill_(unet, UNET_SEED)
+        nparams = sum(p.numel() for p in unet.parameters())
+        x_in = torch.cat([x, x * 0.5 + 0.1])
+        t = torch.tensor([981, 981])
+        eps = unet(x_in, 0, t, context=torch.cat([uncond, c]), coef=coef, bboxs_curr=centres)
+        keys = sorted(unet.state_dict().keys())
+        shapes = {k: list(v.shape) for k, v in unet.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "unet_eps.npz"), checksum=checksum, nparams=nparams, x_in=x_in.numpy(),
+                        t=t.numpy(), input_seed=31,
+                        centres=np.asarray(centres), coef=coef.numpy(), eps=eps.numpy())
+    with open(os.path.join(OUT, "unet_state_dict_keys.json"), "w") as f:
+        json.dump({"cfg": UNET_CFG, "shapes": shapes}, f)
+    print("unet_eps.npz nparams", nparams, "eps |mean| %.4f" % eps.abs().mean().item(), "keys", len(keys))
+
+
+def gen_plms():
+    K, S, scale = 2, 50, 7.5
+    uncond, c, local_ctx, x_T = _unet_inputs(K, 41)
+    centres = [list(cc) for cc in CENTRES[:K]]
+    # per-step weights differ per column so that a wrong step -> column mapping is caught (plms.py:243)
+    W = torch.tensor([[5.0 / K * (1.0 + 0.2 * np.sin(0.7 * i + k)) for i in range(S)] for k in range(K)], dtype=torch.float32)
+    keep = [0, 1, 2, 3, 4, 10, 25, 49]
+    with rh.reference_env(local_ctx) as ref, torch.no_grad():
+        unet = ref.unet.UNetModel(**UNET_CFG).eval()
+        checksum = seeded_fill_(unet, UNET_SEED)
+        model = rh.FakeLatentDiffusion(ref, unet)
+        sampler = rh.make_ref_sampler(ref, model)
+        sampler.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+        timesteps = sampler.ddim_timesteps
+        time_range = np.flip(timesteps)
+        total = timesteps.shape[0]
+        img, old_eps, xs, e0 = x_T.clone(), [], {}, None
+        for i, step in enumerate(time_range):               # restates only the loop header of plms.py:227-247
+            index = total - i - 1
+            ts = torch.full((1,), int(step), dtype=torch.long)
+            ts_next = torch.full((1,), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+            img, pred_x0, e_t = sampler.p_sample_plms(img, c, ts, index=index, unconditional_guidance_scale=scale,
+                                                      unconditional_conditioning=uncond, old_eps=old_eps, t_next=ts_next,
+                                                      text_index=0, coef=W[:, i], bboxs_curr=centres)
+            old_eps.append(e_t)
+            if len(old_eps) >= 4:
+                old_eps.pop(0)
+            if i == 0:
+                e0 = e_t.clone()
+            if i in keep:
+                xs[i] = img.clone()
+        tables = dict(ddim_timesteps=np.asarray(timesteps), ddim_alphas=np.asarray(sampler.ddim_alphas),
+                      ddim_alphas_prev=np.asarray(sampler.ddim_alphas_prev),
+                      ddim_sqrt_one_minus_alphas=np.asarray(sampler.ddim_sqrt_one_minus_alphas))
+    np.savez_compressed(os.path.join(OUT, "plms_traj.npz"), checksum=checksum, S=S, scale=scale, x_T=x_T.numpy(), input_seed=41, centres=np.asarray(centres), W=W.numpy(),
+                        keep=np.asarray(keep), xs=np.stack([xs[i].numpy() for i in keep]), e0=e0.numpy(), x0=img.numpy(), **tables)
+    print("plms_traj.npz x0 |mean| %.4f max %.3f" % (img.abs().mean().item(), img.abs().max().item()))
+
+
+def gen_schedule():
+    out = {}
+    with rh.reference_env() as ref:
+        model = rh.FakeLatentDiffusion(ref, None)
+        for S in (50, 10):
+            s = rh.make_ref_sampler(ref, model)
+            s.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+            out["t_%d" % S] = np.asarray(s.ddim_timesteps)
+            out["a_%d" % S] = np.asarray(s.ddim_alphas, dtype=np.float64)
+            out["ap_%d" % S] = np.asarray(s.ddim_alphas_prev, dtype=np.float64)
+            out["s1m_%d" % S] = np.asarray(s.ddim_sqrt_one_minus_alphas, dtype=np.float64)
+        out["alphas_cumprod"] = model.alphas_cumprod.numpy()
+    np.savez_compressed(os.path.join(OUT, "schedule.npz"), **out)
+    print("schedule.npz", out["t_50"][:3], out["t_50"][-1], out["t_10"][-1])
+
+
+def gen_prompts():
+    """First records of the three datasets and what the reference's parsing yields for them."""
+    ds = os.path.join(rh.REF_ROOT, "datasets")
+    out = {}
+    rows = open(os.path.join(ds, "gpt.txt")).read().split("\n")
+    out["gpt_head"] = rows[:16]
+    out["gpt_prompts"] = [rows[4 * i + 2][10:] for i in range(4)]            # txt2img-gpt.py:255-261
+    for name in ("mscoco", "vsr"):
+        rows = open(os.path.join(ds, name + ".txt")).read().split("\n")
+        out[name + "_head"] = rows[:4]
+        out[name + "_prompts"] = [rows[i] for i in range(4)]                  # txt2img-mscoco.py:255-261
+    # 64 MS-COCO prompts + noun chunks for BASELINE config 4 (bench input; the layout predictor is out of scope)
+    rows = open(os.path.join(ds, "mscoco.txt")).read().split("\n")
+    pk = pickle.load(open(os.path.join(ds, "mscoco.pkl"), "rb"))
+    out["mscoco64"] = [{"prompt": rows[i], "objects": [str(o) for o in pk[i][4]][:2]} for i in range(64)]
+    with open(os.path.join(OUT, "prompts.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("prompts.json", out["gpt_prompts"][0], out["mscoco64"][0])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    np.save(os.path.join(OUT, "uncond_clip_l14.npy"), rh.load_uncond().numpy())
+    gen_masks()
+    for name, cfg in BLOCKS.items():
+        gen_block(name, **cfg)
+    gen_schedule()
+    gen_unet()
+    gen_plms()
+    gen_prompts()
+
+
+if __name__ == "__main__":
+    main()

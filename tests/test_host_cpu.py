@@ -1,0 +1,247 @@
+"""Host logic of the product (blocks, UNet, sampler, schedule, C-ABI loading) on CPU.
+
+The two HIP entry points are swapped for the oracle's fused form (tests/cpu_backend.py) so that the
+Python around them can be checked against the reference's golden vectors without a GPU. The real
+kernels are checked in the `-m gpu` tests.
+"""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import golden_inputs as gi
+from sta.synth import seeded_fill_
+from tests.cpu_backend import oracle_ops
+
+G = gi.GOLDEN
+REPO = os.path.dirname(G.rstrip("/")).rsplit("/tests", 1)[0]
+
+
+def _load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from sta import lib
+    header = open(os.path.join(lib.INCLUDE, "sta_xattn.h")).read()
+    declared = set(re.findall(r"\b(sta_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(lib.SYMBOLS), (declared, set(lib.SYMBOLS))
+    L = lib.load()                       # raises if the .so is missing or a symbol is absent
+    assert L.sta_version() == 0x000100
+    assert L.sta_last_error() == b""
+    # host-only entry points (no GPU work)
+    assert L.sta_xattn_packed_kv_bytes(4, 8, 40) == 4 * 8 * 2 * (5 * 2 + 3 * 3) * 1024
+    assert L.sta_xattn_packed_kv_bytes(4, 8, 168) == 0 and L.sta_xattn_packed_kv_bytes(4, 8, 20) == 0
+    assert L.sta_xattn_bwd_workspace_bytes(4096, 8, 2) >= 2 * 256 * 8 * 4
+
+
+def test_missing_gpu_fails_loudly():
+    from sta import ops
+    q = torch.zeros(2, 16, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.pack_kv(torch.zeros(2, 77, 64, dtype=torch.bfloat16), torch.zeros(2, 77, 64, dtype=torch.bfloat16), 8)
+    packed = ops.PackedKV(torch.zeros(1, dtype=torch.uint8), 2, 8, 77, 64, torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.xattn_blend(q, None, packed, None, 1.0)
+
+
+def test_product_disc_masks_bit_exact():
+    from sta import ops
+    g = _load("masks.npz")
+    centres = [tuple(c) for c in g["centres"]]
+    for dim in g["dims"]:
+        ref = np.unpackbits(g["mask_%d" % dim], axis=1)[:, : dim * dim]
+        got = ops.disc_masks(centres, int(dim)).numpy()
+        assert got.dtype == np.uint8 and (got == ref).all(), dim
+
+
+@pytest.mark.parametrize("name", ["d40", "d80", "d160", "d8k4", "k0"])
+@pytest.mark.parametrize("use_ckpt", [False, True])
+def test_block_forward_and_dcoef(name, use_ckpt):
+    from ldm.modules.attention import BasicTransformerBlock
+    from sta import prompt_state
+    g = _load("block_%s.npz" % name)
+    dim, C, heads, K, seed = (int(g[k]) for k in ("dim", "C", "heads", "K", "seed"))
+    x, context, local_ctx = gi.block_inputs(dim, C, K, seed, gi.load_uncond())
+    blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768, checkpoint=use_ckpt)
+    assert abs(seeded_fill_(blk, seed) - float(g["checksum"])) <= 1e-6 * float(g["checksum"])
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    coef = torch.from_numpy(g["coef"]).requires_grad_(K > 0)
+    centres = [list(c) for c in g["centres"]]
+    with oracle_ops():
+        prompt_state.begin_prompt(local_ctx, first_timestep=981)
+        out = blk(x.clone(), context=context, time=torch.tensor(981), coef=coef, bboxs_curr=centres)
+        np.testing.assert_allclose(out.detach().numpy(), g["out"], rtol=0, atol=5e-4)
+        if K:
+            (0.5 * (out * out).sum()).backward()
+            np.testing.assert_allclose(coef.grad.numpy(), g["dcoef"], rtol=1e-3)
+
+
+def test_block_state_follows_prompt_version():
+    """A new prompt (begin_prompt) must re-pack K/V; the same prompt must not."""
+    from ldm.modules.attention import BasicTransformerBlock
+    from sta import ops, prompt_state
+    blk = BasicTransformerBlock(64, 8, 8, context_dim=768, checkpoint=False)
+    x, ctx = torch.randn(2, 64, 64), torch.randn(2, 77, 768)
+    calls = []
+    with oracle_ops():
+        real = ops.pack_kv
+        ops.pack_kv = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        for prompt in range(2):
+            prompt_state.begin_prompt([torch.randn(1, 77, 768)], first_timestep=981)
+            for step in range(3):
+                blk(x, context=ctx, time=torch.tensor(981 - 20 * step), coef=torch.ones(1), bboxs_curr=[[0.5, 0.5]])
+        assert len(calls) == 2
+        with pytest.raises(ValueError, match="announced 1 local prompts"):
+            blk(x, context=ctx, time=torch.tensor(1), coef=torch.ones(2), bboxs_curr=[[0.5, 0.5], [0.2, 0.2]])
+        with pytest.raises(ValueError, match="batch 2"):
+            blk(x[:1], context=ctx, time=torch.tensor(1), coef=torch.ones(1), bboxs_curr=[[0.5, 0.5]])
+
+
+def _golden_unet():
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    meta = json.load(open(os.path.join(G, "unet_state_dict_keys.json")))
+    unet = UNetModel(**meta["cfg"]).eval()
+    return unet, meta
+
+
+def test_unet_state_dict_contract():
+    unet, meta = _golden_unet()
+    ours = {k: list(v.shape) for k, v in unet.state_dict().items()}
+    assert ours == meta["shapes"]          # same keys, same shapes as the reference's UNetModel
+
+
+def test_unet_eps_matches_reference():
+    from sta import prompt_state
+    g = _load("unet_eps.npz")
+    unet, _ = _golden_unet()
+    assert abs(seeded_fill_(unet, 21) - float(g["checksum"])) <= 1e-6 * float(g["checksum"])
+    c, local_ctx, _ = gi.unet_inputs(2, int(g["input_seed"]))
+    uncond = gi.load_uncond()
+    with oracle_ops(), torch.no_grad():
+        prompt_state.begin_prompt(local_ctx, first_timestep=981)
+        eps = unet(torch.from_numpy(g["x_in"]), 0, torch.from_numpy(g["t"]), context=torch.cat([uncond, c]),
+                   coef=torch.from_numpy(g["coef"]), bboxs_curr=[list(cc) for cc in g["centres"]])
+    np.testing.assert_allclose(eps.numpy(), g["eps"], rtol=0, atol=2e-4)
+
+
+def test_sampler_schedule_tables():
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = _load("schedule.npz")
+    unet, _ = _golden_unet()
+    model = LatentDiffusion(unet_config=unet)
+    np.testing.assert_allclose(model.alphas_cumprod.numpy(), g["alphas_cumprod"], rtol=1e-6)
+    for S in (50, 10):
+        s = PLMSSampler(model, opt_epochs=0)
+        s.make_schedule(S, verbose=False)
+        assert (s.ddim_timesteps == g["t_%d" % S]).all()
+        np.testing.assert_allclose(s.ddim_alphas, g["a_%d" % S], rtol=1e-6)
+        np.testing.assert_allclose(s.ddim_alphas_prev, g["ap_%d" % S], rtol=1e-6)
+        np.testing.assert_allclose(s.ddim_sqrt_one_minus_alphas, g["s1m_%d" % S], rtol=1e-6)
+    with pytest.raises(ValueError, match="ddim_eta must be 0"):
+        PLMSSampler(model).make_schedule(50, ddim_eta=0.5)
+
+
+def test_plms_trajectory_matches_reference():
+    """50 PLMS steps (51 UNet calls) with CFG 7.5 and a different weight column per step."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    from sta import prompt_state
+    g = _load("plms_traj.npz")
+    unet, _ = _golden_unet()
+    seeded_fill_(unet, 21)
+    model = LatentDiffusion(unet_config=unet)
+    c, local_ctx, x_T = gi.unet_inputs(2, int(g["input_seed"]))
+    np.testing.assert_array_equal(x_T.numpy(), g["x_T"])
+    uncond = gi.load_uncond()
+    centres = [list(cc) for cc in g["centres"]]
+    W = torch.from_numpy(g["W"])
+    S, scale = int(g["S"]), float(g["scale"])
+    sampler = PLMSSampler(model, opt_epochs=0, use_graph=False, save_images=False)
+    sampler.make_schedule(S, verbose=False)
+    time_range = np.flip(sampler.ddim_timesteps)
+    keep = list(g["keep"])
+    with oracle_ops(), torch.no_grad():
+        prompt_state.begin_prompt(local_ctx, first_timestep=int(time_range[0]))
+        eps_fn = sampler._make_eps_fn(c, uncond, scale, centres, 0, False, x_T)
+        img, old_eps = x_T.clone(), []
+        for i, step in enumerate(time_range):
+            ts = torch.full((1,), int(step), dtype=torch.long)
+            tn = torch.full((1,), int(time_range[min(i + 1, S - 1)]), dtype=torch.long)
+            img, _, e_t = sampler._plms_update(eps_fn, img, ts, tn, S - i - 1, old_eps, W[:, i])
+            old_eps.append(e_t)
+            if len(old_eps) >= 4:
+                old_eps.pop(0)
+            if i == 0:
+                np.testing.assert_allclose(e_t.numpy(), g["e0"], rtol=0, atol=1e-3)
+            if i in keep:
+                ref = g["xs"][keep.index(i)]
+                err = np.abs(img.numpy() - ref).max() / max(1.0, np.abs(ref).max())
+                assert err < 2e-3, (i, err)
+    err = np.abs(img.numpy() - g["x0"]).max() / np.abs(g["x0"]).max()
+    assert err < 2e-3, err
+
+
+def test_sampler_fixed_weights_path_and_result():
+    """sample(...) with opt_epochs=0: reference keyword surface, W = 5/K, result kept for callers."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    unet, _ = _golden_unet()
+    seeded_fill_(unet, 21)
+    model = LatentDiffusion(unet_config=unet)
+    c, local_ctx, x_T = gi.unet_inputs(2, 5)
+    sampler = PLMSSampler(model, opt_epochs=0, use_graph=False, save_images=False)
+    with oracle_ops():
+        out = sampler.sample(S=10, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False,
+                             unconditional_guidance_scale=7.5, unconditional_conditioning=gi.load_uncond(), eta=0.0,
+                             x_T=x_T[:, :, :16, :16], text_index=0, curr_text="x", bboxs_curr=[[0.3, 0.4], [0.7, 0.6]],
+                             seed=1, prompt_idx=0, object_names=["a", "b"], local_conditionings=local_ctx)
+    assert out is None
+    r = sampler.last_result
+    assert r["x0"].shape == (1, 4, 16, 16) and torch.isfinite(r["x0"]).all()
+    assert r["W"].shape == (2, 10) and torch.allclose(r["W"], torch.full((2, 10), 2.5))
+    with pytest.raises(AssertionError):
+        sampler.sample(S=10, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=gi.load_uncond(), bboxs_curr=[[0.3, 0.4]], object_names=[], seed=1)
+
+
+def test_weight_optimisation_epochs_move_W():
+    """opt_epochs=2 with a differentiable stand-in loss: W gets one Adam step (lr 5e-3) from the first
+    epoch; every column receives gradient only from its own step's UNet call(s)."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    from ldm.models.autoencoder import AutoencoderKL
+
+    class Loss(torch.nn.Module):
+        def forward_2(self, image, text):
+            return image.mean().reshape(1)
+
+        def forward_3(self, image, text):
+            return (image ** 2).mean().reshape(1)
+
+    unet, _ = _golden_unet()
+    seeded_fill_(unet, 21)
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    vae = AutoencoderKL(ddconfig=dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32,
+                                      ch_mult=[1, 2], num_res_blocks=1, attn_resolutions=[], dropout=0.0))
+    seeded_fill_(vae, 3)
+    for p in vae.parameters():
+        p.requires_grad_(False)
+    model = LatentDiffusion(unet_config=unet, first_stage_config=vae)
+    c, local_ctx, x_T = gi.unet_inputs(2, 6)
+    sampler = PLMSSampler(model, loss_model=Loss(), opt_epochs=2, use_graph=False, save_images=False)
+    with oracle_ops():
+        sampler.sample(S=5, conditioning=c, batch_size=1, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=gi.load_uncond(), x_T=x_T[:, :, :8, :8], text_index=0, curr_text="x",
+                       bboxs_curr=[[0.3, 0.4], [0.7, 0.6]], seed=1, prompt_idx=0, object_names=["The cat", "dog"],
+                       local_conditionings=local_ctx)
+    r = sampler.last_result
+    assert len(r["losses"]) == 1 and r["image"].shape == (1, 3, 16, 16)
+    step = (r["W"] - 2.5).abs()
+    assert torch.allclose(step, torch.full_like(step, 0.005), atol=1e-4)   # first Adam step has size lr everywhere
