@@ -104,6 +104,7 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.checkpoint = checkpoint
         self._caches = {}            # (N, K) -> _PromptCache
+        self._last_n = None
 
     # -- per-prompt state (reference: the `time == 981` branch, attention.py:240-263) ---------------
     def _stale(self, cache, centres, time):
@@ -148,6 +149,7 @@ class BasicTransformerBlock(nn.Module):
             raise ValueError("BasicTransformerBlock needs the text context")
         if x.shape[0] != 2:
             raise ValueError("the spatial-temporal block needs the CFG batch [uncond, cond] (batch 2), got x %s" % (tuple(x.shape),))
+        self._last_n = x.shape[1]
         cache = self.prepare_prompt(x.shape[1], context, bboxs_curr, time)
         if coef is None:
             if len(bboxs_curr):

@@ -1,0 +1,70 @@
+"""Assemble the SD-v1 latent-diffusion stack around the fused cross-attention.
+
+`build_sd_v1` gives the architecture of configs/stable-diffusion/v1-inference.yaml (UNet 859.5 M
+parameters, KL-VAE decoder, 77x768 text contexts). Without a checkpoint (`ckpt=None`) the weights
+are synthetic and the text encoder is the deterministic stand-in — there is no network in the build
+environment; with a checkpoint the SD-v1-4 state_dict loads by name (strict=False, as the reference
+does, scripts/txt2img-gpt.py:55-72)."""
+import json
+import os
+
+import torch
+
+from ldm.models.autoencoder import AutoencoderKL
+from ldm.models.diffusion.ddpm import SD_V1_UNET, LatentDiffusion
+from ldm.modules.diffusionmodules.openaimodel import UNetModel
+from ldm.modules.encoders.modules import SyntheticTextEmbedder
+from sta import synth
+
+DEFAULT_CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]
+
+
+def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae=True, use_checkpoint=False,
+                init_weights=True, unet_overrides=None):
+    cfg = dict(SD_V1_UNET, use_checkpoint=use_checkpoint)
+    cfg.update(unet_overrides or {})
+    # parameters are created on the meta device (no default init of 0.9 G values) and materialised
+    # uninitialised on `device`; they are then filled synthetically, loaded, or received by broadcast
+    with torch.device("meta"):
+        unet = UNetModel(**cfg)
+        vae = AutoencoderKL() if with_vae else None
+    unet = unet.to(dtype).to_empty(device=device)
+    if vae is not None:
+        vae = vae.to(dtype).to_empty(device=device)
+    text = SyntheticTextEmbedder().to(device)
+    model = LatentDiffusion(unet_config=unet, first_stage_config=vae, cond_stage_config=text).to(device)
+    model.eval()
+    for p in model.parameters():
+        p.requires_grad_(False)      # frozen: the optimisation variable is the weights tensor only (plms.py:214)
+    if ckpt is not None:
+        sd = torch.load(ckpt, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        print("loaded %s: %d missing, %d unexpected keys" % (ckpt, len(missing), len(unexpected)))
+    elif init_weights:
+        if torch.device(device).type == "cuda":
+            synth.device_fill_(model.model, seed)
+            if vae is not None:
+                synth.device_fill_(vae, seed + 1)
+        else:
+            synth.seeded_fill_(model.model, seed)
+            if vae is not None:
+                synth.seeded_fill_(vae, seed + 1)
+    return model
+
+
+def load_prompts(n=64):
+    """The first 64 MS-COCO prompts with two noun chunks each (BASELINE config 4; datasets/mscoco.txt,
+    mscoco.pkl) — text only, used as keys of the synthetic embedder when CLIP weights are absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "mscoco64.json")
+    return json.load(open(path))[:n]
+
+
+def conditionings(model, prompt, object_names, dtype=None):
+    """(uc, c, [c_i]) as the reference script builds them (scripts/txt2img-gpt.py:314-321)."""
+    uc = model.get_learned_conditioning([""])
+    c = model.get_learned_conditioning([prompt])
+    local = [model.get_learned_conditioning(["a photo of " + name]) for name in object_names]
+    if dtype is not None:
+        uc, c, local = uc.to(dtype), c.to(dtype), [l.to(dtype) for l in local]
+    return uc, c, local

@@ -1,0 +1,148 @@
+"""GPU parity of the product modules (bf16, real HIP kernels) against the reference's golden vectors
+and against the oracle-backed fp32 CPU run of the same modules."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_inputs as gi  # noqa: E402
+from sta.synth import seeded_fill_  # noqa: E402
+
+G = gi.GOLDEN
+
+
+def _load(name):
+    return np.load(os.path.join(G, name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("name", ["d40", "d80", "d160", "d8k4", "k0"])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_block_vs_reference_golden(name, dtype):
+    """Whole BasicTransformerBlock in 16-bit on the GPU vs the reference's fp32 CPU output.
+    Tolerance: the block output has |x| ~ 1..10 and 16-bit activations carry 2^-8 (bf16) / 2^-11
+    (fp16) relative rounding through ~10 ops; stated as max-abs <= 8 eps * max|ref|, mean-abs <= eps * mean|ref| * 4."""
+    from ldm.modules.attention import BasicTransformerBlock
+    from sta import prompt_state
+    g = _load("block_%s.npz" % name)
+    dim, C, heads, K, seed = (int(g[k]) for k in ("dim", "C", "heads", "K", "seed"))
+    x, context, local_ctx = gi.block_inputs(dim, C, K, seed, gi.load_uncond())
+    blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768, checkpoint=False)
+    seeded_fill_(blk, seed)
+    blk = blk.to("cuda", dtype)
+    for p in blk.parameters():
+        p.requires_grad_(False)
+    coef = torch.from_numpy(g["coef"]).cuda().requires_grad_(K > 0)
+    prompt_state.begin_prompt([c.cuda() for c in local_ctx], first_timestep=981)
+    out = blk(x.cuda().to(dtype), context=context.cuda().to(dtype), time=torch.tensor(981), coef=coef,
+              bboxs_curr=[list(c) for c in g["centres"]])
+    ref = g["out"]
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = np.abs(out.detach().float().cpu().numpy() - ref)
+    assert err.max() <= 8 * eps * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    assert err.mean() <= 4 * eps * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
+    if K:
+        (0.5 * (out.float() ** 2).sum()).backward()
+        rel = np.abs(coef.grad.cpu().numpy() - g["dcoef"]) / np.abs(g["dcoef"])
+        assert rel.max() < (0.05 if dtype == torch.bfloat16 else 0.01), (coef.grad, g["dcoef"])
+
+
+def test_block_attention_maps_within_1e3():
+    """north_star: per-step attention maps within 1e-3 of the CPU reference. The maps the kernel
+    computes from the block's 16-bit q/K are compared with the reference's fp32 maps at the stored pixels."""
+    from ldm.modules.attention import BasicTransformerBlock
+    from sta import ops
+    for name, dtype, tol in (("d40", torch.float16, 1e-3), ("d160", torch.float16, 1e-3), ("d40", torch.bfloat16, 8e-3)):
+        g = _load("block_%s.npz" % name)
+        dim, C, heads, K, seed = (int(g[k]) for k in ("dim", "C", "heads", "K", "seed"))
+        x, context, local_ctx = gi.block_inputs(dim, C, K, seed, gi.load_uncond())
+        blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768, checkpoint=False)
+        seeded_fill_(blk, seed)
+        blk = blk.cuda()
+        with torch.no_grad():
+            xc = x.cuda()
+            x1 = blk.attn1(blk.norm1(xc)) + xc
+            q = blk.attn2.to_q(blk.norm2(x1)).to(dtype)
+            ctxs = torch.cat([context] + local_ctx).cuda()
+            k, v = blk.attn2.to_k(ctxs).to(dtype), blk.attn2.to_v(ctxs).to(dtype)
+            packed = ops.pack_kv(k, v, heads)
+            mask = ops.disc_masks([tuple(c) for c in g["centres"]], dim).cuda()
+            _, maps = ops.xattn_forward(q, packed, mask, torch.from_numpy(g["coef"]).cuda(), blk.attn2.scale, want_maps=True)
+        pix = torch.from_numpy(g["map_pixels"]).cuda()
+        got = maps[:, :, pix, :].cpu().numpy()
+        err = np.abs(got - g["maps"]).max()
+        assert err < tol, (name, dtype, err)
+
+
+def _golden_unet(dtype):
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    meta = json.load(open(os.path.join(G, "unet_state_dict_keys.json")))
+    unet = UNetModel(**meta["cfg"]).eval()
+    seeded_fill_(unet, 21)
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    return unet.to("cuda", dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_unet_eps_vs_reference_golden(dtype):
+    from sta import prompt_state
+    g = _load("unet_eps.npz")
+    unet = _golden_unet(dtype)
+    c, local_ctx, _ = gi.unet_inputs(2, int(g["input_seed"]))
+    prompt_state.begin_prompt([l.cuda() for l in local_ctx], first_timestep=981)
+    with torch.no_grad():
+        eps = unet(torch.from_numpy(g["x_in"]).cuda(), 0, torch.from_numpy(g["t"]).cuda(),
+                   context=torch.cat([gi.load_uncond(), c]).cuda().to(dtype), coef=torch.from_numpy(g["coef"]).cuda(),
+                   bboxs_curr=[list(cc) for cc in g["centres"]])
+    ref = g["eps"]
+    e = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = np.abs(eps.float().cpu().numpy() - ref)
+    assert err.max() <= 24 * e * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    assert err.mean() <= 6 * e * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
+
+
+def test_plms_trajectory_fp16_vs_reference_golden_and_graph_equals_eager():
+    """Final x0 of the 50-step trajectory on the GPU vs the reference's fp32 CPU x0 (stated fp16
+    tolerance: max-abs <= 5% of max|x0|, mean-abs <= 1% of mean|x0| — 51 chained UNet calls amplify
+    rounding), and hipGraph replay == eager launches bit for bit."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = _load("plms_traj.npz")
+    c, local_ctx, x_T = gi.unet_inputs(2, int(g["input_seed"]))
+    results = {}
+    for mode in ("eager", "graph"):
+        unet = _golden_unet(torch.float16)
+        model = LatentDiffusion(unet_config=unet).cuda()
+        sampler = PLMSSampler(model, opt_epochs=0, use_graph=(mode == "graph"), save_images=False)
+        # fixed weights path uses W = 5/K; the golden used per-step columns, so drive the loop directly for parity
+        sampler.make_schedule(int(g["S"]), verbose=False)
+        if mode == "eager":
+            from sta import prompt_state
+            time_range = np.flip(sampler.ddim_timesteps)
+            W = torch.from_numpy(g["W"]).cuda()
+            with torch.no_grad():
+                prompt_state.begin_prompt([l.cuda() for l in local_ctx], first_timestep=int(time_range[0]))
+                img = sampler._trajectory(x_T.cuda(), c.cuda(), gi.load_uncond().cuda(), float(g["scale"]), time_range, W,
+                                          [list(cc) for cc in g["centres"]], 0, graph=False)
+            ref = g["x0"]
+            err = np.abs(img.float().cpu().numpy() - ref)
+            assert err.max() <= 0.05 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+            assert err.mean() <= 0.01 * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
+        for rep in range(2):     # second prompt re-uses the captured graph with refilled K/V buffers
+            sampler.sample(S=10, conditioning=c.cuda() * (1 + rep), batch_size=1, shape=[4, 32, 32], verbose=False,
+                           unconditional_guidance_scale=7.5, unconditional_conditioning=gi.load_uncond().cuda(), eta=0.0,
+                           x_T=x_T.cuda(), text_index=0, curr_text="x", bboxs_curr=[[0.3, 0.4], [0.7, 0.6 - 0.1 * rep]], seed=1,
+                           prompt_idx=0, object_names=["a", "b"], local_conditionings=[l.cuda() for l in local_ctx])
+            results[(mode, rep)] = sampler.last_result["x0"].clone()
+    for rep in range(2):
+        assert torch.equal(results[("eager", rep)], results[("graph", rep)])
+    assert not torch.equal(results[("eager", 0)], results[("eager", 1)])
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
