@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "sta_xattn.h"
 
@@ -98,6 +99,19 @@ struct Params {
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
+
+// Optional in-kernel timeline (build with -DSTA_TRACE, tools/trace_fwd.py): lane 0 of every wave of
+// workgroup `STA_TRACE_WG` stores s_memtime at a few points. Compiled out of the product library.
+#ifdef STA_TRACE
+__device__ long long* g_trace = nullptr;
+#define STA_T(i)                                                                          \
+  do {                                                                                    \
+    if (g_trace && blockIdx.x == (unsigned)g_trace[0] && (threadIdx.x & 63) == 0)          \
+      g_trace[8 + (threadIdx.x >> 6) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+#else
+#define STA_T(i) do {} while (0)
+#endif
 
 // --------------------------------------------------------------------------------------------------
 // pack: K,V [n_ctx][M][C] -> fragment image. One 64-lane block per fragment.
@@ -207,137 +221,214 @@ __device__ __forceinline__ void load_b_frags(const T* base, bool valid, int g, i
 }
 
 // --------------------------------------------------------------------------------------------------
-// forward
+// forward: one wave per CONTEXT, operand fragments straight from L2, one LDS combine
 // --------------------------------------------------------------------------------------------------
-// One attention of this wave's 16 pixels against the context staged in `buf`:
-//   o[u][r] = (softmax(scale q K^T) V)[px][16u + 4g + r]
-template <typename T, int NDT>
-__device__ __forceinline__ void attend(const char* buf, const typename Tr<T>::V8 (&qf)[nks_of(NDT)],
-                                       f32x4 (&o)[NDT], int lane, int g, int M, float sl2e,
-                                       float* maps_row /* maps + ((ctx*H+h)*N + px)*M or null */) {
-  using V8 = typename Tr<T>::V8;
-  constexpr int NKS = nks_of(NDT);
-  const V8* frag = (const V8*)buf + lane;  // fragment f is at frag[f * 64]
-  f32x4 st[NKT];
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) st[t] = Tr<T>::mfma(frag[(t * NKS + s) * 64], qf[s], st[t]);
-  }
-  const float inv = softmax_keys(st, g, M, sl2e);
-  if (maps_row) {
-#pragma unroll
-    for (int t = 0; t < NKT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = 16 * t + 4 * g + r;
-        if (key < M) maps_row[key] = st[t][r] * inv;
-      }
-  }
-  V8 pb[NPS];
-  tiles_to_b<T>(st, pb);
-#pragma unroll
-  for (int u = 0; u < NDT; ++u) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(frag[(NKT * NKS + s * NDT + u) * 64], pb[s], acc);
-    o[u] = acc * inv;
-  }
-}
+// Workgroup = 4 waves = one (pixel tile of 16*QT pixels, head). Wave w attends contexts w, w+4, ...
+// (K = 2: wave 0 = "" on the uncond row, wave 1 = global prompt, waves 2/3 = local prompts; a local
+// wave whose tile misses its disc has nothing to do). The K+2 attentions of a tile are independent
+// until the blend, so they run side by side instead of one after another, and there is no K/V
+// staging at all: the packed image is already in MFMA A-operand order, so every fragment is one
+// fully coalesced 1-KiB global_load_dwordx4 per wave that hits L2 (the image of a block is 0.6-1.8
+// MB and is shared by every workgroup). Each fragment is reused for QT pixel tiles (B operands),
+// which is what keeps L2 traffic at the level an LDS-staged design would have.
+// The only cross-wave step is the blend: every wave leaves its fp32 partial in LDS, one barrier, then
+// all 256 threads combine  out1 = sum(partials) - (sum_i coef_i mask_i) * A_u  and write both rows
+// with 16-byte stores.
+constexpr int NSLOT = 5;   // LDS slots: 0 = A_u (row 0), 1 + w = row-1 partial of wave w
 
-template <typename T, int NDT>
+template <typename T, int NDT, int QT>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   using V8 = typename Tr<T>::V8;
-  using V4 = typename Tr<T>::V4;
   constexpr int NKS = nks_of(NDT);
-  constexpr int NFWD = fwd_frags(NDT);
-  constexpr int CB = NFWD * FRAG;  // bytes of one staged context
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int tile = L / p.H, h = L % p.H;
-  const int px = (tile * nw + wv) * 16 + c16;
-  const bool valid = px < p.N;
   const int N = p.N, C = p.C, d = p.d, K = p.K;
-  unsigned* flags = (unsigned*)(smem + 2 * CB);
+  const int px0 = tile * 16 * QT;
+  const int DP = d + 4;                           // fp32 row stride of a slot: conflict-free b128 writes
+  const int slot_floats = 16 * QT * DP;
+  float* slots = (float*)smem;
+  STA_T(0);
 
-  // per-pixel blend weights w_i = coef_i * mask_i(px); which discs touch this wave / workgroup
-  float w[MAXK];
-  unsigned mybits = 0;
+  // which discs touch this tile (every wave computes the same answer: no LDS flag, no barrier).
+  // The K byte loads are issued back to back (clamped index instead of a branch per object) so they
+  // cost one L2 round trip, and they are the oldest loads in flight: waves 0/1, which always have
+  // work, do not wait for them before requesting Q and their K fragments.
+  unsigned tile_bits = 0;
+  {
+    const int pxl = px0 + lane;
+    const bool in_tile = lane < 16 * QT && pxl < N && K > 0;
+    uint8_t mb[MAXK];
 #pragma unroll
-  for (int i = 0; i < MAXK; ++i) {
-    w[i] = 0.f;
-    if (i < K) {
-      const bool m = valid && p.mask[(size_t)i * N + px] != 0;
-      w[i] = m ? p.coef[i] : 0.f;
-      if (__any(m)) mybits |= 1u << i;
+    for (int i = 0; i < MAXK; ++i) {
+      const int ii = i < K ? i : (K > 0 ? K - 1 : 0);
+      mb[i] = in_tile ? p.mask[(size_t)ii * N + pxl] : (uint8_t)0;
     }
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i)
+      if (i < K && __any(mb[i] != 0)) tile_bits |= 1u << i;
+    if (p.aux) tile_bits = (1u << K) - 1u;        // parity mode: every map is wanted
   }
-  if (p.aux) mybits = (1u << K) - 1u;  // parity mode: dump every map, skip nothing
-  if (threadIdx.x == 0) flags[0] = 0;
-  __syncthreads();
-  if (lane == 0 && mybits) atomicOr(flags, mybits);
-  __syncthreads();
-  const unsigned wgbits = flags[0];
 
-  const T* qbase = (const T*)p.q + (size_t)px * C + h * d;
-  V8 q0[NKS], q1[NKS];
-  load_b_frags<T, NKS>(qbase, valid, g, d, q0);
-  load_b_frags<T, NKS>(qbase + (size_t)N * C, valid, g, d, q1);
-
-  const char* img = p.packed;  // (ctx*H + h) * all_frags * FRAG
   const size_t ctx_stride = (size_t)p.H * all_frags(NDT) * FRAG;
-  const char* img_h = img + (size_t)h * all_frags(NDT) * FRAG;
+  const char* img_h = p.packed + (size_t)h * all_frags(NDT) * FRAG;
 
-  f32x4 au[NDT], ac[NDT], o[NDT];
-  int c = 0, b = 0;
-  stage_frags(img_h, smem, NFWD, wv, nw, lane);
-  while (c >= 0) {
-    int cn = -1;
-    for (int cc = c + 1; cc < K + 2; ++cc)
-      if (cc < 2 || ((wgbits >> (cc - 2)) & 1u)) { cn = cc; break; }
-    wait_dma_and_sync();  // context c landed in buffer b; everyone is done reading buffer b^1
-    if (cn >= 0) stage_frags(img_h + cn * ctx_stride, smem + (b ^ 1) * CB, NFWD, wv, nw, lane);
-    const char* buf = smem + b * CB;
-    float* mrow = (p.aux && valid)
-                      ? p.aux + (((size_t)c * p.H + h) * N + px) * p.M
-                      : nullptr;
-    if (c == 0) {
-      attend<T, NDT>(buf, q0, au, lane, g, p.M, p.sl2e, mrow);
-    } else if (c == 1) {
-      attend<T, NDT>(buf, q1, ac, lane, g, p.M, p.sl2e, mrow);
-    } else if ((mybits >> (c - 2)) & 1u) {
-      attend<T, NDT>(buf, q1, o, lane, g, p.M, p.sl2e, mrow);
-      float wc = 0.f;
+  f32x4 part[QT][NDT];                            // this wave's row-1 partial (wave 0, ctx 0: A_u)
+  bool have_part = false;
+  for (int c = wv; c < K + 2; c += 4) {
+    if (c >= 2 && !((tile_bits >> (c - 2)) & 1u)) continue;
+    const int row = c == 0 ? 0 : 1;
+    const V8* frag = (const V8*)(img_h + (size_t)c * ctx_stride) + lane;   // fragment f at frag[f*64]
+
+    // B operands: this wave's row of Q for its QT pixel tiles (16 B per lane, d-offset 32s + 8g)
+    V8 qf[QT][NKS];
+    bool valid[QT];
 #pragma unroll
-      for (int i = 0; i < MAXK; ++i) wc = (i == c - 2) ? w[i] : wc;
-#pragma unroll
-      for (int u = 0; u < NDT; ++u) ac[u] += wc * (o[u] - au[u]);
+    for (int qt = 0; qt < QT; ++qt) {
+      const int px = px0 + 16 * qt + c16;
+      valid[qt] = px < N;
+      load_b_frags<T, NKS>((const T*)p.q + ((size_t)row * N + px) * C + h * d, valid[qt], g, d, qf[qt]);
     }
-    c = cn;
-    b ^= 1;
-  }
 
-  if (valid) {
-    T* obase = (T*)p.out + (size_t)px * C + h * d;
+    // All K-side fragments are requested before the first MFMA: left to itself hipcc emits
+    // load -> s_waitcnt vmcnt(0) -> mfma per fragment, i.e. one L2 round trip per MFMA (measured:
+    // 13 us for 55 fragments). With the loads issued back to back the wave pays the L2 latency once.
+    STA_T(1);
+    V8 ka[NKT * NKS];
 #pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      const int dd = 16 * u + 4 * g;
-      if (dd < d) {
-        V4 r0, r1;
+    for (int f = 0; f < NKT * NKS; ++f) ka[f] = frag[f * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    STA_T(2);
+
+    // S^T = K Q^T : every A fragment is used for QT pixel tiles
+    f32x4 st[QT][NKT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          r0[r] = (T)au[u][r];
-          r1[r] = (T)ac[u][r];
-        }
-        *(V4*)(obase + dd) = r0;
-        *(V4*)(obase + (size_t)N * C + dd) = r1;
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int s = 0; s < NKS; ++s)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
+
+    // V-side fragments are requested now; the softmax below runs while they are in flight
+    __builtin_amdgcn_sched_barrier(0);
+    STA_T(3);
+    V8 va[NPS * NDT];
+#pragma unroll
+    for (int f = 0; f < NPS * NDT; ++f) va[f] = frag[(NKT * NKS + f) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+    STA_T(4);
+
+    float inv[QT];
+    V8 pb[QT][NPS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      inv[qt] = softmax_keys(st[qt], g, p.M, p.sl2e);
+      if (p.aux && valid[qt]) {
+        float* mrow = p.aux + (((size_t)c * p.H + h) * N + (px0 + 16 * qt + c16)) * p.M;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * g + r;
+            if (key < p.M) mrow[key] = st[qt][t][r] * inv[qt];
+          }
+      }
+      tiles_to_b<T>(st[qt], pb[qt]);
+    }
+
+    STA_T(5);
+    // O^T = V^T P^T, then this context's share of the blend
+    float wc[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      wc[qt] = inv[qt];
+      if (c >= 2) {
+        const int px = px0 + 16 * qt + c16;
+        const bool m = valid[qt] && p.mask[(size_t)(c - 2) * N + px] != 0;
+        wc[qt] = m ? inv[qt] * p.coef[c - 2] : 0.f;
       }
     }
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      f32x4 acc[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NPS; ++s)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) acc[qt] = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc[qt]);
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+        part[qt][u] = (have_part && c != 0) ? part[qt][u] + acc[qt] * wc[qt] : acc[qt] * wc[qt];
+    }
+    if (c == 0) {
+      // A_u goes to slot 0 right away; wave 0 may go on with local contexts 4, 8 (row-1 partial)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int u = 0; u < NDT; ++u)
+          if (16 * u + 4 * g < d) *(f32x4*)(slots + (16 * qt + c16) * DP + 16 * u + 4 * g) = part[qt][u];
+    } else {
+      have_part = true;
+    }
   }
+  if (have_part) {
+    float* sl = slots + (1 + wv) * slot_floats;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int u = 0; u < NDT; ++u)
+        if (16 * u + 4 * g < d) *(f32x4*)(sl + (16 * qt + c16) * DP + 16 * u + 4 * g) = part[qt][u];
+  }
+  STA_T(6);
+  // which slots hold a row-1 partial: wave w if any of its contexts w, w+4, ... (>= 1) was active
+  unsigned slot_bits = 0;
+  for (int c = 1; c < K + 2; ++c)
+    if (c < 2 || ((tile_bits >> (c - 2)) & 1u)) slot_bits |= 1u << (c & 3);
+  __syncthreads();
+  STA_T(7);
+
+  // combine + store: thread -> (pixel, 8-channel chunk); 16-byte stores to both rows
+  const int chunks = d >> 3;
+  for (int it = threadIdx.x; it < 16 * QT * chunks; it += 256) {
+    const int pl = it / chunks, ch = it - pl * chunks;
+    const int px = px0 + pl;
+    if (px >= N) continue;
+    float wsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i)
+      if (i < K && p.mask[(size_t)i * N + px] != 0) wsum += p.coef[i];
+    const float* s0 = slots + pl * DP + 8 * ch;
+    float au[8], o1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      au[j] = s0[j];
+      o1[j] = -wsum * au[j];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if ((slot_bits >> w) & 1u) {
+        const float* sw = slots + (1 + w) * slot_floats + pl * DP + 8 * ch;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o1[j] += sw[j];
+      }
+    V8 r0, r1;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      r0[j] = (T)au[j];
+      r1[j] = (T)o1[j];
+    }
+    T* ob = (T*)p.out + (size_t)px * C + h * d + 8 * ch;
+    *(V8*)ob = r0;
+    *(V8*)(ob + (size_t)N * C) = r1;
+  }
+  STA_T(8);
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -604,18 +695,42 @@ int check_shape(int N, int C, int heads, int M, int K) {
   return STA_OK;
 }
 
-template <typename T, int NDT>
-int launch_fwd(const Params& p, int nw, hipStream_t st) {
-  constexpr int lds = 2 * fwd_frags(NDT) * FRAG + 16;
+// Pixel tiles per wave: each K/V fragment read from L2 is reused QT times, so larger QT cuts L2
+// traffic; smaller QT gives more workgroups. Take the largest QT the register budget of the head
+// dim allows that still yields >= 512 workgroups (2 per CU), else 1.
+int pick_qt(int N, int heads, int ndt) {
+  int cap = ndt <= 3 ? 4 : (ndt <= 6 ? 2 : 1);
+  if (const char* e = getenv("STA_FWD_QT")) {  // tuning knob (tools/kernel_bench.py); not used in production
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4) return v < cap ? v : cap;
+  }
+  for (int qt = cap; qt > 1; qt >>= 1)
+    if ((long)((N + 16 * qt - 1) / (16 * qt)) * heads >= 512) return qt;
+  return 1;
+}
+
+template <typename T, int NDT, int QT>
+int launch_fwd(const Params& p0, hipStream_t st) {
+  Params p = p0;
+  p.ntiles = (p.N + 16 * QT - 1) / (16 * QT);
+  const int lds = NSLOT * 16 * QT * (p.d + 4) * (int)sizeof(float);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)xattn_fwd_kernel<T, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    constexpr int lds_max = NSLOT * 16 * QT * (16 * NDT + 4) * (int)sizeof(float);
+    if (hipFuncSetAttribute((const void*)xattn_fwd_kernel<T, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess)
       return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd) failed");
     attr_set = true;
   }
-  hipLaunchKernelGGL((xattn_fwd_kernel<T, NDT>), dim3(p.ntiles * p.H), dim3(64 * nw), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_kernel<T, NDT, QT>), dim3(p.ntiles * p.H), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd launch: %s", hipGetErrorString(e));
+}
+
+template <typename T, int NDT>
+int launch_fwd_qt(const Params& p, int qt, hipStream_t st) {
+  if constexpr (NDT <= 3) { if (qt == 4) return launch_fwd<T, NDT, 4>(p, st); }
+  if constexpr (NDT <= 6) { if (qt >= 2) return launch_fwd<T, NDT, 2>(p, st); }
+  return launch_fwd<T, NDT, 1>(p, st);
 }
 
 template <typename T, int NDT>
@@ -640,18 +755,20 @@ int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
 }
 
 template <typename T>
-int dispatch_fwd(const Params& p, int nw, hipStream_t st) {
-  switch ((p.d + 15) / 16) {
-    case 1: return launch_fwd<T, 1>(p, nw, st);
-    case 2: return launch_fwd<T, 2>(p, nw, st);
-    case 3: return launch_fwd<T, 3>(p, nw, st);
-    case 4: return launch_fwd<T, 4>(p, nw, st);
-    case 5: return launch_fwd<T, 5>(p, nw, st);
-    case 6: return launch_fwd<T, 6>(p, nw, st);
-    case 7: return launch_fwd<T, 7>(p, nw, st);
-    case 8: return launch_fwd<T, 8>(p, nw, st);
-    case 9: return launch_fwd<T, 9>(p, nw, st);
-    case 10: return launch_fwd<T, 10>(p, nw, st);
+int dispatch_fwd(const Params& p, hipStream_t st) {
+  const int ndt = (p.d + 15) / 16;
+  const int qt = pick_qt(p.N, p.H, ndt);
+  switch (ndt) {
+    case 1: return launch_fwd_qt<T, 1>(p, qt, st);
+    case 2: return launch_fwd_qt<T, 2>(p, qt, st);
+    case 3: return launch_fwd_qt<T, 3>(p, qt, st);
+    case 4: return launch_fwd_qt<T, 4>(p, qt, st);
+    case 5: return launch_fwd_qt<T, 5>(p, qt, st);
+    case 6: return launch_fwd_qt<T, 6>(p, qt, st);
+    case 7: return launch_fwd_qt<T, 7>(p, qt, st);
+    case 8: return launch_fwd_qt<T, 8>(p, qt, st);
+    case 9: return launch_fwd_qt<T, 9>(p, qt, st);
+    case 10: return launch_fwd_qt<T, 10>(p, qt, st);
   }
   return fail(STA_E_UNSUP, "head dim %d unsupported", p.d);
 }
@@ -676,6 +793,13 @@ int dispatch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
 }  // namespace
 
 extern "C" {
+
+#ifdef STA_TRACE
+// trace build only: buf[0] = workgroup to trace, buf[8 + wave*16 + i] = s_memtime at point i
+int sta_debug_set_trace(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int sta_version(void) { return STA_VERSION; }
 
@@ -714,14 +838,12 @@ int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const 
   if (int rc = check_shape(N, C, heads, M, K)) return rc;
   if (K > 0 && (!mask || !coef)) return fail(STA_E_ARG, "mask/coef required when K > 0");
   if (dtype != STA_BF16 && dtype != STA_F16) return fail(STA_E_UNSUP, "dtype %d", dtype);
-  const int nw = pick_waves(N, heads);
   Params p{};
   p.q = q; p.packed = (const char*)packed; p.mask = mask; p.coef = coef; p.out = out; p.dout = nullptr;
   p.aux = maps; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K;
-  p.ntiles = (N + 16 * nw - 1) / (16 * nw);
   p.scale = scale; p.sl2e = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  return dtype == STA_BF16 ? dispatch_fwd<__bf16>(p, nw, st) : dispatch_fwd<_Float16>(p, nw, st);
+  return dtype == STA_BF16 ? dispatch_fwd<__bf16>(p, st) : dispatch_fwd<_Float16>(p, st);
 }
 
 size_t sta_xattn_bwd_workspace_bytes(int N, int heads, int K) {

@@ -1,0 +1,51 @@
+"""In-kernel timeline of the fused forward kernel (debug build with -DSTA_TRACE, never shipped).
+
+Builds csrc/sta_xattn.hip with -DSTA_TRACE into gpurun_out/libsta_trace.so, launches the kernel at the
+four level shapes and prints, per wave of one workgroup, s_memtime deltas (shader cycles) between:
+ 0 start | 1 ctx loop entered (mask known for local waves) | 2 K loads issued | 3 S MFMAs issued |
+ 4 V loads issued | 5 softmax done | 6 PV done, partial in LDS | 7 after barrier | 8 stores issued
+"""
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd"))
+from sta import lib, ops  # noqa: E402
+
+out = os.path.join(ROOT, "gpurun_out", "libsta_trace.so")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSTA_TRACE",
+                       "-I", lib.INCLUDE, lib.SOURCES[0], "-o", out])
+lib.LIB_PATH = out
+L = lib.load()
+L.sta_debug_set_trace.restype, L.sta_debug_set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
+
+dev = "cuda"
+for (N, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
+    K, H, M = 2, 8, 77
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(2, N, C, generator=g).bfloat16().to(dev)
+    k = torch.randn(K + 2, M, C, generator=g).bfloat16().to(dev)
+    v = torch.randn(K + 2, M, C, generator=g).bfloat16().to(dev)
+    dim = int(N ** 0.5)
+    mask = ops.disc_masks([(0.3, 0.4), (0.7, 0.6)], dim).to(dev)
+    coef = torch.full((K,), 2.5, device=dev)
+    packed = ops.pack_kv(k, v, H)
+    nwg_guess = 0
+    for wg in (0, 37):
+        tr = torch.zeros(8 + 4 * 16, dtype=torch.int64, device=dev)
+        tr[0] = wg
+        assert L.sta_debug_set_trace(tr.data_ptr()) == 0
+        for _ in range(3):
+            ops.xattn_forward(q, packed, mask, coef, (C // H) ** -0.5)
+        torch.cuda.synchronize()
+        t = tr[8:].cpu().view(4, 16)[:, :9]
+        print("N=%d C=%d wg=%d" % (N, C, wg))
+        for w in range(4):
+            row = t[w].tolist()
+            base = t[:, 0].min().item()
+            print("  wave %d start+%5d :" % (w, row[0] - base), " ".join("%6d" % (row[i] - row[0]) if row[i] else "     -" for i in range(1, 9)))
