@@ -93,7 +93,8 @@ struct Params {
   const void* dout;      // bwd only
   float* aux;            // fwd: maps or null; bwd: dcoef partials workspace
   int N, C, H, d, M, K;
-  int ntiles;            // pixel tiles per head = ceil(N / (16*NW))
+  int ntiles;            // pixel tiles per head
+  int ntiles_aux;        // staged forward: contexts that fit LDS at once
   float sl2e;            // scale * log2(e)
   float scale;
 };
@@ -104,12 +105,20 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 // workgroup `STA_TRACE_WG` stores s_memtime at a few points. Compiled out of the product library.
 #ifdef STA_TRACE
 __device__ long long* g_trace = nullptr;
-#define STA_T(i)                                                                          \
-  do {                                                                                    \
-    if (g_trace && blockIdx.x == (unsigned)g_trace[0] && (threadIdx.x & 63) == 0)          \
-      g_trace[8 + (threadIdx.x >> 6) * 16 + (i)] = (long long)__builtin_readcyclecounter(); \
+// the pointer and the traced workgroup are read ONCE (STA_T_INIT); each point is then one store
+#define STA_T_INIT()                                                                       \
+  long long* trace_base = g_trace;                                                          \
+  const bool trace_on = trace_base && blockIdx.x == (unsigned)trace_base[0] && (threadIdx.x & 63) == 0; \
+  long long* trace_row = trace_base + 8 + (threadIdx.x >> 6) * 16;                          \
+  if (trace_on) trace_row[15] = (long long)wall_clock64()
+#define STA_T(i)                                                                           \
+  do {                                                                                     \
+    if (trace_on) __builtin_nontemporal_store((long long)__builtin_readcyclecounter(), trace_row + (i)); \
   } while (0)
+#define STA_T_END() do { if (trace_on) trace_row[14] = (long long)wall_clock64(); } while (0)
 #else
+#define STA_T_INIT() do {} while (0)
+#define STA_T_END() do {} while (0)
 #define STA_T(i) do {} while (0)
 #endif
 
@@ -231,15 +240,68 @@ __device__ __forceinline__ void load_b_frags(const T* base, bool valid, int g, i
 // fully coalesced 1-KiB global_load_dwordx4 per wave that hits L2 (the image of a block is 0.6-1.8
 // MB and is shared by every workgroup). Each fragment is reused for QT pixel tiles (B operands),
 // which is what keeps L2 traffic at the level an LDS-staged design would have.
-// The only cross-wave step is the blend: every wave leaves its fp32 partial in LDS, one barrier, then
-// all 256 threads combine  out1 = sum(partials) - (sum_i coef_i mask_i) * A_u  and write both rows
-// with 16-byte stores.
+//
+// The kernel is LATENCY bound, not bandwidth bound (in-kernel s_memtime timeline, tools/trace_fwd.py:
+// a first-touch global round trip costs 1000-1800 cycles on a freshly launched workgroup while all
+// MFMAs of a wave take ~500). So the structure is: every global load the wave will ever need is
+// requested in the prologue, oldest first — disc-mask bytes, blend weights for the epilogue, Q, then
+// the K-side and V-side fragments — and nothing afterwards waits for memory again:
+//   prologue loads -> [wait: mask] tile test -> [wait: Q,K] S^T MFMAs -> softmax -> [wait: V] O^T MFMAs
+//   -> fp32 partial to LDS -> one barrier -> combine (LDS only) -> 16-byte stores.
+// Local waves request their fragments speculatively (before the tile test) — a wasted 10-25 KB of L2
+// reads when the tile misses the disc, in exchange for one round trip less when it does not.
 constexpr int NSLOT = 5;   // LDS slots: 0 = A_u (row 0), 1 + w = row-1 partial of wave w
+
+// butterfly partners without LDS: v_permlane16_swap / v_permlane32_swap exchange 16- and 32-lane rows
+__device__ __forceinline__ float bfly_max(float x) {
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned v = __float_as_uint(m);
+  auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float bfly_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned v = __float_as_uint(m);
+  auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// softmax over keys with tree-shaped (not chained) reductions; see softmax_keys for the layout
+__device__ __forceinline__ float softmax_keys_fast(f32x4 (&st)[NKT], int g, int M, float sl2e) {
+  float m4[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (16 * t + 4 * g + r < M) ? st[t][r] : -3.0e38f;
+    m4[t] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+  }
+  float mx = fmaxf(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])), m4[4]);
+  mx = bfly_max(mx);
+  const float off = mx * sl2e;
+  float s4[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      st[t][r] = (16 * t + 4 * g + r < M) ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], sl2e, -off)) : 0.f;
+    s4[t] = (st[t][0] + st[t][1]) + (st[t][2] + st[t][3]);
+  }
+  const float l = bfly_sum(((s4[0] + s4[1]) + (s4[2] + s4[3])) + s4[4]);
+  return 1.0f / l;
+}
 
 template <typename T, int NDT, int QT>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
+  constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
+  constexpr bool V_EARLY = NDT <= 6;              // request V fragments with the K fragments?
+  constexpr int ITEMS = (16 * QT * 2 * NDT + 255) / 256;   // combine items per thread (upper bound)
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -250,133 +312,159 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   const int DP = d + 4;                           // fp32 row stride of a slot: conflict-free b128 writes
   const int slot_floats = 16 * QT * DP;
   float* slots = (float*)smem;
+  STA_T_INIT();
   STA_T(0);
 
-  // which discs touch this tile (every wave computes the same answer: no LDS flag, no barrier).
-  // The K byte loads are issued back to back (clamped index instead of a branch per object) so they
-  // cost one L2 round trip, and they are the oldest loads in flight: waves 0/1, which always have
-  // work, do not wait for them before requesting Q and their K fragments.
-  unsigned tile_bits = 0;
+  // ---- prologue: request everything, oldest first ------------------------------------------------
+  // Every load below is UNCONDITIONAL with a clamped (always valid) address and the predicate is
+  // applied to the value afterwards: a guarded load (`cond ? *p : 0`) makes hipcc emit a branch plus
+  // an s_waitcnt per load, i.e. one serialized round trip each.
+  // (a) blend weights (uniform -> scalar loads) and the disc-mask bytes of the tile, one pixel per lane
+  //     (with K == 0 the host points mask/coef at q: readable bytes whose values are never used)
+  float coefv[MAXK], coef_lane;
+  unsigned mbits;                                 // this lane's tile pixel: bit i = inside disc i
+  const int chunks = d >> 3;
+  float wsum[ITEMS];
+  unsigned mi[ITEMS];
   {
-    const int pxl = px0 + lane;
-    const bool in_tile = lane < 16 * QT && pxl < N && K > 0;
-    uint8_t mb[MAXK];
+    // one vector load for all weights (lane i holds coef[i]); a scalar load per object would be
+    // s_load + s_waitcnt each, i.e. K serialized scalar-cache round trips
+    coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
+    mbits = p.mask[min(px0 + lane, N - 1)];
+    // (b) epilogue bookkeeping: this thread's (pixel, 8-channel chunk) items need sum_i coef_i mask_i
 #pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-      const int ii = i < K ? i : (K > 0 ? K - 1 : 0);
-      mb[i] = in_tile ? p.mask[(size_t)ii * N + pxl] : (uint8_t)0;
-    }
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i)
-      if (i < K && __any(mb[i] != 0)) tile_bits |= 1u << i;
-    if (p.aux) tile_bits = (1u << K) - 1u;        // parity mode: every map is wanted
+    for (int j = 0; j < ITEMS; ++j) mi[j] = p.mask[min(px0 + (int)(threadIdx.x + 256 * j) / chunks, N - 1)];
   }
 
   const size_t ctx_stride = (size_t)p.H * all_frags(NDT) * FRAG;
   const char* img_h = p.packed + (size_t)h * all_frags(NDT) * FRAG;
 
-  f32x4 part[QT][NDT];                            // this wave's row-1 partial (wave 0, ctx 0: A_u)
-  bool have_part = false;
-  for (int c = wv; c < K + 2; c += 4) {
-    if (c >= 2 && !((tile_bits >> (c - 2)) & 1u)) continue;
-    const int row = c == 0 ? 0 : 1;
-    const V8* frag = (const V8*)(img_h + (size_t)c * ctx_stride) + lane;   // fragment f at frag[f*64]
-
-    // B operands: this wave's row of Q for its QT pixel tiles (16 B per lane, d-offset 32s + 8g)
-    V8 qf[QT][NKS];
-    bool valid[QT];
+  // (c) operands of this wave's first context (speculative for local contexts)
+  V8 qf[QT][NKS], ka[NKF], va[NVF];
+  bool valid[QT];
+  int c = wv;
+  auto request = [&](int cc) {
+    const int row = cc == 0 ? 0 : 1;
+    const V8* frag = (const V8*)(img_h + (size_t)cc * ctx_stride) + lane;   // fragment f at frag[f*64]
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const int px = px0 + 16 * qt + c16;
       valid[qt] = px < N;
       load_b_frags<T, NKS>((const T*)p.q + ((size_t)row * N + px) * C + h * d, valid[qt], g, d, qf[qt]);
     }
-
-    // All K-side fragments are requested before the first MFMA: left to itself hipcc emits
-    // load -> s_waitcnt vmcnt(0) -> mfma per fragment, i.e. one L2 round trip per MFMA (measured:
-    // 13 us for 55 fragments). With the loads issued back to back the wave pays the L2 latency once.
-    STA_T(1);
-    V8 ka[NKT * NKS];
 #pragma unroll
-    for (int f = 0; f < NKT * NKS; ++f) ka[f] = frag[f * 64];
-    __builtin_amdgcn_sched_barrier(0);
-    STA_T(2);
-
-    // S^T = K Q^T : every A fragment is used for QT pixel tiles
-    f32x4 st[QT][NKT];
+    for (int f = 0; f < NKF; ++f) ka[f] = frag[f * 64];
+    if (V_EARLY) {
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-      for (int t = 0; t < NKT; ++t) st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < NKT; ++t)
-#pragma unroll
-      for (int s = 0; s < NKS; ++s)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
-
-    // V-side fragments are requested now; the softmax below runs while they are in flight
-    __builtin_amdgcn_sched_barrier(0);
-    STA_T(3);
-    V8 va[NPS * NDT];
-#pragma unroll
-    for (int f = 0; f < NPS * NDT; ++f) va[f] = frag[(NKT * NKS + f) * 64];
-    __builtin_amdgcn_sched_barrier(0);
-    STA_T(4);
-
-    float inv[QT];
-    V8 pb[QT][NPS];
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      inv[qt] = softmax_keys(st[qt], g, p.M, p.sl2e);
-      if (p.aux && valid[qt]) {
-        float* mrow = p.aux + (((size_t)c * p.H + h) * N + (px0 + 16 * qt + c16)) * p.M;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = 16 * t + 4 * g + r;
-            if (key < p.M) mrow[key] = st[qt][t][r] * inv[qt];
-          }
-      }
-      tiles_to_b<T>(st[qt], pb[qt]);
+      for (int f = 0; f < NVF; ++f) va[f] = frag[(NKF + f) * 64];
     }
+  };
+  if (c < K + 2) request(c);
+  __builtin_amdgcn_sched_barrier(0);
+  STA_T(1);
 
-    STA_T(5);
-    // O^T = V^T P^T, then this context's share of the blend
-    float wc[QT];
+  // first consumers of the (oldest) mask loads: which discs touch this tile — every wave computes the
+  // same answer, so no LDS flag and no barrier — and the epilogue's per-item weight sums
+  unsigned tile_bits = 0;
+  {
+    const bool in_tile = lane < 16 * QT && px0 + lane < N;
+    mbits = in_tile ? (mbits & ((1u << K) - 1u)) : 0u;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      wc[qt] = inv[qt];
-      if (c >= 2) {
-        const int px = px0 + 16 * qt + c16;
-        const bool m = valid[qt] && p.mask[(size_t)(c - 2) * N + px] != 0;
-        wc[qt] = m ? inv[qt] * p.coef[c - 2] : 0.f;
-      }
+    for (int i = 0; i < MAXK; ++i) {
+      coefv[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+      if (i < K && __any((mbits >> i) & 1u)) tile_bits |= 1u << i;
     }
 #pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      f32x4 acc[QT];
+    for (int j = 0; j < ITEMS; ++j) {
+      wsum[j] = 0.f;
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NPS; ++s)
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) acc[qt] = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc[qt]);
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
-        part[qt][u] = (have_part && c != 0) ? part[qt][u] + acc[qt] * wc[qt] : acc[qt] * wc[qt];
+      for (int i = 0; i < MAXK; ++i) wsum[j] += (i < K && ((mi[j] >> i) & 1u)) ? coefv[i] : 0.f;
     }
-    if (c == 0) {
-      // A_u goes to slot 0 right away; wave 0 may go on with local contexts 4, 8 (row-1 partial)
+  }
+  if (p.aux) tile_bits = (1u << K) - 1u;          // parity mode: every map is wanted
+  STA_T(2);
+
+  f32x4 part[QT][NDT];                            // this wave's row-1 partial (wave 0, ctx 0: A_u)
+  bool have_part = false;
+  while (c < K + 2) {
+    const bool active = c < 2 || ((tile_bits >> (c - 2)) & 1u);
+    if (active) {
+      // S^T = K Q^T : every A fragment is used for QT pixel tiles
+      f32x4 st[QT][NKT];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int u = 0; u < NDT; ++u)
-          if (16 * u + 4 * g < d) *(f32x4*)(slots + (16 * qt + c16) * DP + 16 * u + 4 * g) = part[qt][u];
-    } else {
-      have_part = true;
+        for (int t = 0; t < NKT; ++t) st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < NKT; ++t)
+#pragma unroll
+        for (int s = 0; s < NKS; ++s)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
+      STA_T(3);
+      if (!V_EARLY) {   // large head dims: V fragments are requested once the K registers are free
+        const V8* frag = (const V8*)(img_h + (size_t)c * ctx_stride) + lane;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < NVF; ++f) va[f] = frag[(NKF + f) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      STA_T(4);
+
+      float wc[QT];
+      V8 pb[QT][NPS];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        const float inv = softmax_keys_fast(st[qt], g, p.M, p.sl2e);
+        if (p.aux && valid[qt]) {
+          float* mrow = p.aux + (((size_t)c * p.H + h) * N + (px0 + 16 * qt + c16)) * p.M;
+#pragma unroll
+          for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = 16 * t + 4 * g + r;
+              if (key < p.M) mrow[key] = st[qt][t][r] * inv;
+            }
+        }
+        tiles_to_b<T>(st[qt], pb[qt]);
+        wc[qt] = inv;
+        if (c >= 2) {   // this context's blend weight for the lane's pixel: coef_i * mask_i(px)
+          const unsigned m = ((unsigned)__shfl((int)mbits, 16 * qt + c16) >> (c - 2)) & 1u;
+          float cw = 0.f;
+#pragma unroll
+          for (int i = 0; i < MAXK; ++i) cw = (i == c - 2) ? coefv[i] : cw;
+          wc[qt] = m ? inv * cw : 0.f;
+        }
+      }
+      STA_T(5);
+
+      // O^T = V^T P^T, then this context's share of the blend
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) {
+        f32x4 acc[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NPS; ++s)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) acc[qt] = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc[qt]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+          part[qt][u] = (have_part && c != 0) ? part[qt][u] + acc[qt] * wc[qt] : acc[qt] * wc[qt];
+      }
+      if (c == 0) {
+        // A_u goes to slot 0 right away; wave 0 may go on with local contexts 4, 8 (row-1 partial)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+          for (int u = 0; u < NDT; ++u)
+            if (16 * u + 4 * g < d) *(f32x4*)(slots + (16 * qt + c16) * DP + 16 * u + 4 * g) = part[qt][u];
+      } else {
+        have_part = true;
+      }
     }
+    c += 4;
+    if (c < K + 2) request(c);                    // K > 2 only: next context of this wave
   }
   if (have_part) {
     float* sl = slots + (1 + wv) * slot_floats;
@@ -389,46 +477,200 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   STA_T(6);
   // which slots hold a row-1 partial: wave w if any of its contexts w, w+4, ... (>= 1) was active
   unsigned slot_bits = 0;
-  for (int c = 1; c < K + 2; ++c)
-    if (c < 2 || ((tile_bits >> (c - 2)) & 1u)) slot_bits |= 1u << (c & 3);
+  for (int cc = 1; cc < K + 2; ++cc)
+    if (cc < 2 || ((tile_bits >> (cc - 2)) & 1u)) slot_bits |= 1u << (cc & 3);
   __syncthreads();
   STA_T(7);
 
-  // combine + store: thread -> (pixel, 8-channel chunk); 16-byte stores to both rows
-  const int chunks = d >> 3;
-  for (int it = threadIdx.x; it < 16 * QT * chunks; it += 256) {
+  // combine + store: thread -> (pixel, 8-channel chunk); LDS reads only, 16-byte stores to both rows
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int it = threadIdx.x + 256 * j;
     const int pl = it / chunks, ch = it - pl * chunks;
     const int px = px0 + pl;
-    if (px >= N) continue;
-    float wsum = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i)
-      if (i < K && p.mask[(size_t)i * N + px] != 0) wsum += p.coef[i];
+    if (it >= 16 * QT * chunks || px >= N) continue;
     const float* s0 = slots + pl * DP + 8 * ch;
     float au[8], o1[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      au[j] = s0[j];
-      o1[j] = -wsum * au[j];
+    for (int e = 0; e < 8; ++e) {
+      au[e] = s0[e];
+      o1[e] = -wsum[j] * au[e];
     }
 #pragma unroll
     for (int w = 0; w < 4; ++w)
       if ((slot_bits >> w) & 1u) {
         const float* sw = slots + (1 + w) * slot_floats + pl * DP + 8 * ch;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o1[j] += sw[j];
+        for (int e = 0; e < 8; ++e) o1[e] += sw[e];
       }
     V8 r0, r1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      r0[j] = (T)au[j];
-      r1[j] = (T)o1[j];
+    for (int e = 0; e < 8; ++e) {
+      r0[e] = (T)au[e];
+      r1[e] = (T)o1[e];
     }
     T* ob = (T*)p.out + (size_t)px * C + h * d + 8 * ch;
     *(V8*)ob = r0;
     *(V8*)(ob + (size_t)N * C) = r1;
   }
   STA_T(8);
+  STA_T_END();
+}
+
+// --------------------------------------------------------------------------------------------------
+// forward, LDS-resident variant for the large levels (many pixel tiles per head, d <= 96)
+// --------------------------------------------------------------------------------------------------
+// With thousands of pixel tiles per head the per-CU vector-memory path (64 B/clk) becomes the limit
+// of the wave-per-context kernel above: every wave streams its context's fragments itself. Here a
+// workgroup (4 waves x 16 pixels, one head) copies the fragments of ALL contexts it needs into LDS
+// once (LDS-DMA, 76 KB at d = 40 / K = 2), passes ONE barrier, and each wave then attends its 16
+// pixels against every context from LDS (2x the bandwidth of the vector-memory path, no L2 latency).
+// LDS fragment reads are hoisted into registers ahead of the MFMAs for the same reason the global
+// loads are in the other kernel. Contexts 0/1 are requested before the disc mask is known; local
+// contexts right after the tile test. If the contexts do not fit LDS at once they go in groups.
+template <typename T, int NDT>
+__global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params p) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  constexpr int NKS = nks_of(NDT);
+  constexpr int NKF = NKT * NKS, NVF = NPS * NDT, NFWD = NKF + NVF;
+  constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile = L / p.H, h = L % p.H;
+  const int N = p.N, C = p.C, d = p.d, K = p.K;
+  const int px0 = tile * 64;
+  const int px = px0 + wv * 16 + c16;
+  const bool valid = px < N;
+  const int G = p.ntiles_aux;                     // contexts that fit LDS at once (>= 2)
+  STA_T_INIT();
+  STA_T(0);
+
+  const size_t ctx_stride = (size_t)p.H * all_frags(NDT) * FRAG;
+  const char* img_h = p.packed + (size_t)h * all_frags(NDT) * FRAG;
+
+  // ---- prologue: oldest first — mask bits / weights, fragments of contexts 0 and 1, Q ------------
+  const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
+  unsigned tbits = p.mask[min(px0 + lane, N - 1)];          // lane <-> pixel of the 64-pixel tile
+  stage_frags(img_h, smem, NFWD, wv, 4, lane);
+  stage_frags(img_h + ctx_stride, smem + CB, NFWD, wv, 4, lane);
+  const T* qbase = (const T*)p.q + (size_t)px * C + h * d;
+  V8 q0[NKS], q1[NKS];
+  load_b_frags<T, NKS>(qbase, valid, g, d, q0);
+  load_b_frags<T, NKS>(qbase + (size_t)N * C, valid, g, d, q1);
+  __builtin_amdgcn_sched_barrier(0);
+  STA_T(1);
+
+  tbits = (px0 + lane < N) ? (tbits & ((1u << K) - 1u)) : 0u;
+  unsigned tile_bits = 0, wave_bits = 0;
+  float coefv[MAXK];
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    coefv[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+    if (i < K) {
+      const unsigned long long b = __ballot((tbits >> i) & 1u);
+      if (b) tile_bits |= 1u << i;
+      if ((b >> (16 * wv)) & 0xffffull) wave_bits |= 1u << i;
+    }
+  }
+  const unsigned mybits = (unsigned)__shfl((int)tbits, 16 * wv + c16);   // this lane's own pixel
+  if (p.aux) { tile_bits = (1u << K) - 1u; wave_bits = tile_bits; }      // parity mode: every map
+
+  // active contexts in order: 0, 1, then the local ones whose disc touches the tile (WG-uniform)
+  // entry e of the list sits in LDS slot e % G
+  int n_active = 2 + __builtin_popcount(tile_bits);
+  auto ctx_of = [&](int e) {                      // e-th active context
+    if (e < 2) return e;
+    unsigned rest = tile_bits;
+    for (int k = 2; k < e; ++k) rest &= rest - 1;           // drop the lowest set bits
+    return 2 + (int)__builtin_ctz(rest);
+  };
+  for (int e = 2; e < n_active && e < G; ++e)
+    stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + e * CB, NFWD, wv, 4, lane);
+
+  STA_T(2);
+  f32x4 au[NDT], ac[NDT];
+  for (int e0 = 0; e0 < n_active; e0 += G) {
+    if (e0 > 0) {   // next group: everyone is done reading the previous one
+      __syncthreads();
+      for (int e = e0; e < n_active && e < e0 + G; ++e)
+        stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + (e - e0) * CB, NFWD, wv, 4, lane);
+    }
+    wait_dma_and_sync();
+    STA_T(3);
+    for (int e = e0; e < n_active && e < e0 + G; ++e) {
+      const int c = ctx_of(e);
+      if (e == 1) STA_T(4);
+      if (e == 2) STA_T(5);
+      if (c >= 2 && !((wave_bits >> (c - 2)) & 1u)) continue;   // none of this wave's 16 pixels inside
+      const V8* fr = (const V8*)(smem + (e - e0) * CB) + lane;
+      // LDS -> registers for the whole context, then MFMAs (no ds_read -> wait -> mfma chains)
+      V8 ka[NKF], va[NVF];
+#pragma unroll
+      for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
+#pragma unroll
+      for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
+      f32x4 st[NKT];
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) st[t] = Tr<T>::mfma(ka[t * NKS + s], c == 0 ? q0[s] : q1[s], st[t]);
+      }
+      const float inv = softmax_keys_fast(st, g, p.M, p.sl2e);
+      if (p.aux && valid) {
+        float* mrow = p.aux + (((size_t)c * p.H + h) * N + px) * p.M;
+#pragma unroll
+        for (int t = 0; t < NKT; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * t + 4 * g + r;
+            if (key < p.M) mrow[key] = st[t][r] * inv;
+          }
+      }
+      V8 pb[NPS];
+      tiles_to_b<T>(st, pb);
+      float w = inv;
+      if (c >= 2) {
+        float cw = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXK; ++i) cw = (i == c - 2) ? coefv[i] : cw;
+        w = ((mybits >> (c - 2)) & 1u) ? cw : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[s], acc);
+        if (c == 0) au[u] = acc * inv;
+        else if (c == 1) ac[u] = acc * inv;
+        else ac[u] += w * (acc * inv - au[u]);
+      }
+    }
+  }
+
+  STA_T(6);
+  if (valid) {
+    T* obase = (T*)p.out + (size_t)px * C + h * d;
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      const int dd = 16 * u + 4 * g;
+      if (dd < d) {
+        V4 r0, r1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          r0[r] = (T)au[u][r];
+          r1[r] = (T)ac[u][r];
+        }
+        *(V4*)(obase + dd) = r0;
+        *(V4*)(obase + (size_t)N * C + dd) = r1;
+      }
+    }
+  }
+  STA_T(8);
+  STA_T_END();
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -519,7 +761,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params p) {
     w[i] = 0.f;
     dc[i] = 0.f;
     if (i < K) {
-      const bool m = valid && p.mask[(size_t)i * N + px] != 0;
+      const bool m = valid && ((p.mask[px] >> i) & 1u) != 0;
       w[i] = m ? p.coef[i] : 0.f;
       wsum += w[i];
       if (__any(m)) mybits |= 1u << i;
@@ -608,7 +850,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params p) {
       for (int u = 0; u < NDT; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) part += g1t[u][r] * (o[u][r] - au[u][r]);
-      const bool inside = valid && p.mask[(size_t)(c - 2) * N + px] != 0;
+      const bool inside = valid && ((p.mask[px] >> (c - 2)) & 1u) != 0;
       part = inside ? part : 0.f;
 #pragma unroll
       for (int i = 0; i < MAXK; ++i) dc[i] += (i == c - 2) ? part : 0.f;
@@ -727,6 +969,39 @@ int launch_fwd(const Params& p0, hipStream_t st) {
 }
 
 template <typename T, int NDT>
+int launch_fwd_staged(const Params& p0, hipStream_t st) {
+  constexpr int CB = fwd_frags(NDT) * FRAG;
+  Params p = p0;
+  p.ntiles = (p.N + 63) / 64;
+  int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
+  if (G > p.K + 2) G = p.K + 2;
+  if (2 * G * CB <= 150 * 1024 && p.ntiles * p.H > 256) {}  // (two workgroups per CU fit as they are)
+  p.ntiles_aux = G;
+  const int lds = G * CB;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)xattn_fwd_staged_kernel<T, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT>), dim3(p.ntiles * p.H), dim3(256), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
+}
+
+// Which forward kernel (rocprofv3 kernel durations, K = 2, bf16, MI355X; profiles/r01_kernel_variants.md):
+//   N=4096 d=40 : staged 10.6 us | split 14.3-18.0 us      N=1024 d=80 : staged 10.5 | split 7.9-8.5
+//   N=256/64 d=160 : split 8.3-8.8 (staged not possible: 2 x 55 KB per context pair only)
+// -> the LDS-resident kernel for small head dims with >= 256 workgroups, the wave-per-context one else.
+bool use_staged(int N, int heads, int ndt) {
+  if (const char* e = getenv("STA_FWD_KERNEL")) {  // tuning knob: "staged" / "split"
+    if (!strcmp(e, "staged")) return ndt <= 6;
+    if (!strcmp(e, "split")) return false;
+  }
+  return ndt <= 3 && (long)((N + 63) / 64) * heads >= 256;
+}
+
+template <typename T, int NDT>
 int launch_fwd_qt(const Params& p, int qt, hipStream_t st) {
   if constexpr (NDT <= 3) { if (qt == 4) return launch_fwd<T, NDT, 4>(p, st); }
   if constexpr (NDT <= 6) { if (qt >= 2) return launch_fwd<T, NDT, 2>(p, st); }
@@ -757,6 +1032,16 @@ int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
 template <typename T>
 int dispatch_fwd(const Params& p, hipStream_t st) {
   const int ndt = (p.d + 15) / 16;
+  if (use_staged(p.N, p.H, ndt)) {
+    switch (ndt) {
+      case 1: return launch_fwd_staged<T, 1>(p, st);
+      case 2: return launch_fwd_staged<T, 2>(p, st);
+      case 3: return launch_fwd_staged<T, 3>(p, st);
+      case 4: return launch_fwd_staged<T, 4>(p, st);
+      case 5: return launch_fwd_staged<T, 5>(p, st);
+      case 6: return launch_fwd_staged<T, 6>(p, st);
+    }
+  }
   const int qt = pick_qt(p.N, p.H, ndt);
   switch (ndt) {
     case 1: return launch_fwd_qt<T, 1>(p, qt, st);
@@ -840,6 +1125,10 @@ int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const 
   if (dtype != STA_BF16 && dtype != STA_F16) return fail(STA_E_UNSUP, "dtype %d", dtype);
   Params p{};
   p.q = q; p.packed = (const char*)packed; p.mask = mask; p.coef = coef; p.out = out; p.dout = nullptr;
+  if (K == 0) {  // the kernel's prologue loads are unconditional: give it readable (ignored) bytes
+    p.mask = (const uint8_t*)q;
+    p.coef = (const float*)q;
+  }
   p.aux = maps; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K;
   p.scale = scale; p.sl2e = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;

@@ -135,7 +135,7 @@ class BasicTransformerBlock(nn.Module):
             v = self.attn2.to_v(ctxs)
             cache.packed = _ops.pack_kv(k, v, self.attn2.heads, out=cache.packed)
             if centres:
-                m = _ops.disc_masks(centres, dim).to(context.device)
+                m = _ops.disc_mask_bits(centres, dim).to(context.device)
                 if cache.mask is None:
                     cache.mask = m
                 else:

@@ -47,6 +47,20 @@ def disc_masks(centres, dim, radius_sq=0.04):
     return out
 
 
+def mask_bits(mask_kn):
+    """[K, N] 0/1 masks -> [N] uint8 bit field (bit i = inside disc i), the layout the kernels read."""
+    K = mask_kn.shape[0]
+    if K > _lib.MAX_OBJECTS:
+        raise ValueError("at most %d objects are supported, got %d" % (_lib.MAX_OBJECTS, K))
+    weights = (2 ** torch.arange(K, dtype=torch.int32, device=mask_kn.device)).view(K, 1)
+    return (mask_kn.to(torch.int32).ne(0).to(torch.int32) * weights).sum(0).to(torch.uint8)
+
+
+def disc_mask_bits(centres, dim):
+    """Disc masks of all objects as the [N] uint8 bit field (CPU tensor)."""
+    return mask_bits(disc_masks(centres, dim))
+
+
 class PackedKV:
     """Fragment image of the projected keys/values of all contexts of one transformer block."""
 
@@ -98,8 +112,8 @@ def _check_inputs(q, packed, mask, coef):
     if K > 0:
         if mask is None or coef is None:
             raise ValueError("mask and coef are required when local contexts are present")
-        if tuple(mask.shape) != (K, N) or mask.dtype != torch.uint8:
-            raise ValueError("mask must be uint8 [K=%d, N=%d], got %s %s" % (K, N, mask.dtype, tuple(mask.shape)))
+        if tuple(mask.shape) != (N,) or mask.dtype != torch.uint8:
+            raise ValueError("mask must be the uint8 bit field [N=%d] (see mask_bits), got %s %s" % (N, mask.dtype, tuple(mask.shape)))
         if coef.numel() != K:
             raise ValueError("coef must have K=%d elements, got %d" % (K, coef.numel()))
     return N, C, K

@@ -82,7 +82,9 @@ int sta_xattn_pack_kv(const void* k, const void* v, void* packed,
  * to_out once to `out` equals the reference's post-projection blend (bias cancels in the difference).
  *   q      : [2][N][C] dtype   (to_q(norm2(x)), attention.py:178)
  *   packed : image from sta_xattn_pack_kv for n_ctx = K + 2
- *   mask   : [K][N] uint8, 1 inside disc i (attention.py:251-262); may be NULL iff K == 0
+ *   mask   : [N] uint8 bit field, bit i set iff pixel n lies inside disc i (attention.py:251-262; the
+ *            K boolean [dim,dim] masks of the reference packed into one byte per pixel, K <= 8);
+ *            may be NULL iff K == 0
  *   coef   : [K] fp32 device (W[:, step], plms.py:243);      may be NULL iff K == 0
  *   out    : [2][N][C] dtype
  *   maps   : NULL, or [K+2][heads][N][M] fp32 — the softmax probabilities ("attn", attention.py:194)

@@ -23,7 +23,7 @@ def _pack_kv(k, v, heads, out=None):
 
 def _xattn_blend(q, coef, packed, mask, scale):
     K = packed.n_ctx - 2
-    m = mask.bool() if K else torch.zeros((0, q.shape[1]), dtype=torch.bool)
+    m = torch.stack([(mask >> i) & 1 for i in range(K)]).bool() if K else torch.zeros((0, q.shape[1]), dtype=torch.bool)
     c = coef if K else torch.zeros(0, dtype=q.dtype)
     return orc.fused_xattn(q, packed.k, packed.v, m, c.to(q.dtype), packed.heads, scale)
 

@@ -56,6 +56,8 @@ def test_product_disc_masks_bit_exact():
         ref = np.unpackbits(g["mask_%d" % dim], axis=1)[:, : dim * dim]
         got = ops.disc_masks(centres, int(dim)).numpy()
         assert got.dtype == np.uint8 and (got == ref).all(), dim
+        bits = ops.disc_mask_bits(centres, int(dim)).numpy()          # what the kernels read: bit i = disc i
+        assert bits.dtype == np.uint8 and all((((bits >> i) & 1) == ref[i]).all() for i in range(len(centres)))
 
 
 @pytest.mark.parametrize("name", ["d40", "d80", "d160", "d8k4", "k0"])

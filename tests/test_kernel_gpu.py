@@ -30,7 +30,7 @@ def _run_fwd(q, k, v, mask, coef, heads, want_maps):
     dev = "cuda"
     packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
     scale = (q.shape[-1] // heads) ** -0.5
-    out, maps = ops.xattn_forward(q.to(dev), packed, mask.to(torch.uint8).to(dev), coef.to(dev), scale, want_maps)
+    out, maps = ops.xattn_forward(q.to(dev), packed, ops.mask_bits(mask).to(dev), coef.to(dev), scale, want_maps)
     torch.cuda.synchronize()
     return out.float().cpu(), None if maps is None else maps.cpu()
 
@@ -82,7 +82,7 @@ def test_bwd_matches_oracle(N, C, heads, K, dtype):
     ref.backward(dout.double())
     dev = "cuda"
     packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
-    dq, dcoef = ops.xattn_backward(q.to(dev), packed, mask.to(torch.uint8).to(dev), coef.to(dev), dout.to(dev), scale)
+    dq, dcoef = ops.xattn_backward(q.to(dev), packed, ops.mask_bits(mask).to(dev), coef.to(dev), dout.to(dev), scale)
     torch.cuda.synchronize()
     dq, dcoef = dq.float().cpu().double(), dcoef.cpu().double()
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
@@ -103,7 +103,7 @@ def test_autograd_function_roundtrip():
     packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
     qg = q.to(dev).requires_grad_(True)
     W = torch.full((K, 50), 2.5, device=dev, requires_grad=True)   # plms.py:204-209 leaf
-    out = ops.xattn_blend(qg, W[:, 7], packed, mask.to(torch.uint8).to(dev), (C // heads) ** -0.5)
+    out = ops.xattn_blend(qg, W[:, 7], packed, ops.mask_bits(mask).to(dev), (C // heads) ** -0.5)
     out.float().square().sum().backward()
     assert qg.grad is not None and qg.grad.shape == qg.shape
     assert W.grad is not None and W.grad[:, 7].abs().sum() > 0 and W.grad[:, :7].abs().sum() == 0

@@ -26,7 +26,7 @@ def bench_level(N, C, K, heads=8, M=77, iters=200, dtype=torch.bfloat16, bwd=Fal
     k = (torch.randn(K + 2, M, C, generator=g) * 0.78).to(dtype).to(dev)
     v = torch.randn(K + 2, M, C, generator=g).to(dtype).to(dev)
     dim = int(N ** 0.5)
-    mask = ops.disc_masks(CENTRES[:K], dim).to(dev)
+    mask = ops.disc_mask_bits(CENTRES[:K], dim).to(dev)
     coef = torch.full((K,), 5.0 / max(K, 1), device=dev)
     packed = ops.pack_kv(k, v, heads)
     scale = (C // heads) ** -0.5

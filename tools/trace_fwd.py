@@ -2,6 +2,7 @@
 
 Builds csrc/sta_xattn.hip with -DSTA_TRACE into gpurun_out/libsta_trace.so, launches the kernel at the
 four level shapes and prints, per wave of one workgroup, s_memtime deltas (shader cycles) between:
+ (staged kernel: 1 prologue issued | 2 tile bits + local staging issued | 3 DMA landed + barrier | 4 ctx0 done | 5 ctx1 done | 6 all ctx | 8 stores)
  0 start | 1 ctx loop entered (mask known for local waves) | 2 K loads issued | 3 S MFMAs issued |
  4 V loads issued | 5 softmax done | 6 PV done, partial in LDS | 7 after barrier | 8 stores issued
 """
@@ -25,14 +26,14 @@ L = lib.load()
 L.sta_debug_set_trace.restype, L.sta_debug_set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
 
 dev = "cuda"
-for (N, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
+for (N, C) in [(4096, 320), (1024, 640)]:
     K, H, M = 2, 8, 77
     g = torch.Generator().manual_seed(0)
     q = torch.randn(2, N, C, generator=g).bfloat16().to(dev)
     k = torch.randn(K + 2, M, C, generator=g).bfloat16().to(dev)
     v = torch.randn(K + 2, M, C, generator=g).bfloat16().to(dev)
     dim = int(N ** 0.5)
-    mask = ops.disc_masks([(0.3, 0.4), (0.7, 0.6)], dim).to(dev)
+    mask = ops.disc_mask_bits([(0.3, 0.4), (0.7, 0.6)], dim).to(dev)
     coef = torch.full((K,), 2.5, device=dev)
     packed = ops.pack_kv(k, v, H)
     nwg_guess = 0
@@ -43,9 +44,12 @@ for (N, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
         for _ in range(3):
             ops.xattn_forward(q, packed, mask, coef, (C // H) ** -0.5)
         torch.cuda.synchronize()
-        t = tr[8:].cpu().view(4, 16)[:, :9]
+        full = tr[8:].cpu().view(4, 16)
+        wall = (full[:, 14] - full[:, 15]).tolist()     # 100 MHz ticks start -> end
+        t = full[:, :9]
         print("N=%d C=%d wg=%d" % (N, C, wg))
         for w in range(4):
             row = t[w].tolist()
             base = t[:, 0].min().item()
-            print("  wave %d start+%5d :" % (w, row[0] - base), " ".join("%6d" % (row[i] - row[0]) if row[i] else "     -" for i in range(1, 9)))
+            mhz = (row[8] - row[0]) / max(wall[w], 1) * 100 if row[8] else 0
+            print("  wave %d start+%5d (%4d ticks@100MHz => %4.0f MHz):" % (w, row[0] - base, wall[w], mhz), " ".join("%6d" % (row[i] - row[0]) if row[i] else "     -" for i in range(1, 9)))
