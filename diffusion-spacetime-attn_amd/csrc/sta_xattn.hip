@@ -95,6 +95,7 @@ struct Params {
   int N, C, H, d, M, K;
   int ntiles;            // pixel tiles per head
   int ntiles_aux;        // staged forward: contexts that fit LDS at once
+  int head_major;        // 1: block b -> head b % H (= XCD b % 8 when H == 8); 0: XCD-contiguous tile ranges
   float sl2e;            // scale * log2(e)
   float scale;
 };
@@ -305,7 +306,11 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  // Two block -> (tile, head) maps, chosen per level on measured HBM traffic (profiles/r01_pmc_traffic.md):
+  // tile-contiguous ranges per XCD keep the 8 heads of a pixel tile (which share the 128-B lines of the
+  // [N][C] rows) on one L2 but make all 8 L2s fetch the whole K/V image; head-major (block b -> head
+  // b % H, i.e. XCD b % 8 owns head b % 8) fetches each head's image once and re-fetches partial q lines.
+  const int L = p.head_major ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const int tile = L / p.H, h = L % p.H;
   const int N = p.N, C = p.C, d = p.d, K = p.K;
   const int px0 = tile * 16 * QT;
@@ -955,6 +960,10 @@ template <typename T, int NDT, int QT>
 int launch_fwd(const Params& p0, hipStream_t st) {
   Params p = p0;
   p.ntiles = (p.N + 16 * QT - 1) / (16 * QT);
+  // 7 extra copies of the fragment image (one per further XCD) vs the partial-line over-fetch of q
+  // (a head's d*2-byte segment of each row straddles 128-B lines): head-major wins from d = 80 up
+  p.head_major = (p.H % 8 == 0 && NDT >= 5) ? 1 : 0;
+  if (const char* e = getenv("STA_FWD_HEAD_MAJOR")) p.head_major = atoi(e) ? 1 : 0;   // tuning knob
   const int lds = NSLOT * 16 * QT * (p.d + 4) * (int)sizeof(float);
   static bool attr_set = false;  // benign race: idempotent
   if (!attr_set) {

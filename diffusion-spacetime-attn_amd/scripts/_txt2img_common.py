@@ -1,0 +1,103 @@
+"""Shared body of scripts/txt2img-{gpt,mscoco,vsr}.py — the reference's three entry points differ only
+in the dataset they read (scripts/txt2img-gpt.py vs -mscoco.py vs -vsr.py: lines 255-261).
+
+Kept from the reference CLI (txt2img-gpt.py:105-247): --plms --ddim_steps --H --W --C --f --n_samples --scale
+--ddim_eta --fixed_code --config --ckpt --precision --outdir --seed --process_id (+ the flags it parses and
+ignores, accepted for compatibility). Added: --layout (JSON replacing the layout-predictor call),
+--dataset (path override), --opt_epochs (0 = fixed weights), --limit/--start, --dtype, --synthetic.
+With torch.distributed.run the prompts are sharded round-robin over the ranks (one GPU each).
+"""
+import argparse
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+import torch  # noqa: E402
+
+
+def build_parser(default_dataset):
+    p = argparse.ArgumentParser()
+    p.add_argument("--prompt", type=str, nargs="?", default="a painting of a virus monster playing guitar",
+                   help="parsed and ignored, as in the reference (prompts come from the dataset)")
+    p.add_argument("--outdir", type=str, nargs="?", default="outputs/notuse")
+    p.add_argument("--skip_grid", action="store_true")
+    p.add_argument("--skip_save", action="store_true")
+    p.add_argument("--ddim_steps", type=int, default=50)
+    p.add_argument("--plms", action="store_true")
+    p.add_argument("--dpm_solver", action="store_true")
+    p.add_argument("--laion400m", action="store_true")
+    p.add_argument("--fixed_code", action="store_true")
+    p.add_argument("--ddim_eta", type=float, default=0.0)
+    p.add_argument("--n_iter", type=int, default=2)
+    p.add_argument("--H", type=int, default=512)
+    p.add_argument("--W", type=int, default=512)
+    p.add_argument("--C", type=int, default=4)
+    p.add_argument("--f", type=int, default=8)
+    p.add_argument("--n_samples", type=int, default=1)
+    p.add_argument("--n_rows", type=int, default=0)
+    p.add_argument("--scale", type=float, default=7.5)
+    p.add_argument("--from-file", type=str)
+    p.add_argument("--config", type=str, default="configs/stable-diffusion/v1-inference.yaml")
+    p.add_argument("--ckpt", type=str, default="models/ldm/stable-diffusion-v1/model.ckpt")
+    p.add_argument("--seed", type=int, default=42, help="parsed and ignored: the reference uses seed = 1 for every prompt")
+    p.add_argument("--process_id", type=int, default=0)
+    p.add_argument("--precision", type=str, choices=["full", "autocast"], default="autocast")
+    # additions
+    p.add_argument("--dataset", type=str, default=default_dataset)
+    p.add_argument("--layout", type=str, default=None, help="JSON {prompt | index: {object: [x, y]}}")
+    p.add_argument("--opt_epochs", type=int, default=3, help="weight-optimisation epochs (reference: 3; 0 = fixed weights)")
+    p.add_argument("--start", type=int, default=0)
+    p.add_argument("--limit", type=int, default=500)
+    p.add_argument("--dtype", type=str, choices=["bf16", "fp16"], default="bf16")
+    p.add_argument("--synthetic", action="store_true", help="synthetic weights/text embeddings when no checkpoint is available")
+    return p
+
+
+def run(kind, default_dataset):
+    opt = build_parser(default_dataset).parse_args()
+    if not opt.plms:
+        raise SystemExit("only --plms works with the spatial-temporal UNet (DDIM/DPM-Solver call apply_model with the "
+                         "wrong positional arguments in the reference, ddim.py:172-177 vs ddpm.py:1420)")
+    if opt.n_samples != 1:
+        raise SystemExit("--n_samples must be 1 (the blocks reshape to the CFG batch of 2, attention.py:282)")
+    from ldm.models.diffusion.plms import PLMSSampler
+    from sta import datasets, parallel
+    from sta.pipeline import build_sd_v1, conditionings
+
+    rank, world, local = parallel.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("a GPU is required (the fused cross-attention has no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float16
+
+    prompts = datasets.load_prompts(opt.dataset, kind, opt.limit)
+    layouts = datasets.load_layouts(opt.layout) if opt.layout else None
+    ckpt = opt.ckpt if (os.path.exists(opt.ckpt) and not opt.synthetic) else None
+    if ckpt is None and not opt.synthetic:
+        raise SystemExit("checkpoint %s not found (pass --synthetic to run with synthetic weights)" % opt.ckpt)
+    model = build_sd_v1(dev, dtype, ckpt=ckpt if rank == 0 else None, init_weights=(rank == 0), use_checkpoint=opt.opt_epochs > 1)
+    parallel.broadcast_module_(model)                                   # one RCCL broadcast of the frozen weights
+    sampler = PLMSSampler(model, opt_epochs=opt.opt_epochs, loss_model=None)
+    os.makedirs(opt.outdir, exist_ok=True)
+
+    seed = 1                                                            # txt2img-gpt.py:304
+    shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
+    todo = list(enumerate(prompts))[opt.start: opt.start + 500]
+    for j in parallel.shard_indices(len(todo), rank, world):
+        prompt_idx, prompt = todo[j]
+        torch.manual_seed(seed)                                         # seed_everything(seed), :306
+        layout = datasets.layout_for(layouts, prompt, prompt_idx) or {}
+        print("[rank %d] Start inference for %dth prompt: %s" % (rank, prompt_idx, prompt))
+        names = list(layout.keys())
+        uc, c, local_c = conditionings(model, prompt, names, dtype)
+        x_T = torch.randn([opt.n_samples, *shape], device=dev) if opt.fixed_code else None
+        sampler.sample(S=opt.ddim_steps, conditioning=c, batch_size=opt.n_samples, shape=shape, verbose=False,
+                       unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc, eta=opt.ddim_eta, x_T=x_T,
+                       text_index=0, curr_text=prompt, bboxs_curr=[layout[n] for n in names], seed=seed,
+                       prompt_idx=prompt_idx, object_names=names, local_conditionings=local_c)
+    parallel.barrier()
