@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--objects", type=int, default=2)
     ap.add_argument("--no-graph", action="store_true", help="issue the UNet eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nchw", action="store_true", help="keep NCHW activations (default: channels_last / NHWC)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=2, help="timed CPU UNet calls of the baseline sample")
     return ap.parse_args()
@@ -148,7 +149,7 @@ def main():
 
     K, dt = a.objects, torch.bfloat16
     # rank 0 creates the (synthetic) frozen weights; everyone else receives them over RCCL/xGMI
-    model = build_sd_v1(dev, dt, with_vae=True, init_weights=(rank == 0), seed=0)
+    model = build_sd_v1(dev, dt, with_vae=True, init_weights=(rank == 0), seed=0, channels_last=not a.nchw)
     t0 = time.perf_counter()
     nbytes = parallel.broadcast_module_(model)
     torch.cuda.synchronize()

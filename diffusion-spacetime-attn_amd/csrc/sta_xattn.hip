@@ -111,12 +111,20 @@ __device__ long long* g_trace = nullptr;
   long long* trace_base = g_trace;                                                          \
   const bool trace_on = trace_base && blockIdx.x == (unsigned)trace_base[0] && (threadIdx.x & 63) == 0; \
   long long* trace_row = trace_base + 8 + (threadIdx.x >> 6) * 16;                          \
-  if (trace_on) trace_row[15] = (long long)wall_clock64()
+  const long long trace_t0 = (long long)wall_clock64();                                    \
+  if (trace_on) trace_row[15] = trace_t0
 #define STA_T(i)                                                                           \
   do {                                                                                     \
     if (trace_on) __builtin_nontemporal_store((long long)__builtin_readcyclecounter(), trace_row + (i)); \
   } while (0)
-#define STA_T_END() do { if (trace_on) trace_row[14] = (long long)wall_clock64(); } while (0)
+#define STA_T_END()                                                                       \
+  do {                                                                                     \
+    if (trace_on) trace_row[14] = (long long)wall_clock64();                               \
+    if (trace_base && trace_base[1] && threadIdx.x == 0) {                                  \
+      trace_base[128 + 2 * blockIdx.x] = trace_t0;                                         \
+      trace_base[129 + 2 * blockIdx.x] = (long long)wall_clock64();                        \
+    }                                                                                      \
+  } while (0)
 #else
 #define STA_T_INIT() do {} while (0)
 #define STA_T_END() do {} while (0)
@@ -218,6 +226,18 @@ __device__ __forceinline__ void tiles_to_b(const f32x4 (&st)[NKT], typename Tr<T
     }
 }
 
+// Buffer (SRD) loads: one instruction per 16-byte access — per-lane byte offset in a VGPR, the
+// per-fragment offset in an SGPR/immediate — instead of a 64-bit VALU address computation per load.
+// Offsets past `bytes` read as zero, which doubles as the predicate for pixels >= N.
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
+}
+template <typename V8>
+__device__ __forceinline__ V8 srd_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 template <typename T, int NKS>
 __device__ __forceinline__ void load_b_frags(const T* base, bool valid, int g, int d,
                                              typename Tr<T>::V8 (&f)[NKS]) {
@@ -301,8 +321,8 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
-  constexpr bool V_EARLY = NDT <= 6;              // request V fragments with the K fragments?
-  constexpr int ITEMS = (16 * QT * 2 * NDT + 255) / 256;   // combine items per thread (upper bound)
+  constexpr int CHK = 2 * NDT;                    // 8-channel chunks per pixel (compile-time bound; 8*ch < d is checked)
+  constexpr int ITEMS = (16 * QT * CHK + 255) / 256;        // combine items per thread
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -311,7 +331,8 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   // [N][C] rows) on one L2 but make all 8 L2s fetch the whole K/V image; head-major (block b -> head
   // b % H, i.e. XCD b % 8 owns head b % 8) fetches each head's image once and re-fetches partial q lines.
   const int L = p.head_major ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = L / p.H, h = L % p.H;
+  int tile, h;
+  if (p.H == 8) { tile = L >> 3; h = L & 7; } else { tile = L / p.H; h = L % p.H; }   // no integer divide on the hot map
   const int N = p.N, C = p.C, d = p.d, K = p.K;
   const int px0 = tile * 16 * QT;
   const int DP = d + 4;                           // fp32 row stride of a slot: conflict-free b128 writes
@@ -321,48 +342,46 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   STA_T(0);
 
   // ---- prologue: request everything, oldest first ------------------------------------------------
-  // Every load below is UNCONDITIONAL with a clamped (always valid) address and the predicate is
-  // applied to the value afterwards: a guarded load (`cond ? *p : 0`) makes hipcc emit a branch plus
-  // an s_waitcnt per load, i.e. one serialized round trip each.
-  // (a) blend weights (uniform -> scalar loads) and the disc-mask bytes of the tile, one pixel per lane
-  //     (with K == 0 the host points mask/coef at q: readable bytes whose values are never used)
-  float coefv[MAXK], coef_lane;
-  unsigned mbits;                                 // this lane's tile pixel: bit i = inside disc i
-  const int chunks = d >> 3;
-  float wsum[ITEMS];
+  // Every load is UNCONDITIONAL (clamped or bounds-checked address) and the predicate is applied to the
+  // value afterwards: a guarded load (`cond ? *p : 0`) makes hipcc emit a branch plus an s_waitcnt per
+  // load, i.e. one serialized round trip each. With K == 0 the host points mask/coef at q (readable,
+  // ignored). Loads go through buffer descriptors: one instruction each, no per-load 64-bit VALU math.
+  const unsigned row_bytes = (unsigned)C * (unsigned)sizeof(T);
+  const __amdgpu_buffer_rsrc_t q_srd = make_srd(p.q, 2u * (unsigned)N * row_bytes);
+  const __amdgpu_buffer_rsrc_t kv_srd = make_srd(p.packed + (size_t)h * all_frags(NDT) * FRAG,
+                                                 (unsigned)(K + 2) * (unsigned)p.H * all_frags(NDT) * FRAG);
+  const unsigned ctx_stride = (unsigned)p.H * all_frags(NDT) * FRAG;
+
+  // (a) blend weights: ONE vector load (lane i holds coef[i]) — a scalar load per object would be K
+  //     serialized scalar-cache round trips; (b) mask bits of the tile pixels (lane <-> pixel) and of
+  //     this thread's epilogue items
+  float coefv[MAXK];
+  const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
+  unsigned mbits = p.mask[min(px0 + lane, N - 1)];
   unsigned mi[ITEMS];
-  {
-    // one vector load for all weights (lane i holds coef[i]); a scalar load per object would be
-    // s_load + s_waitcnt each, i.e. K serialized scalar-cache round trips
-    coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
-    mbits = p.mask[min(px0 + lane, N - 1)];
-    // (b) epilogue bookkeeping: this thread's (pixel, 8-channel chunk) items need sum_i coef_i mask_i
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) mi[j] = p.mask[min(px0 + (int)(threadIdx.x + 256 * j) / chunks, N - 1)];
-  }
+  for (int j = 0; j < ITEMS; ++j) mi[j] = p.mask[min(px0 + (int)(threadIdx.x + 256 * j) / CHK, N - 1)];
 
-  const size_t ctx_stride = (size_t)p.H * all_frags(NDT) * FRAG;
-  const char* img_h = p.packed + (size_t)h * all_frags(NDT) * FRAG;
-
-  // (c) operands of this wave's first context (speculative for local contexts)
+  // (c) operands of this wave's first context (speculative for local contexts). Q: B operand, 16 B per
+  //     lane at d-offset 32s + 8g of its pixel row; K/V: fragment f at byte f*1024 + lane*16 of the image
   V8 qf[QT][NKS], ka[NKF], va[NVF];
-  bool valid[QT];
   int c = wv;
   auto request = [&](int cc) {
-    const int row = cc == 0 ? 0 : 1;
-    const V8* frag = (const V8*)(img_h + (size_t)cc * ctx_stride) + lane;   // fragment f at frag[f*64]
+    const unsigned qrow = cc == 0 ? 0u : (unsigned)N * row_bytes;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const int px = px0 + 16 * qt + c16;
-      valid[qt] = px < N;
-      load_b_frags<T, NKS>((const T*)p.q + ((size_t)row * N + px) * C + h * d, valid[qt], g, d, qf[qt]);
-    }
+      // pixels >= N and head-dim offsets >= d are pushed out of the descriptor's range -> read as 0
+      const unsigned base = px < N ? (unsigned)px * row_bytes + (unsigned)(h * d + 8 * g) * (unsigned)sizeof(T) : 0xfffffff0u;
 #pragma unroll
-    for (int f = 0; f < NKF; ++f) ka[f] = frag[f * 64];
-    if (V_EARLY) {
-#pragma unroll
-      for (int f = 0; f < NVF; ++f) va[f] = frag[(NKF + f) * 64];
+      for (int s = 0; s < NKS; ++s)
+        qf[qt][s] = srd_load16<V8>(q_srd, (32 * s + 8 * g < d) ? base : 0xfffffff0u, qrow + 64u * s);
     }
+    const unsigned cbase = (unsigned)cc * ctx_stride;
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) ka[f] = srd_load16<V8>(kv_srd, lane * 16, cbase + f * FRAG);
+#pragma unroll
+    for (int f = 0; f < NVF; ++f) va[f] = srd_load16<V8>(kv_srd, lane * 16, cbase + (NKF + f) * FRAG);
   };
   if (c < K + 2) request(c);
   __builtin_amdgcn_sched_barrier(0);
@@ -371,6 +390,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
   // first consumers of the (oldest) mask loads: which discs touch this tile — every wave computes the
   // same answer, so no LDS flag and no barrier — and the epilogue's per-item weight sums
   unsigned tile_bits = 0;
+  float wsum[ITEMS];
   {
     const bool in_tile = lane < 16 * QT && px0 + lane < N;
     mbits = in_tile ? (mbits & ((1u << K) - 1u)) : 0u;
@@ -407,13 +427,6 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
 #pragma unroll
           for (int qt = 0; qt < QT; ++qt) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
       STA_T(3);
-      if (!V_EARLY) {   // large head dims: V fragments are requested once the K registers are free
-        const V8* frag = (const V8*)(img_h + (size_t)c * ctx_stride) + lane;
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int f = 0; f < NVF; ++f) va[f] = frag[(NKF + f) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-      }
       STA_T(4);
 
       float wc[QT];
@@ -421,7 +434,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         const float inv = softmax_keys_fast(st[qt], g, p.M, p.sl2e);
-        if (p.aux && valid[qt]) {
+        if (p.aux && px0 + 16 * qt + c16 < N) {
           float* mrow = p.aux + (((size_t)c * p.H + h) * N + (px0 + 16 * qt + c16)) * p.M;
 #pragma unroll
           for (int t = 0; t < NKT; ++t)
@@ -434,7 +447,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
         tiles_to_b<T>(st[qt], pb[qt]);
         wc[qt] = inv;
         if (c >= 2) {   // this context's blend weight for the lane's pixel: coef_i * mask_i(px)
-          const unsigned m = ((unsigned)__shfl((int)mbits, 16 * qt + c16) >> (c - 2)) & 1u;
+          const unsigned m = ((unsigned)__shfl((int)mbits, 16 * qt + c16) >> (c - 2)) & 1u;   // 0 for pixels >= N
           float cw = 0.f;
 #pragma unroll
           for (int i = 0; i < MAXK; ++i) cw = (i == c - 2) ? coefv[i] : cw;
@@ -491,9 +504,9 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
     const int it = threadIdx.x + 256 * j;
-    const int pl = it / chunks, ch = it - pl * chunks;
+    const int pl = it / CHK, ch = it - pl * CHK;
     const int px = px0 + pl;
-    if (it >= 16 * QT * chunks || px >= N) continue;
+    if (pl >= 16 * QT || 8 * ch >= d || px >= N) continue;
     const float* s0 = slots + pl * DP + 8 * ch;
     float au[8], o1[8];
 #pragma unroll

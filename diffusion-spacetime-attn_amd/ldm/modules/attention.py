@@ -180,8 +180,10 @@ class SpatialTransformer(nn.Module):
 
     def forward(self, x, context=None, time=None, text_index=None, coef=None, bboxs_curr=None):
         b, c, h, w = x.shape
-        t = self.proj_in(self.norm(x)).flatten(2).transpose(1, 2)          # 'b c h w -> b (h w) c'
+        t = self.proj_in(self.norm(x))
+        # 'b c h w -> b (h w) c': a free view when the activation is channels_last (NHWC in memory)
+        t = t.permute(0, 2, 3, 1).reshape(b, h * w, -1)
         for blk in self.transformer_blocks:
             t = blk(t, context=context, time=time, text_index=text_index, coef=coef, bboxs_curr=bboxs_curr)
-        t = t.transpose(1, 2).reshape(b, -1, h, w)
+        t = t.reshape(b, h, w, -1).permute(0, 3, 1, 2)          # back to [b, c, h, w] without a copy (NHWC strides)
         return self.proj_out(t) + x

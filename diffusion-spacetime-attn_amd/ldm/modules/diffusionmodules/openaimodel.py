@@ -163,6 +163,8 @@ class UNetModel(nn.Module):
         emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).to(wdtype))
         time = timesteps[0]
         h, skips = x.to(wdtype), []
+        if self.input_blocks[0][0].weight.is_contiguous(memory_format=torch.channels_last) and h.is_cuda:
+            h = h.contiguous(memory_format=torch.channels_last)       # NHWC pipeline (sta.pipeline.build_sd_v1)
         for module in self.input_blocks:
             h = module(h, emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
             skips.append(h)

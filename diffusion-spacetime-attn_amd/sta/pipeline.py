@@ -20,7 +20,7 @@ DEFAULT_CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]      # 
 
 
 def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae=True, use_checkpoint=False,
-                init_weights=True, unet_overrides=None):
+                init_weights=True, unet_overrides=None, channels_last=True):
     cfg = dict(SD_V1_UNET, use_checkpoint=use_checkpoint)
     cfg.update(unet_overrides or {})
     # parameters are created on the meta device (no default init of 0.9 G values) and materialised
@@ -33,6 +33,13 @@ def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae
         vae = vae.to(dtype).to_empty(device=device)
     text = SyntheticTextEmbedder().to(device)
     model = LatentDiffusion(unet_config=unet, first_stage_config=vae, cond_stage_config=text).to(device)
+    if channels_last and torch.device(device).type == "cuda":
+        # NHWC activations and weights: MIOpen's bf16 convolutions are NHWC kernels (the NCHW path wraps each
+        # of them in two transposes) and the b c h w <-> b (hw) c reshapes around the transformer blocks
+        # become views
+        unet.to(memory_format=torch.channels_last)
+        if vae is not None:
+            vae.to(memory_format=torch.channels_last)
     model.eval()
     for p in model.parameters():
         p.requires_grad_(False)      # frozen: the optimisation variable is the weights tensor only (plms.py:214)

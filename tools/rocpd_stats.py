@@ -21,7 +21,7 @@ def stats(path):
     return list(c.execute(q)), cols
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--breakdown"):
     print("kernel,calls,total_ns,avg_ns,min_ns,max_ns,grid_x,wg_x")
     for p in sys.argv[1:]:
         rows, _ = stats(p)
@@ -41,3 +41,48 @@ def pmc_stats(path):
          "join %s s on d.kernel_id = s.id join %s i on e.pmc_id = i.id group by s.%s, d.grid_size_x, i.name order by 5 desc"
          % (name_col, pe, kd, ks, ip, name_col))
     return list(c.execute(q))
+
+
+def category(n):
+    if "naive_conv" in n:
+        return "miopen-find (naive conv, warm-up only)"
+    if "xattn" in n or "pack_kv" in n or "dcoef_reduce" in n:
+        return "sta xattn (ours)"
+    if "attn_fwd" in n or "attention" in n.lower():
+        return "SDPA self-attention"
+    if "igemm" in n or "conv" in n.lower():
+        return "conv (MIOpen/CK)"
+    if "Cijk" in n or "gemm" in n.lower():
+        return "GEMM (hipBLASLt/rocBLAS)"
+    if "RowwiseMoments" in n or "GroupNorm" in n or "group_norm" in n or "ComputeFused" in n:
+        return "GroupNorm"
+    if "layer_norm" in n.lower():
+        return "LayerNorm"
+    if "transpose" in n.lower():
+        return "transpose (layout)"
+    if "SubTensor" in n or "OpTensor" in n:
+        return "MIOpen tensor ops (bias add ...)"
+    if "elementwise" in n.lower() or "copy" in n.lower():
+        return "elementwise / copy (aten)"
+    return "other"
+
+
+def breakdown(path, top=12):
+    import collections
+    rows, _ = stats(path)
+    t, c = collections.Counter(), collections.Counter()
+    for r in rows:
+        t[category(r[0])] += r[2]
+        c[category(r[0])] += r[1]
+    tot = sum(v for k, v in t.items() if "warm-up" not in k)
+    print("category,total_ms,calls,share_of_steady_state")
+    for k, v in t.most_common():
+        print("%s,%.1f,%d,%.1f%%" % (k, v / 1e6, c[k], 100.0 * v / tot))
+    print("--- top kernels (steady state)")
+    for r in [r for r in rows if "naive_conv" not in r[0]][:top]:
+        print("%.1f ms  %6d calls  avg %.1f us  grid %s  %s" % (r[2] / 1e6, r[1], r[3] / 1e3, r[6], r[0][:120]))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--breakdown":
+    breakdown(sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 12)
+    sys.exit(0)
