@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--nchw", action="store_true", help="keep NCHW activations (default: channels_last / NHWC)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=2, help="timed CPU UNet calls of the baseline sample")
+    ap.add_argument("--opt-epochs", type=int, default=0,
+                    help="weight-optimisation epochs (0 = fixed weights = BASELINE configs[1], the headline; 3 = configs[2] "
+                         "with a CLIP stand-in loss, reported as a side measurement)")
     return ap.parse_args()
 
 
@@ -149,7 +152,8 @@ def main():
 
     K, dt = a.objects, torch.bfloat16
     # rank 0 creates the (synthetic) frozen weights; everyone else receives them over RCCL/xGMI
-    model = build_sd_v1(dev, dt, with_vae=True, init_weights=(rank == 0), seed=0, channels_last=not a.nchw)
+    model = build_sd_v1(dev, dt, with_vae=True, init_weights=(rank == 0), seed=0, channels_last=not a.nchw,
+                        use_checkpoint=a.opt_epochs > 1)
     t0 = time.perf_counter()
     nbytes = parallel.broadcast_module_(model)
     torch.cuda.synchronize()
@@ -159,7 +163,12 @@ def main():
     mine = parallel.shard_indices(len(prompts), rank, world)
     lat = a.res // 8
     centres = [list(c) for c in DEFAULT_CENTRES[:K]]
-    sampler = PLMSSampler(model, opt_epochs=0, use_graph=not a.no_graph, save_images=False)
+    loss_model = None
+    if a.opt_epochs > 0:
+        from ldm.models.diffusion.plms import DCLIPLoss
+        from sta.synth import SyntheticCLIP
+        loss_model = DCLIPLoss(SyntheticCLIP().to(dev))
+    sampler = PLMSSampler(model, opt_epochs=a.opt_epochs, loss_model=loss_model, use_graph=not a.no_graph, save_images=False)
 
     def one_image(j):
         rec = prompts[mine[j % len(mine)]]
@@ -193,7 +202,9 @@ def main():
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "SD-v1-4 UNet+VAE (synthetic weights), %dx%d, %d PLMS steps (%d CFG UNet calls), %d objects, "
-                               "fixed blend weights (BASELINE configs[1])" % (a.res, a.res, a.ddim_steps, a.ddim_steps + 1, K),
+                               "%s" % (a.res, a.res, a.ddim_steps, a.ddim_steps + 1, K,
+                                       "fixed blend weights (BASELINE configs[1])" if a.opt_epochs == 0 else
+                                       "%d weight-optimisation epochs, CLIP stand-in loss (BASELINE configs[2])" % a.opt_epochs),
                    "global_batch": world, "prompts": "first 64 of datasets/mscoco.txt, sharded i %% %d" % world,
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes},

@@ -61,3 +61,28 @@ def device_fill_(module, seed=0):
             else:
                 n = 0.05 * n
             t.copy_(n.to(t.dtype))
+
+
+class SyntheticCLIP(torch.nn.Module):
+    """Stand-in for the third-party CLIP ViT-B/32 the reference's fidelity loss calls (plms.py:21-45):
+    same interface (`encode_image([1,3,224,224])`, `encode_text(str)`, 512-d features), tiny frozen
+    random weights. It exists so that the gradient path loss -> VAE decoder -> 51 UNet calls -> blend
+    weights can be exercised and timed without CLIP weights; it says nothing about image quality."""
+
+    def __init__(self, dim=512, seed=0):
+        super().__init__()
+        self.patch = torch.nn.Conv2d(3, 256, kernel_size=32, stride=32)
+        self.proj = torch.nn.Linear(256, dim)
+        self.dim = dim
+        seeded_fill_(self, seed)
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    def encode_image(self, image):
+        w = self.patch.weight
+        f = self.patch(image.to(w.dtype)).flatten(2).mean(-1)
+        return self.proj(torch.nn.functional.gelu(f))
+
+    def encode_text(self, text):
+        rng = np.random.Generator(np.random.PCG64([7, zlib.crc32(str(text).encode("utf-8"))]))
+        return torch.from_numpy(rng.standard_normal((1, self.dim), dtype=np.float32)).to(self.proj.weight.device)

@@ -16,7 +16,7 @@ def _case(N, C, heads, K, dtype, seed=0, M=77, centres=None, dev="cuda"):
     v = torch.randn(K + 2, M, C, generator=g)
     dim = int(math.isqrt(N))
     if dim * dim == N and K > 0:
-        centres = centres or [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)][:K]
+        centres = centres or [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75), (0.05, 0.95), (0.9, 0.1), (0.5, 0.5), (0.0, 0.0)][:K]
         mask = orc.disc_masks(centres, dim)
     else:
         mask = torch.rand(K, N, generator=g) < 0.3
@@ -46,6 +46,11 @@ SHAPES = [
     (144, 640, 8, 4),    # 768^2 mid-ish N not multiple of 64, K = 4
     (100, 128, 4, 3),    # ragged N (not multiple of 16), d = 32
     (256, 192, 8, 0),    # no objects
+    (9216, 320, 8, 4),   # BASELINE configs[4]: 768^2 level 0, 4 objects (staged kernel, 6 contexts in LDS)
+    (2304, 640, 8, 4),   # 768^2 level 1
+    (576, 1280, 8, 4),   # 768^2 level 2
+    (1024, 320, 8, 8),   # K = 8 (maximum): wave w attends contexts w, w+4, w+8
+    (4096, 384, 8, 6),   # d = 48, 8 contexts: the staged kernel needs two LDS groups
 ]
 
 
@@ -91,8 +96,36 @@ def test_bwd_matches_oracle(N, C, heads, K, dtype):
     err = (dq - qd.grad).abs().max().item()
     assert err <= 6 * eps * gscale + 1e-6, (err, gscale)
     if K:
-        rel = ((dcoef - cd.grad).abs() / (cd.grad.abs() + 1e-3 * math.sqrt(N * C))).max().item()
-        assert rel < 2e-2, (dcoef, cd.grad)
+        # dcoef_i sums N*C signed products of 16-bit-rounded factors: 2 % relative + 0.5 % of the largest component
+        g = cd.grad
+        tol = 0.02 * g.abs() + 0.005 * g.abs().max() + 1e-4 * math.sqrt(N * C)
+        assert ((dcoef - g).abs() <= tol).all(), (dcoef, g)
+
+
+def test_domain_properties_full_size():
+    """Size-independent properties at the BASELINE level-0 shape (N=4096, C=320, K=2):
+    (1) coef = 0 or empty discs -> plain attention of both rows; (2) out[1] is affine in coef;
+    (3) swapping the two objects (contexts, mask bits, weights together) changes nothing;
+    (4) out[0] does not depend on masks/weights at all."""
+    from sta import ops
+    N, C, heads, K = 4096, 320, 8, 2
+    q, k, v, mask, coef = _case(N, C, heads, K, torch.bfloat16, seed=5)
+    dev, scale = "cuda", (C // heads) ** -0.5
+    packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
+    mb = ops.mask_bits(mask).to(dev)
+    run = lambda pk, m, c: ops.xattn_forward(q.to(dev), pk, m, c.to(dev), scale)[0].float()
+    base = run(packed, mb, coef)
+    plain = ops.xattn_forward(q.to(dev), ops.pack_kv(k[:2].to(dev), v[:2].to(dev), heads), None, None, scale)[0].float()
+    assert torch.equal(run(packed, mb, torch.zeros(K)), plain)                       # (1) zero weights
+    assert torch.equal(run(packed, torch.zeros_like(mb), coef), plain)                # (1) empty discs
+    assert torch.equal(base[0], plain[0])                                             # (4)
+    o1, o2, o3 = run(packed, mb, coef), run(packed, mb, 2 * coef), run(packed, mb, 3 * coef)
+    assert ((o3 - o2) - (o2 - o1)).abs().max() <= 0.02 * (o2 - o1).abs().max() + 2 ** -6      # (2) up to output rounding
+    perm = [0, 1, 3, 2]
+    packed_sw = ops.pack_kv(k[perm].to(dev), v[perm].to(dev), heads)
+    mb_sw = ops.mask_bits(mask[[1, 0]]).to(dev)
+    sw = run(packed_sw, mb_sw, coef[[1, 0]])
+    assert (sw - base).abs().max() <= 2 ** -6 * (1 + base.abs().max())                # (3) up to summation order
 
 
 def test_autograd_function_roundtrip():

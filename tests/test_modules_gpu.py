@@ -149,6 +149,38 @@ def test_plms_trajectory_fp16_vs_reference_golden_and_graph_matches_eager():
     assert (a - b).abs().max() > 0.05 * a.abs().max()       # the second prompt really used its own K/V and masks
 
 
+def test_weight_optimisation_on_gpu():
+    """BASELINE configs[2] in miniature: 2 epochs x 6 PLMS steps through the HIP forward AND backward
+    kernels, block recomputation, the VAE decoder and the CLIP-loss front end (CLIP itself is a stand-in).
+    The first Adam step moves every weight by exactly lr = 5e-3 (its sign is the sign of the gradient)."""
+    from ldm.models.autoencoder import AutoencoderKL
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import DCLIPLoss, PLMSSampler
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from sta.synth import SyntheticCLIP
+    meta = json.load(open(os.path.join(G, "unet_state_dict_keys.json")))
+    unet = UNetModel(**dict(meta["cfg"], use_checkpoint=True)).eval()
+    seeded_fill_(unet, 21)
+    vae = AutoencoderKL(ddconfig=dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32,
+                                      ch_mult=[1, 2, 4, 4], num_res_blocks=1, attn_resolutions=[], dropout=0.0))
+    seeded_fill_(vae, 3)
+    model = LatentDiffusion(unet_config=unet.to(torch.bfloat16), first_stage_config=vae.to(torch.bfloat16)).cuda()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    c, local_ctx, x_T = gi.unet_inputs(2, 6)
+    sampler = PLMSSampler(model, loss_model=DCLIPLoss(SyntheticCLIP().cuda()), opt_epochs=2, save_images=False)
+    sampler.sample(S=6, conditioning=c.cuda(), batch_size=1, shape=[4, 32, 32], verbose=False, unconditional_guidance_scale=7.5,
+                   unconditional_conditioning=gi.load_uncond().cuda(), x_T=x_T.cuda(), text_index=0, curr_text="two things",
+                   bboxs_curr=[[0.3, 0.4], [0.7, 0.6]], seed=1, prompt_idx=0, object_names=["The cat", "dog"],
+                   local_conditionings=[l.cuda() for l in local_ctx])
+    r = sampler.last_result
+    assert len(r["losses"]) == 1 and r["image"].shape == (1, 3, 256, 256) and torch.isfinite(r["x0"]).all()
+    # Adam's first step is lr * g / (|g| + 1e-8): exactly lr = 5e-3 unless a gradient is ~1e-8 small
+    step = (r["W"] - 2.5).abs()
+    assert (step > 0).all() and (step <= 0.005 + 1e-5).all(), step
+    assert (step > 0.0049).float().mean() >= 0.8, step
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
