@@ -546,22 +546,22 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
 // LDS fragment reads are hoisted into registers ahead of the MFMAs for the same reason the global
 // loads are in the other kernel. Contexts 0/1 are requested before the disc mask is known; local
 // contexts right after the tile test. If the contexts do not fit LDS at once they go in groups.
-template <typename T, int NDT>
+template <typename T, int NDT, int QT>
 __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NVF = NPS * NDT, NFWD = NKF + NVF;
   constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
+  constexpr int TP = 64 * QT;                     // pixels per workgroup: 4 waves x QT tiles x 16
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = L / p.H, h = L % p.H;
+  int tile, h;
+  if (p.H == 8) { tile = L >> 3; h = L & 7; } else { tile = L / p.H; h = L % p.H; }
   const int N = p.N, C = p.C, d = p.d, K = p.K;
-  const int px0 = tile * 64;
-  const int px = px0 + wv * 16 + c16;
-  const bool valid = px < N;
+  const int px0 = tile * TP;
   const int G = p.ntiles_aux;                     // contexts that fit LDS at once (>= 2)
   STA_T_INIT();
   STA_T(0);
@@ -571,34 +571,62 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params p) {
 
   // ---- prologue: oldest first — mask bits / weights, fragments of contexts 0 and 1, Q ------------
   const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
-  unsigned tbits = p.mask[min(px0 + lane, N - 1)];          // lane <-> pixel of the 64-pixel tile
+  unsigned tb[QT];                                 // lane <-> pixel px0 + 64*j + lane of the tile
+#pragma unroll
+  for (int j = 0; j < QT; ++j) tb[j] = p.mask[min(px0 + 64 * j + lane, N - 1)];
   stage_frags(img_h, smem, NFWD, wv, 4, lane);
   stage_frags(img_h + ctx_stride, smem + CB, NFWD, wv, 4, lane);
-  const T* qbase = (const T*)p.q + (size_t)px * C + h * d;
-  V8 q0[NKS], q1[NKS];
-  load_b_frags<T, NKS>(qbase, valid, g, d, q0);
-  load_b_frags<T, NKS>(qbase + (size_t)N * C, valid, g, d, q1);
+  // this wave's QT pixel tiles: pixels px0 + (wv*QT + qt)*16 + c16, rows 0 (uncond) and 1 (cond) of Q
+  V8 q0[QT][NKS], q1[QT][NKS];
+  bool valid[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int px = px0 + (wv * QT + qt) * 16 + c16;
+    valid[qt] = px < N;
+    const T* qbase = (const T*)p.q + (size_t)px * C + h * d;
+    load_b_frags<T, NKS>(qbase, valid[qt], g, d, q0[qt]);
+    load_b_frags<T, NKS>(qbase + (size_t)N * C, valid[qt], g, d, q1[qt]);
+  }
   __builtin_amdgcn_sched_barrier(0);
   STA_T(1);
 
-  tbits = (px0 + lane < N) ? (tbits & ((1u << K) - 1u)) : 0u;
-  unsigned tile_bits = 0, wave_bits = 0;
+  unsigned tile_bits = 0, wave_bits = 0, mybits[QT];
   float coefv[MAXK];
+#pragma unroll
+  for (int j = 0; j < QT; ++j) tb[j] = (px0 + 64 * j + lane < N) ? (tb[j] & ((1u << K) - 1u)) : 0u;
 #pragma unroll
   for (int i = 0; i < MAXK; ++i) {
     coefv[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
     if (i < K) {
-      const unsigned long long b = __ballot((tbits >> i) & 1u);
-      if (b) tile_bits |= 1u << i;
-      if ((b >> (16 * wv)) & 0xffffull) wave_bits |= 1u << i;
+#pragma unroll
+      for (int j = 0; j < QT; ++j) {
+        const unsigned long long bl = __ballot((tb[j] >> i) & 1u);       // pixels 64j .. 64j+63 of the tile
+        if (bl) tile_bits |= 1u << i;
+        // this wave's pixels are 16*QT*wv .. +16*QT-1 of the tile: the part of them inside chunk j
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          const int first = (wv * QT + qt) * 16;                         // tile-relative
+          if ((first >> 6) == j && ((bl >> (first & 63)) & 0xffffull)) wave_bits |= 1u << i;
+        }
+      }
     }
   }
-  const unsigned mybits = (unsigned)__shfl((int)tbits, 16 * wv + c16);   // this lane's own pixel
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {                // mask bits of this lane's own pixel in tile qt
+    const int rel = (wv * QT + qt) * 16 + c16;
+    unsigned v = 0;
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+      const unsigned cand = (unsigned)__shfl((int)tb[j], rel & 63);
+      v = ((rel >> 6) == j) ? cand : v;
+    }
+    mybits[qt] = v;
+  }
   if (p.aux) { tile_bits = (1u << K) - 1u; wave_bits = tile_bits; }      // parity mode: every map
 
-  // active contexts in order: 0, 1, then the local ones whose disc touches the tile (WG-uniform)
+  // active contexts in order: 0, 1, then the local ones whose disc touches the tile (WG-uniform);
   // entry e of the list sits in LDS slot e % G
-  int n_active = 2 + __builtin_popcount(tile_bits);
+  const int n_active = 2 + __builtin_popcount(tile_bits);
   auto ctx_of = [&](int e) {                      // e-th active context
     if (e < 2) return e;
     unsigned rest = tile_bits;
@@ -609,7 +637,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params p) {
     stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + e * CB, NFWD, wv, 4, lane);
 
   STA_T(2);
-  f32x4 au[NDT], ac[NDT];
+  f32x4 au[QT][NDT], ac[QT][NDT];
   for (int e0 = 0; e0 < n_active; e0 += G) {
     if (e0 > 0) {   // next group: everyone is done reading the previous one
       __syncthreads();
@@ -622,56 +650,75 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params p) {
       const int c = ctx_of(e);
       if (e == 1) STA_T(4);
       if (e == 2) STA_T(5);
-      if (c >= 2 && !((wave_bits >> (c - 2)) & 1u)) continue;   // none of this wave's 16 pixels inside
+      if (c >= 2 && !((wave_bits >> (c - 2)) & 1u)) continue;   // none of this wave's pixels inside
       const V8* fr = (const V8*)(smem + (e - e0) * CB) + lane;
-      // LDS -> registers for the whole context, then MFMAs (no ds_read -> wait -> mfma chains)
+      // LDS -> registers for the whole context, then MFMAs (no ds_read -> wait -> mfma chains); each
+      // fragment serves QT pixel tiles, whose independent softmax chains interleave
       V8 ka[NKF], va[NVF];
 #pragma unroll
       for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
 #pragma unroll
       for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
-      f32x4 st[NKT];
+      f32x4 st[QT][NKT];
 #pragma unroll
-      for (int t = 0; t < NKT; ++t) {
-        st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) st[t] = Tr<T>::mfma(ka[t * NKS + s], c == 0 ? q0[s] : q1[s], st[t]);
-      }
-      const float inv = softmax_keys_fast(st, g, p.M, p.sl2e);
-      if (p.aux && valid) {
-        float* mrow = p.aux + (((size_t)c * p.H + h) * N + px) * p.M;
+        for (int t = 0; t < NKT; ++t) st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < NKT; ++t)
+      for (int t = 0; t < NKT; ++t)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = 16 * t + 4 * g + r;
-            if (key < p.M) mrow[key] = st[t][r] * inv;
-          }
-      }
-      V8 pb[NPS];
-      tiles_to_b<T>(st, pb);
-      float w = inv;
-      if (c >= 2) {
-        float cw = 0.f;
+        for (int s = 0; s < NKS; ++s)
 #pragma unroll
-        for (int i = 0; i < MAXK; ++i) cw = (i == c - 2) ? coefv[i] : cw;
-        w = ((mybits >> (c - 2)) & 1u) ? cw : 0.f;
+          for (int qt = 0; qt < QT; ++qt)
+            st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], c == 0 ? q0[qt][s] : q1[qt][s], st[qt][t]);
+      float inv[QT], w[QT];
+      V8 pb[QT][NPS];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        inv[qt] = softmax_keys_fast(st[qt], g, p.M, p.sl2e);
+        if (p.aux && valid[qt]) {
+          float* mrow = p.aux + (((size_t)c * p.H + h) * N + (px0 + (wv * QT + qt) * 16 + c16)) * p.M;
+#pragma unroll
+          for (int t = 0; t < NKT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = 16 * t + 4 * g + r;
+              if (key < p.M) mrow[key] = st[qt][t][r] * inv[qt];
+            }
+        }
+        tiles_to_b<T>(st[qt], pb[qt]);
+        w[qt] = inv[qt];
+        if (c >= 2) {
+          float cw = 0.f;
+#pragma unroll
+          for (int i = 0; i < MAXK; ++i) cw = (i == c - 2) ? coefv[i] : cw;
+          w[qt] = ((mybits[qt] >> (c - 2)) & 1u) ? cw : 0.f;
+        }
       }
 #pragma unroll
       for (int u = 0; u < NDT; ++u) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[QT];
 #pragma unroll
-        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[s], acc);
-        if (c == 0) au[u] = acc * inv;
-        else if (c == 1) ac[u] = acc * inv;
-        else ac[u] += w * (acc * inv - au[u]);
+        for (int qt = 0; qt < QT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NPS; ++s)
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) acc[qt] = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc[qt]);
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+          if (c == 0) au[qt][u] = acc[qt] * inv[qt];
+          else if (c == 1) ac[qt][u] = acc[qt] * inv[qt];
+          else ac[qt][u] += w[qt] * (acc[qt] * inv[qt] - au[qt][u]);
+        }
       }
     }
   }
 
   STA_T(6);
-  if (valid) {
-    T* obase = (T*)p.out + (size_t)px * C + h * d;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    if (!valid[qt]) continue;
+    T* obase = (T*)p.out + (size_t)(px0 + (wv * QT + qt) * 16 + c16) * C + h * d;
 #pragma unroll
     for (int u = 0; u < NDT; ++u) {
       const int dd = 16 * u + 4 * g;
@@ -679,8 +726,8 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params p) {
         V4 r0, r1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          r0[r] = (T)au[u][r];
-          r1[r] = (T)ac[u][r];
+          r0[r] = (T)au[qt][u][r];
+          r1[r] = (T)ac[qt][u][r];
         }
         *(V4*)(obase + dd) = r0;
         *(V4*)(obase + (size_t)N * C + dd) = r1;
@@ -990,25 +1037,35 @@ int launch_fwd(const Params& p0, hipStream_t st) {
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd launch: %s", hipGetErrorString(e));
 }
 
-template <typename T, int NDT>
-int launch_fwd_staged(const Params& p0, hipStream_t st) {
+template <typename T, int NDT, int QT>
+int launch_fwd_staged_qt(const Params& p0, hipStream_t st) {
   constexpr int CB = fwd_frags(NDT) * FRAG;
   Params p = p0;
-  p.ntiles = (p.N + 63) / 64;
+  p.ntiles = (p.N + 64 * QT - 1) / (64 * QT);
   int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
   if (G > p.K + 2) G = p.K + 2;
-  if (2 * G * CB <= 150 * 1024 && p.ntiles * p.H > 256) {}  // (two workgroups per CU fit as they are)
   p.ntiles_aux = G;
   const int lds = G * CB;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)xattn_fwd_staged_kernel<T, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)xattn_fwd_staged_kernel<T, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
     attr_set = true;
   }
-  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT>), dim3(p.ntiles * p.H), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT, QT>), dim3(p.ntiles * p.H), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
+}
+
+// 64-pixel workgroups (one tile per wave, two workgroups per CU). The 128-pixel variant (two tiles per wave:
+// half the LDS reads per pixel, one workgroup per CU) measured SLOWER at N=4096 d=40 — 11.9 vs 9.1 us,
+// workgroup lifetime 7.4 vs 6.4 us median — the two softmax chains of a wave do not overlap as hoped;
+// it stays selectable for experiments only.
+template <typename T, int NDT>
+int launch_fwd_staged(const Params& p, hipStream_t st) {
+  int qt = 1;
+  if (const char* e = getenv("STA_FWD_STAGED_QT")) qt = atoi(e) == 2 ? 2 : 1;     // tuning knob
+  return qt == 2 ? launch_fwd_staged_qt<T, NDT, 2>(p, st) : launch_fwd_staged_qt<T, NDT, 1>(p, st);
 }
 
 // Which forward kernel (rocprofv3 kernel durations, K = 2, bf16, MI355X; profiles/r01_kernel_variants.md):
