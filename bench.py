@@ -41,6 +41,8 @@ def parse():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--ddim_steps", type=int, default=50)
     ap.add_argument("--objects", type=int, default=2)
+    ap.add_argument("--images-per-step", type=int, default=1,
+                    help="independent prompts sampled together per step (one CFG batch of 2I per UNet call)")
     ap.add_argument("--no-graph", action="store_true", help="issue the UNet eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nchw", action="store_true", help="keep NCHW activations (default: channels_last / NHWC)")
@@ -52,7 +54,7 @@ def parse():
     return ap.parse_args()
 
 
-def xattn_units(model, K):
+def xattn_units(model, K):  # per image
     """Algorithmic work of the fused forward kernel per launch, per block of the UNet:
     F = 4*M*C*N*(K+2) flop;  Bt = 8*N*C (q in, out; bf16) + 4*(K+2)*M*C (K,V) + K*N (mask) bytes."""
     units = []
@@ -63,40 +65,32 @@ def xattn_units(model, K):
     return units
 
 
-def measure_xattn(model, K, reps=20):
-    """Per-launch duration of the fused forward kernel for the 16 block shapes of one UNet call, each
-    launch bracketed by its own pair of HIP events on the launch stream (torch's current stream IS the
-    stream sta_xattn_fwd is given)."""
+def measure_xattn(run_eager_calls, n_calls=4):
+    """Per-launch duration of the fused forward kernel IN SITU: `run_eager_calls(n)` issues n real CFG UNet
+    calls eagerly while sta.ops brackets every sta_xattn_fwd launch with its own HIP-event pair on the launch
+    stream (torch's current stream is the stream the launch is given). The cost of an empty event pair
+    (marker -> marker) is measured the same way and subtracted, so the figure is comparable with
+    rocprofv3's kernel durations. Returns {(N, C): mean us} and the subtracted overhead."""
     from sta import ops
-    blocks = model.model.diffusion_model.transformer_blocks()
-    dev = next(model.parameters()).device
-    # what an event pair costs by itself (marker -> marker with nothing in between): subtracted below so
-    # that the number is comparable with rocprofv3's kernel durations (dispatch start -> end)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
     for e0, e1 in evs:
         e0.record()
         e1.record()
     torch.cuda.synchronize()
     gaps = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
-    measure_xattn.event_overhead_us = gaps[len(gaps) // 2]
-    per_block = []
-    for blk in blocks:
-        cache = blk._caches[(blk._last_n, K)]
-        c = blk.attn2.to_q.weight.shape[0]
-        q = torch.randn(2, blk._last_n, c, device=dev, dtype=cache.packed.dtype)
-        coef = torch.full((K,), 5.0 / max(K, 1), device=dev) if K else None
-        for _ in range(3):
-            ops.xattn_forward(q, cache.packed, cache.mask, coef, blk.attn2.scale)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        for e0, e1 in evs:
-            e0.record()
-            ops.xattn_forward(q, cache.packed, cache.mask, coef, blk.attn2.scale)
-            e1.record()
+    overhead = gaps[len(gaps) // 2]
+    run_eager_calls(1)                                   # warm the eager path (first launches, allocator)
+    ops.EVENT_LOG = []
+    try:
+        run_eager_calls(n_calls)
         torch.cuda.synchronize()
-        ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
-        t = sum(ts[: max(1, reps // 2)]) / max(1, reps // 2)                     # mean of the faster half (us)
-        per_block.append(max(t - measure_xattn.event_overhead_us, 0.1))
-    return per_block
+        log = ops.EVENT_LOG
+    finally:
+        ops.EVENT_LOG = None
+    per = {}
+    for e0, e1, I, N, C, K in log:
+        per.setdefault((N, C), []).append(max(e0.elapsed_time(e1) * 1e3 - overhead, 0.1))
+    return {k: sum(v) / len(v) for k, v in per.items()}, {k: len(v) for k, v in per.items()}, overhead
 
 
 def cpu_baseline(res, ddim_steps, K, n_calls):
@@ -170,62 +164,94 @@ def main():
         loss_model = DCLIPLoss(SyntheticCLIP().to(dev))
     sampler = PLMSSampler(model, opt_epochs=a.opt_epochs, loss_model=loss_model, use_graph=not a.no_graph, save_images=False)
 
-    def one_image(j):
-        rec = prompts[mine[j % len(mine)]]
-        names = (rec["objects"] + ["object"] * K)[:K]
-        uc, c, local_c = conditionings(model, rec["prompt"], names, dt)
-        g = torch.Generator(device=dev).manual_seed(1)                      # seed = 1 for every prompt (txt2img-gpt.py:304)
-        x_T = torch.randn([1, 4, lat, lat], generator=g, device=dev)
-        sampler.sample(S=a.ddim_steps, conditioning=c, batch_size=1, shape=[4, lat, lat], verbose=False,
-                       unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T, text_index=0,
-                       curr_text=rec["prompt"], bboxs_curr=centres, seed=1, prompt_idx=mine[j % len(mine)],
-                       object_names=names, local_conditionings=local_c)
+    I = a.images_per_step
+    g = torch.Generator(device=dev).manual_seed(1)                          # seed = 1 for every prompt (txt2img-gpt.py:304)
+    x_T1 = torch.randn([1, 4, lat, lat], generator=g, device=dev)
+
+    def one_step(j):
+        """One step = I independent prompts of this rank's shard sampled together (I = 1: the reference's loop body)."""
+        recs = [prompts[mine[(j * I + i) % len(mine)]] for i in range(I)]
+        names = [(r["objects"] + ["object"] * K)[:K] for r in recs]
+        conds = [conditionings(model, r["prompt"], nm, dt) for r, nm in zip(recs, names)]
+        if I == 1:
+            uc, c, local_c = conds[0]
+            sampler.sample(S=a.ddim_steps, conditioning=c, batch_size=1, shape=[4, lat, lat], verbose=False,
+                           unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0, x_T=x_T1, text_index=0,
+                           curr_text=recs[0]["prompt"], bboxs_curr=centres, seed=1, prompt_idx=0, object_names=names[0],
+                           local_conditionings=local_c)
+        else:
+            sampler.sample_batch(S=a.ddim_steps, shape=[4, lat, lat], conditionings=[c[1] for c in conds],
+                                 unconditional_conditionings=[c[0] for c in conds], bboxs=[centres] * I, object_names=names,
+                                 local_conditionings=[c[2] for c in conds], curr_texts=[r["prompt"] for r in recs],
+                                 x_T=x_T1.expand(I, -1, -1, -1), unconditional_guidance_scale=7.5, seed=1)
         return sampler.last_result
 
     for j in range(a.warmup):
-        one_image(j)
+        one_step(j)
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for j in range(a.steps):
-        r = one_image(a.warmup + j)
+        r = one_step(a.warmup + j)
     torch.cuda.synchronize()
     parallel.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(elapsed, dev)
-    assert torch.isfinite(r["x0"]).all() and r["image"] is not None
+    assert torch.isfinite(r["x0"]).all() and r["image"] is not None and r["x0"].shape[0] == I
 
     if rank != 0:
         return
     out = {
-        "metric": "images/sec at 512x512, 50 PLMS steps, 2 objects", "value": world * a.steps / elapsed, "unit": "images/s",
+        "metric": "images/sec at 512x512, 50 PLMS steps, 2 objects", "value": world * a.steps * I / elapsed, "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "SD-v1-4 UNet+VAE (synthetic weights), %dx%d, %d PLMS steps (%d CFG UNet calls), %d objects, "
                                "%s" % (a.res, a.res, a.ddim_steps, a.ddim_steps + 1, K,
                                        "fixed blend weights (BASELINE configs[1])" if a.opt_epochs == 0 else
                                        "%d weight-optimisation epochs, CLIP stand-in loss (BASELINE configs[2])" % a.opt_epochs),
-                   "global_batch": world, "prompts": "first 64 of datasets/mscoco.txt, sharded i %% %d" % world,
+                   "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt, sharded i %% %d" % world,
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes},
     }
     if not a.no_roofline:
+        # in-situ per-launch times of the fused forward kernel: a few real CFG UNet calls issued eagerly
+        from sta import prompt_state
+        rec = prompts[mine[0]]
+        names = (rec["objects"] + ["object"] * K)[:K]
+        uc, c, local_c = conditionings(model, rec["prompt"], names, dt)
+        pair = lambda u, v: torch.stack([u, v], dim=1).reshape(2 * I, *u.shape[1:])
+        c_in = pair(uc.expand(I, -1, -1), c.expand(I, -1, -1)).contiguous()
+        x_in = torch.randn(2 * I, 4, lat, lat, device=dev)
+        t_in = torch.full((2 * I,), 981, device=dev, dtype=torch.long)
+        coef = torch.full((I, K), 5.0 / max(K, 1), device=dev) if I > 1 else torch.full((K,), 5.0 / max(K, 1), device=dev)
+        boxes = [centres] * I if I > 1 else centres
+        prompt_state.begin_prompt([local_c] * I if I > 1 else local_c, first_timestep=981)
+
+        def run_eager_calls(n):
+            with torch.no_grad():
+                for _ in range(n):
+                    model.apply_model_extra(x_in, 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
+
+        per_us, counts, overhead = measure_xattn(run_eager_calls)
         units = xattn_units(model, K)
-        per_block_us = measure_xattn(model, K)
-        byts, flops, us = sum(u["bytes"] for u in units), sum(u["flops"] for u in units), sum(per_block_us)
+        byts = sum(u["bytes"] for u in units) * I                          # algorithmic bytes of one UNet call
+        flops = sum(u["flops"] for u in units) * I
+        us = sum(per_us[(u["N"], u["C"])] for u in units)                  # 16 launches of one UNet call
         n = len(units)
-        achieved = byts / us / 1e3                                       # GB/s over the 16 launches of one UNet call
+        achieved = byts / us / 1e3
         traffic = None
         pmc = os.path.join(REPO, "profiles", "xattn_fwd_hbm_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and I == 1:
             traffic = json.load(open(pmc)).get("bytes_per_launch")
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "xattn_fwd_kernel (fused QK^T+softmax+disc mask+blend+PV), 16 launches per UNet call",
+                           "kernel": "xattn_fwd{,_staged}_kernel (fused QK^T+softmax+disc mask+blend+PV), 16 launches per UNet call, "
+                                     "%d image(s) per launch" % I,
                            "bytes_per_launch": byts / n, "flops_per_launch": flops / n, "avg_launch_us": us / n,
-                           "event_pair_overhead_us_subtracted": round(measure_xattn.event_overhead_us, 2),
+                           "event_pair_overhead_us_subtracted": round(overhead, 2),
+                           "launches_measured": int(sum(counts.values())), "how": "in situ: real eager CFG UNet calls, one HIP-event pair per launch",
                            "mfma_tflops": flops / us / 1e6, "mfma_frac": flops / us / 1e6 / MFMA_PEAK_TFLOPS,
-                           "per_level_us": {"N%d_C%d" % (u["N"], u["C"]): round(t, 2) for u, t in zip(units, per_block_us)}}
+                           "per_level_us": {"N%d_C%d" % k: round(v, 2) for k, v in sorted(per_us.items(), reverse=True)}}
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a.res, a.ddim_steps, K, a.cpu_calls)
     print(json.dumps(out))

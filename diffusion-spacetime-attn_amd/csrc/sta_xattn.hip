@@ -96,11 +96,29 @@ struct Params {
   int ntiles;            // pixel tiles per head
   int ntiles_aux;        // staged forward: contexts that fit LDS at once
   int head_major;        // 1: block b -> head b % H (= XCD b % 8 when H == 8); 0: XCD-contiguous tile ranges
+  int n_img;             // images in this launch (blockIdx.y); every tensor has a leading image axis
   float sl2e;            // scale * log2(e)
   float scale;
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem[];
+
+// Launches cover n_img independent images (prompts) at once: blockIdx.y selects the image and every
+// pointer is advanced to that image's slice ([I][2][N][C] activations, [I][K+2] packed contexts,
+// [I][N] mask bits, [I][K] weights, ...). Scalar arithmetic only.
+template <typename T, int NDT>
+__device__ __forceinline__ Params for_image(const Params& p, int img, size_t aux_per_img) {
+  Params r = p;
+  const size_t act = (size_t)2 * p.N * p.C * sizeof(T);
+  r.q = (const char*)p.q + img * act;
+  r.out = (char*)p.out + img * act;
+  if (p.dout) r.dout = (const char*)p.dout + img * act;
+  r.packed = p.packed + (size_t)img * (p.K + 2) * p.H * all_frags(NDT) * FRAG;
+  r.mask = p.mask + (size_t)img * p.N;
+  r.coef = p.coef + (size_t)img * p.K;
+  if (p.aux) r.aux = p.aux + img * aux_per_img;
+  return r;
+}
 
 // Optional in-kernel timeline (build with -DSTA_TRACE, tools/trace_fwd.py): lane 0 of every wave of
 // workgroup `STA_TRACE_WG` stores s_memtime at a few points. Compiled out of the product library.
@@ -317,8 +335,9 @@ __device__ __forceinline__ float softmax_keys_fast(f32x4 (&st)[NKT], int g, int 
 }
 
 template <typename T, int NDT, int QT>
-__global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
+__global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
+  const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)(pin.K + 2) * pin.H * pin.N * pin.M);
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
   constexpr int CHK = 2 * NDT;                    // 8-channel chunks per pixel (compile-time bound; 8*ch < d is checked)
@@ -547,9 +566,10 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params p) {
 // loads are in the other kernel. Contexts 0/1 are requested before the disc mask is known; local
 // contexts right after the tile test. If the contexts do not fit LDS at once they go in groups.
 template <typename T, int NDT, int QT>
-__global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params p) {
+__global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
+  const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)(pin.K + 2) * pin.H * pin.N * pin.M);
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NVF = NPS * NDT, NFWD = NKF + NVF;
   constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
@@ -800,9 +820,10 @@ __device__ __forceinline__ void attend_bwd(const char* buf, const typename Tr<T>
 }
 
 template <typename T, int NDT>
-__global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params p) {
+__global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
+  const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)pin.K * gridDim.x * (blockDim.x >> 6));
   constexpr int NKS = nks_of(NDT);
   constexpr int NALL = all_frags(NDT);
   constexpr int CB = NALL * FRAG;
@@ -956,7 +977,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params p) {
 __global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restrict__ part, float* dcoef,
                                                            int n) {
   __shared__ float sm[256];
-  const float* src = part + (size_t)blockIdx.x * n;
+  const float* src = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n;
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) acc += src[i];
   sm[threadIdx.x] = acc;
@@ -965,7 +986,7 @@ __global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restri
     if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) dcoef[blockIdx.x] = sm[0];
+  if (threadIdx.x == 0) dcoef[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1032,7 +1053,7 @@ int launch_fwd(const Params& p0, hipStream_t st) {
       return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd) failed");
     attr_set = true;
   }
-  hipLaunchKernelGGL((xattn_fwd_kernel<T, NDT, QT>), dim3(p.ntiles * p.H), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_kernel<T, NDT, QT>), dim3(p.ntiles * p.H, p.n_img), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd launch: %s", hipGetErrorString(e));
 }
@@ -1052,7 +1073,7 @@ int launch_fwd_staged_qt(const Params& p0, hipStream_t st) {
       return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
     attr_set = true;
   }
-  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT, QT>), dim3(p.ntiles * p.H), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT, QT>), dim3(p.ntiles * p.H, p.n_img), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
 }
@@ -1097,11 +1118,11 @@ int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
     attr_set = true;
   }
   const int nwg = p.ntiles * p.H;
-  hipLaunchKernelGGL((xattn_bwd_kernel<T, NDT>), dim3(nwg), dim3(64 * nw), lds, st, p);
+  hipLaunchKernelGGL((xattn_bwd_kernel<T, NDT>), dim3(nwg, p.n_img), dim3(64 * nw), lds, st, p);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(STA_E_LAUNCH, "bwd launch: %s", hipGetErrorString(e));
   if (p.K > 0) {
-    hipLaunchKernelGGL(dcoef_reduce_kernel, dim3(p.K), dim3(256), 0, st, p.aux, dcoef, nwg * nw);
+    hipLaunchKernelGGL(dcoef_reduce_kernel, dim3(p.K, p.n_img), dim3(256), 0, st, p.aux, dcoef, nwg * nw);
     e = hipGetLastError();
     if (e != hipSuccess) return fail(STA_E_LAUNCH, "dcoef reduce launch: %s", hipGetErrorString(e));
   }
@@ -1195,10 +1216,11 @@ int sta_xattn_pack_kv(const void* k, const void* v, void* packed, int n_ctx, int
 }
 
 int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const float* coef, void* out,
-                  float* maps, int N, int C, int heads, int M, int K, float scale, int dtype,
+                  float* maps, int n_img, int N, int C, int heads, int M, int K, float scale, int dtype,
                   void* stream) {
   g_err[0] = 0;
   if (!q || !packed || !out) return fail(STA_E_ARG, "null pointer");
+  if (n_img < 1 || n_img > 65535) return fail(STA_E_ARG, "n_img=%d", n_img);
   if (int rc = check_shape(N, C, heads, M, K)) return rc;
   if (K > 0 && (!mask || !coef)) return fail(STA_E_ARG, "mask/coef required when K > 0");
   if (dtype != STA_BF16 && dtype != STA_F16) return fail(STA_E_UNSUP, "dtype %d", dtype);
@@ -1208,29 +1230,30 @@ int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const 
     p.mask = (const uint8_t*)q;
     p.coef = (const float*)q;
   }
-  p.aux = maps; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K;
+  p.aux = maps; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K; p.n_img = n_img;
   p.scale = scale; p.sl2e = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_fwd<__bf16>(p, st) : dispatch_fwd<_Float16>(p, st);
 }
 
-size_t sta_xattn_bwd_workspace_bytes(int N, int heads, int K) {
-  if (N <= 0 || heads <= 0 || K <= 0) return 16;
-  return (size_t)K * ((N + 15) / 16 + 4) * heads * sizeof(float);
+size_t sta_xattn_bwd_workspace_bytes(int n_img, int N, int heads, int K) {
+  if (n_img <= 0 || N <= 0 || heads <= 0 || K <= 0) return 16;
+  return (size_t)n_img * K * ((N + 15) / 16 + 4) * heads * sizeof(float);
 }
 
 int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const float* coef,
-                  const void* dout, void* dq, float* dcoef, void* workspace, int N, int C, int heads,
+                  const void* dout, void* dq, float* dcoef, void* workspace, int n_img, int N, int C, int heads,
                   int M, int K, float scale, int dtype, void* stream) {
   g_err[0] = 0;
   if (!q || !packed || !dout || !dq) return fail(STA_E_ARG, "null pointer");
+  if (n_img < 1 || n_img > 65535) return fail(STA_E_ARG, "n_img=%d", n_img);
   if (int rc = check_shape(N, C, heads, M, K)) return rc;
   if (K > 0 && (!mask || !coef || !dcoef || !workspace)) return fail(STA_E_ARG, "mask/coef/dcoef/workspace required when K > 0");
   if (dtype != STA_BF16 && dtype != STA_F16) return fail(STA_E_UNSUP, "dtype %d", dtype);
   const int nw = pick_waves(N, heads);
   Params p{};
   p.q = q; p.packed = (const char*)packed; p.mask = mask; p.coef = coef; p.out = dq; p.dout = dout;
-  p.aux = (float*)workspace; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K;
+  p.aux = (float*)workspace; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K; p.n_img = n_img;
   p.ntiles = (N + 16 * nw - 1) / (16 * nw);
   p.scale = scale; p.sl2e = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;

@@ -121,25 +121,54 @@ class PLMSSampler(object):
                            object_names=object_names, local_conditionings=local_conditionings)
         return None
 
+    def sample_batch(self, S, shape, conditionings, unconditional_conditionings, bboxs, object_names, local_conditionings,
+                     curr_texts=None, x_T=None, unconditional_guidance_scale=7.5, eta=0.0, seed=1, prompt_indices=None,
+                     verbose=False):
+        """MI355X extension: I independent prompts (same number of objects) through ONE CFG batch of 2I
+        per UNet call — the reference loops over prompts with n_samples = 1 (scripts/txt2img-gpt.py:305).
+        Arguments are per-image lists; every image keeps its own x_T, weights W[i] and Adam state, so the
+        result of image i equals `sample(...)` on prompt i alone."""
+        I = len(conditionings)
+        self.make_schedule(ddim_num_steps=S, ddim_eta=eta, verbose=verbose)
+        C, H, W = shape
+        cond = torch.cat(list(conditionings))
+        uncond = torch.cat(list(unconditional_conditionings)) if isinstance(unconditional_conditionings, (list, tuple)) \
+            else unconditional_conditionings.expand(I, -1, -1)
+        self.plms_sampling(cond, (I, C, H, W), x_T=x_T, unconditional_guidance_scale=unconditional_guidance_scale,
+                           unconditional_conditioning=uncond, text_index=0,
+                           curr_text=list(curr_texts) if curr_texts is not None else [""] * I, bboxs_curr=list(bboxs), seed=seed,
+                           prompt_idx=list(prompt_indices) if prompt_indices is not None else list(range(I)),
+                           object_names=list(object_names), local_conditionings=list(local_conditionings), batched=True)
+        return None
+
     # --------------------------------------------------------------------------------------------------
     def plms_sampling(self, cond, shape, x_T=None, temperature=1.0, unconditional_guidance_scale=1.0,
                       unconditional_conditioning=None, text_index=None, curr_text="", bboxs_curr=None, seed=None,
-                      prompt_idx=None, object_names=None, local_conditionings=None, **ignored):
+                      prompt_idx=None, object_names=None, local_conditionings=None, batched=False, **ignored):
         assert seed is not None
         bboxs_curr = [] if bboxs_curr is None else bboxs_curr
         object_names = [] if object_names is None else object_names
-        assert len(bboxs_curr) == len(object_names)
         device = self.model.device
-        K, b = len(bboxs_curr), shape[0]
+        b = shape[0]
+        if not batched:          # the reference's single-image call: wrap into one-element batches
+            assert len(bboxs_curr) == len(object_names)
+            boxes, names, texts, pidx = [bboxs_curr], [object_names], [curr_text], [prompt_idx]
+            local = None if local_conditionings is None else [local_conditionings]
+        else:
+            boxes, names, texts, pidx, local = bboxs_curr, object_names, curr_text, prompt_idx, local_conditionings
+            assert len(boxes) == len(names) == b and all(len(bx) == len(nm) for bx, nm in zip(boxes, names))
+        K = len(boxes[0])
+        assert all(len(bx) == K for bx in boxes), "images of a batch must have the same number of objects"
         timesteps = self.ddim_timesteps
         S = timesteps.shape[0]
         time_range = np.flip(timesteps)
         img_input = (torch.randn(shape, device=device) if x_T is None else x_T.to(device)).clone()
 
-        # tell the 16 blocks a new prompt starts (replaces the `time == 981` test + cwd files)
-        _ps.begin_prompt(local_conditionings, first_timestep=int(time_range[0]))
+        # tell the 16 blocks a new prompt (batch) starts (replaces the `time == 981` test + cwd files)
+        _ps.begin_prompt(local if (batched or local is None) else local[0], first_timestep=int(time_range[0]))
+        block_boxes = boxes if batched else boxes[0]
 
-        W = torch.full((K, S), self.weight_init / K if K else 0.0, device=device, dtype=torch.float32)   # :204-209
+        W = torch.full((b, K, S), self.weight_init / K if K else 0.0, device=device, dtype=torch.float32)   # :204-209
         W.requires_grad_(self.opt_epochs > 0 and K > 0)
         optimizer = torch.optim.Adam([W], lr=self.lr) if W.requires_grad else None
 
@@ -152,20 +181,23 @@ class PLMSSampler(object):
             track = W.requires_grad and not last
             with torch.set_grad_enabled(track):
                 img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
-                                       time_range, W, bboxs_curr, text_index, graph=self.use_graph and not track)
+                                       time_range, W if batched else W[0], block_boxes, text_index,
+                                       graph=self.use_graph and not track)
                 x_img = None
                 if self.model.first_stage_model is not None:
                     x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
                 if track:
-                    loss = self._fidelity_loss(x_img[0].float(), curr_text, bboxs_curr, object_names)
+                    loss = sum(self._fidelity_loss(x_img[i].float(), texts[i], boxes[i], names[i]) for i in range(b))
                     optimizer.zero_grad()
                     loss.backward()
                     optimizer.step()
                     result.setdefault("losses", []).append(float(loss.detach()))
             if last:
-                result.update(x0=img.detach(), image=None if x_img is None else x_img.detach(), W=W.detach().clone())
+                result.update(x0=img.detach(), image=None if x_img is None else x_img.detach(),
+                              W=(W if batched else W[0]).detach().clone())
                 if self.save_images and x_img is not None:
-                    self._save(x_img[0], epochs - 1, seed, prompt_idx)
+                    for i in range(b):
+                        self._save(x_img[i], epochs - 1, seed, pidx[i])
         self.last_result = result
         return None
 
@@ -189,6 +221,7 @@ class PLMSSampler(object):
 
     # --------------------------------------------------------------------------------------------------
     def _trajectory(self, img, cond, uncond, scale, time_range, W, bboxs_curr, text_index, graph=False):
+        """W: [K, S] for one image or [I, K, S] for a batch; column i of every image is used at step i."""
         S, b, device = len(time_range), img.shape[0], img.device
         eps_fn = self._make_eps_fn(cond, uncond, scale, bboxs_curr, text_index, graph, img)
         old_eps = []
@@ -196,19 +229,23 @@ class PLMSSampler(object):
             index = S - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
             ts_next = torch.full((b,), int(time_range[min(i + 1, S - 1)]), device=device, dtype=torch.long)
-            img, _, e_t = self._plms_update(eps_fn, img, ts, ts_next, index, old_eps, W[:, i])
+            img, _, e_t = self._plms_update(eps_fn, img, ts, ts_next, index, old_eps, W[..., i])
             old_eps.append(e_t)
             if len(old_eps) >= 4:
                 old_eps.pop(0)
         return img
 
     def _make_eps_fn(self, cond, uncond, scale, bboxs_curr, text_index, graph, img):
-        """eps(x, t, coef) with classifier-free guidance: batch row 0 = uncond, row 1 = cond (:304-308)."""
+        """eps(x, t, coef) with classifier-free guidance. The UNet batch is [uncond_0, cond_0, uncond_1, cond_1, ...]:
+        for one image this is the reference's `cat([uc, c])` (:304-308); for a batch the pairs stay adjacent,
+        which is the layout the fused kernel indexes (image-major, row 0 = uncond, row 1 = cond)."""
         if uncond is None or scale == 1.0:
             raise ValueError("the spatial-temporal path needs classifier-free guidance (scale != 1, uc given): "
                              "the blend subtracts the unconditional row (attention.py:290)")
         wdtype = next(self.model.model.parameters()).dtype
-        c_in = torch.cat([uncond, cond]).to(wdtype)           # built once per trajectory (the reference: per call)
+        b = img.shape[0]
+        pair = lambda u, c: torch.stack([u, c], dim=1).reshape(2 * b, *u.shape[1:])
+        c_in = pair(uncond.expand(b, -1, -1), cond).to(wdtype)      # built once per trajectory (the reference: per call)
         apply_fn = self.model.apply_model_extra
         if graph and img.is_cuda:
             from sta.graphs import GraphedEps
@@ -217,9 +254,9 @@ class PLMSSampler(object):
             apply_fn = self._graphs.bind(c_in, bboxs_curr, text_index)
 
         def eps(x, t, coef):
-            x_in = torch.cat([x] * 2)
-            t_in = torch.cat([t] * 2)
-            e_u, e_c = apply_fn(x_in, text_index, t_in, c_in, coef=coef, bboxs_curr=bboxs_curr).chunk(2)
+            out = apply_fn(pair(x, x), text_index, pair(t, t), c_in, coef=coef, bboxs_curr=bboxs_curr)
+            out = out.reshape(b, 2, *out.shape[1:])
+            e_u, e_c = out[:, 0], out[:, 1]
             return e_u + scale * (e_c - e_u)
         return eps
 

@@ -114,28 +114,42 @@ class BasicTransformerBlock(nn.Module):
         # rebuild at the first timestep of every trajectory (costs the same host sync it pays).
         return _ps.version() == 0 and time is not None and int(time) == _ps.first_timestep()
 
+    @staticmethod
+    def _per_image_boxes(bboxs_curr, n_img):
+        """bboxs_curr is the reference's list of K [x, y] for one image, or a list of n_img such lists."""
+        boxes = [bboxs_curr] if n_img == 1 and (len(bboxs_curr) == 0 or not isinstance(bboxs_curr[0][0], (list, tuple))) \
+            else list(bboxs_curr)
+        if len(boxes) != n_img or any(len(b) != len(boxes[0]) for b in boxes):
+            raise ValueError("need one box list per image, all with the same number of objects (got %d lists for %d images)"
+                             % (len(boxes), n_img))
+        return tuple(tuple((float(b[0]), float(b[1])) for b in bx) for bx in boxes)
+
     def prepare_prompt(self, n, context, bboxs_curr, time=None):
         """(Re)build the packed K/V image and the disc masks for N = n pixels. Called lazily from
         forward(), or ahead of time by the sampler before replaying a captured graph."""
-        centres = tuple((float(b[0]), float(b[1])) for b in bboxs_curr)
-        cache = self._caches.setdefault((n, len(centres)), _PromptCache())
+        if context.shape[0] % 2:
+            raise ValueError("the spatial-temporal block needs CFG pairs [uncond, cond] (even batch), got context %s"
+                             % (tuple(context.shape),))
+        n_img = context.shape[0] // 2
+        centres = self._per_image_boxes(bboxs_curr, n_img)
+        K = len(centres[0])
+        cache = self._caches.setdefault((n, K, n_img), _PromptCache())
         if not self._stale(cache, centres, time):
             return cache
-        if context.shape[0] != 2:
-            raise ValueError("the spatial-temporal block needs the CFG batch [uncond, cond] (batch 2), got context %s"
-                             % (tuple(context.shape),))
         dim = math.isqrt(n)
         if dim * dim != n:
             raise ValueError("latent must be square (N=%d)" % n)
         wdtype = self.attn2.to_k.weight.dtype
         with torch.no_grad():
-            local = _ps.local_contexts(len(centres), context.device, wdtype)              # [K, M, Dc]
-            ctxs = context.to(wdtype) if local is None else torch.cat([context.to(wdtype), local])   # "", global, locals
+            local = _ps.local_contexts(K, n_img, context.device, wdtype)                  # [I, K, M, Dc]
+            ctx = context.to(wdtype).reshape(n_img, 2, context.shape[1], context.shape[2])   # per image: "", global
+            ctxs = ctx if local is None else torch.cat([ctx, local], dim=1)                  # + locals
+            ctxs = ctxs.reshape(n_img * (K + 2), context.shape[1], context.shape[2])
             k = self.attn2.to_k(ctxs)
             v = self.attn2.to_v(ctxs)
-            cache.packed = _ops.pack_kv(k, v, self.attn2.heads, out=cache.packed)
-            if centres:
-                m = _ops.disc_mask_bits(centres, dim).to(context.device)
+            cache.packed = _ops.pack_kv(k, v, self.attn2.heads, out=cache.packed, n_img=n_img)
+            if K:
+                m = torch.stack([_ops.disc_mask_bits(c, dim) for c in centres]).to(context.device)   # [I, N]
                 if cache.mask is None:
                     cache.mask = m
                 else:
@@ -147,12 +161,13 @@ class BasicTransformerBlock(nn.Module):
         bboxs_curr = [] if bboxs_curr is None else bboxs_curr
         if context is None:
             raise ValueError("BasicTransformerBlock needs the text context")
-        if x.shape[0] != 2:
-            raise ValueError("the spatial-temporal block needs the CFG batch [uncond, cond] (batch 2), got x %s" % (tuple(x.shape),))
+        if x.shape[0] % 2 or x.shape[0] != context.shape[0]:
+            raise ValueError("the spatial-temporal block needs the CFG batch [uncond, cond] (batch 2 per image), got x %s context %s"
+                             % (tuple(x.shape), tuple(context.shape)))
         self._last_n = x.shape[1]
         cache = self.prepare_prompt(x.shape[1], context, bboxs_curr, time)
         if coef is None:
-            if len(bboxs_curr):
+            if len(cache.centres[0]):
                 raise ValueError("coef is required when objects are present")
             coef = x.new_zeros(0, dtype=torch.float32)
         return checkpoint(lambda xx, cc: self._forward(xx, cc, cache), (x, coef), self.parameters(), self.checkpoint)

@@ -30,18 +30,22 @@ class GraphedEps:
 
     def bind(self, c_in, bboxs_curr, text_index):
         """Return an apply_model_extra-compatible callable for this prompt (context + objects)."""
-        K = len(bboxs_curr)
-        centres = tuple((float(b[0]), float(b[1])) for b in bboxs_curr)
+        n_img = c_in.shape[0] // 2
+        from ldm.modules.attention import BasicTransformerBlock
+        centres = BasicTransformerBlock._per_image_boxes(bboxs_curr, n_img)
+        K = len(centres[0])
+        boxes = [list(map(list, c)) for c in centres] if n_img > 1 else [list(b) for b in centres[0]]
 
         def apply(x_in, text_index_, t_in, c_in_, coef=None, bboxs_curr=None):
             key = (tuple(x_in.shape), x_in.dtype, K)
             ent = self._entries.get(key)
             if ent is None:
-                ent = self._capture(key, x_in, t_in, c_in, coef, list(centres), text_index)
+                ent = self._capture(key, x_in, t_in, c_in, coef, boxes, K, text_index)
+                ent.centres = centres
             elif ent.version != _ps.version() or ent.centres != centres:
                 # new prompt: refill every block's K/V image and masks in place, outside the graph
                 for blk, n in ent.blocks:
-                    blk.prepare_prompt(n, c_in, list(centres))
+                    blk.prepare_prompt(n, c_in, boxes)
                 ent.version, ent.centres = _ps.version(), centres
             ent.x.copy_(x_in)
             ent.t.copy_(t_in)
@@ -51,9 +55,8 @@ class GraphedEps:
             return ent.out
         return apply
 
-    def _capture(self, key, x_in, t_in, c_in, coef, centres, text_index):
+    def _capture(self, key, x_in, t_in, c_in, coef, centres, K, text_index):
         ent = _Entry()
-        K = len(centres)
         ent.x, ent.t = x_in.clone(), t_in.clone()
         ent.coef = coef.detach().to(torch.float32).clone() if K else None
         fn = lambda: self.model.apply_model_extra(ent.x, text_index, ent.t, c_in, coef=ent.coef, bboxs_curr=centres)
@@ -67,6 +70,6 @@ class GraphedEps:
         ent.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(ent.graph):
             ent.out = fn()
-        ent.version, ent.centres = _ps.version(), tuple((float(b[0]), float(b[1])) for b in centres)
+        ent.version, ent.centres = _ps.version(), None
         self._entries[key] = ent
         return ent

@@ -28,9 +28,9 @@ SYMBOLS = {
     "sta_last_error": (ctypes.c_char_p, []),
     "sta_xattn_packed_kv_bytes": (_sz, [_i, _i, _i]),
     "sta_xattn_pack_kv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
-    "sta_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
 }
 
 

@@ -62,43 +62,48 @@ def disc_mask_bits(centres, dim):
 
 
 class PackedKV:
-    """Fragment image of the projected keys/values of all contexts of one transformer block."""
+    """Fragment image of the projected keys/values of all contexts of one transformer block, for
+    `n_img` images (prompts) that share the object count: n_ctx = K + 2 contexts per image."""
 
-    __slots__ = ("buf", "n_ctx", "heads", "M", "C", "dtype")
+    __slots__ = ("buf", "n_ctx", "heads", "M", "C", "dtype", "n_img")
 
-    def __init__(self, buf, n_ctx, heads, M, C, dtype):
-        self.buf, self.n_ctx, self.heads, self.M, self.C, self.dtype = buf, n_ctx, heads, M, C, dtype
+    def __init__(self, buf, n_ctx, heads, M, C, dtype, n_img=1):
+        self.buf, self.n_ctx, self.heads, self.M, self.C, self.dtype, self.n_img = buf, n_ctx, heads, M, C, dtype, n_img
 
 
-def pack_kv(k, v, heads, out=None):
-    """k, v: [n_ctx, M, C] (ctx 0 = "", 1 = global prompt, 2+i = local prompt i) -> PackedKV.
-
-    `out`: a PackedKV of the same shape to refill in place (keeps its device address stable)."""
+def pack_kv(k, v, heads, out=None, n_img=1):
+    """k, v: [n_img * n_ctx, M, C], image-major; per image ctx 0 = "", 1 = global prompt, 2+i = local
+    prompt i -> PackedKV. `out`: a PackedKV of the same shape to refill in place (stable device address)."""
     if k.shape != v.shape or k.dim() != 3:
-        raise ValueError("k and v must both be [n_ctx, M, C], got %s and %s" % (tuple(k.shape), tuple(v.shape)))
+        raise ValueError("k and v must both be [n_img * n_ctx, M, C], got %s and %s" % (tuple(k.shape), tuple(v.shape)))
     if not k.is_cuda:
         raise RuntimeError("pack_kv needs CUDA/HIP tensors (there is no CPU path)")
-    n_ctx, M, C = k.shape
+    total, M, C = k.shape
     if C % heads:
         raise ValueError("C=%d is not divisible by heads=%d" % (C, heads))
+    if n_img < 1 or total % n_img:
+        raise ValueError("%d contexts do not split over n_img=%d images" % (total, n_img))
+    n_ctx = total // n_img
     L = _lib.load()
     k, v = k.contiguous(), v.contiguous()
-    nbytes = L.sta_xattn_packed_kv_bytes(n_ctx, heads, C // heads)
+    nbytes = L.sta_xattn_packed_kv_bytes(total, heads, C // heads)
     if nbytes == 0:
         raise ValueError("unsupported head dim %d (need d %% 8 == 0 and d <= %d)" % (C // heads, _lib.MAX_HEAD_DIM))
-    if out is not None and (out.n_ctx, out.heads, out.M, out.C, out.dtype) == (n_ctx, heads, M, C, k.dtype) \
+    if out is not None and (out.n_ctx, out.heads, out.M, out.C, out.dtype, out.n_img) == (n_ctx, heads, M, C, k.dtype, n_img) \
             and out.buf.device == k.device:
         buf = out.buf
     else:
         buf = torch.empty(nbytes, dtype=torch.uint8, device=k.device)
-    _lib.check(L.sta_xattn_pack_kv(k.data_ptr(), v.data_ptr(), buf.data_ptr(), n_ctx, M, C, heads,
+    _lib.check(L.sta_xattn_pack_kv(k.data_ptr(), v.data_ptr(), buf.data_ptr(), total, M, C, heads,
                                    _dtype_code(k), _stream(k)), "sta_xattn_pack_kv")
-    return PackedKV(buf, n_ctx, heads, M, C, k.dtype)
+    return PackedKV(buf, n_ctx, heads, M, C, k.dtype, n_img)
 
 
 def _check_inputs(q, packed, mask, coef):
-    if q.dim() != 3 or q.shape[0] != 2:
-        raise ValueError("q must be [2, N, C] (uncond row, cond row), got %s" % (tuple(q.shape),))
+    I = packed.n_img
+    if q.dim() != 3 or q.shape[0] != 2 * I:
+        raise ValueError("q must be [2 * n_img, N, C] (per image: uncond row, cond row) with n_img=%d, got %s"
+                         % (I, tuple(q.shape)))
     if not q.is_cuda:
         raise RuntimeError("fused cross-attention needs CUDA/HIP tensors (there is no CPU path)")
     if q.dtype != packed.dtype:
@@ -112,40 +117,54 @@ def _check_inputs(q, packed, mask, coef):
     if K > 0:
         if mask is None or coef is None:
             raise ValueError("mask and coef are required when local contexts are present")
-        if tuple(mask.shape) != (N,) or mask.dtype != torch.uint8:
-            raise ValueError("mask must be the uint8 bit field [N=%d] (see mask_bits), got %s %s" % (N, mask.dtype, tuple(mask.shape)))
-        if coef.numel() != K:
-            raise ValueError("coef must have K=%d elements, got %d" % (K, coef.numel()))
-    return N, C, K
+        if mask.numel() != I * N or mask.dtype != torch.uint8:
+            raise ValueError("mask must be the uint8 bit field [n_img=%d, N=%d] (see mask_bits), got %s %s"
+                             % (I, N, mask.dtype, tuple(mask.shape)))
+        if coef.numel() != I * K:
+            raise ValueError("coef must have n_img*K=%d elements, got %d" % (I * K, coef.numel()))
+    return I, N, C, K
+
+
+# bench.py's roofline leg: when set to a list, every forward launch is bracketed by its own HIP-event pair
+# on the launch stream and (e0, e1, n_img, N, C, K) is appended — in situ, inside real UNet calls.
+EVENT_LOG = None
 
 
 def xattn_forward(q, packed, mask, coef, scale, want_maps=False):
-    """Raw forward call (no autograd). Returns (out [2,N,C], maps [K+2,heads,N,M] fp32 or None)."""
-    N, C, K = _check_inputs(q, packed, mask, coef)
+    """Raw forward call (no autograd). Returns (out [2I,N,C], maps [I,K+2,heads,N,M] fp32 or None)."""
+    I, N, C, K = _check_inputs(q, packed, mask, coef)
     L = _lib.load()
     q = q.contiguous()
     coef32 = coef.detach().to(torch.float32).contiguous() if K else None
     maskc = mask.contiguous() if K else None
     out = torch.empty_like(q)
-    maps = torch.empty((K + 2, packed.heads, N, packed.M), dtype=torch.float32, device=q.device) if want_maps else None
+    maps = torch.empty((I, K + 2, packed.heads, N, packed.M), dtype=torch.float32, device=q.device) if want_maps else None
+    if EVENT_LOG is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.check(L.sta_xattn_fwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), out.data_ptr(),
-                               _ptr(maps), N, C, packed.heads, packed.M, K, float(scale), _dtype_code(q),
+                               _ptr(maps), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(q),
                                _stream(q)), "sta_xattn_fwd")
+    if EVENT_LOG is not None:
+        e1.record()
+        EVENT_LOG.append((e0, e1, I, N, C, K))
+    if maps is not None and I == 1:
+        maps = maps[0]
     return out, maps
 
 
 def xattn_backward(q, packed, mask, coef, dout, scale):
-    """Raw backward call. Returns (dq [2,N,C], dcoef [K] fp32)."""
-    N, C, K = _check_inputs(q, packed, mask, coef)
+    """Raw backward call. Returns (dq [2I,N,C], dcoef [I*K] fp32)."""
+    I, N, C, K = _check_inputs(q, packed, mask, coef)
     L = _lib.load()
     q, dout = q.contiguous(), dout.to(q.dtype).contiguous()
     coef32 = coef.detach().to(torch.float32).contiguous() if K else None
     maskc = mask.contiguous() if K else None
     dq = torch.empty_like(q)
-    dcoef = torch.empty(K, dtype=torch.float32, device=q.device)
-    ws = torch.empty(L.sta_xattn_bwd_workspace_bytes(N, packed.heads, K), dtype=torch.uint8, device=q.device)
+    dcoef = torch.empty(I * K, dtype=torch.float32, device=q.device)
+    ws = torch.empty(L.sta_xattn_bwd_workspace_bytes(I, N, packed.heads, K), dtype=torch.uint8, device=q.device)
     _lib.check(L.sta_xattn_bwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), dout.data_ptr(),
-                               dq.data_ptr(), _ptr(dcoef) if K else 0, ws.data_ptr(), N, C, packed.heads,
+                               dq.data_ptr(), _ptr(dcoef) if K else 0, ws.data_ptr(), I, N, C, packed.heads,
                                packed.M, K, float(scale), _dtype_code(q), _stream(q)), "sta_xattn_bwd")
     return dq, dcoef
 
@@ -172,9 +191,9 @@ class _XAttnBlend(torch.autograd.Function):
 
 
 def xattn_blend(q, coef, packed, mask, scale):
-    """Differentiable fused op: q [2,N,C], coef [K] -> blended pre-projection output [2,N,C].
+    """Differentiable fused op: q [2I,N,C], coef [K] or [I,K] -> blended pre-projection output [2I,N,C].
 
-    out[0] = A(q[0]; ctx 0);  out[1] = A(q[1]; ctx 1) + sum_i coef[i] mask[i] (A(q[1]; ctx 2+i) - out[0]).
+    Per image: out[0] = A(q[0]; ctx 0);  out[1] = A(q[1]; ctx 1) + sum_i coef[i] mask[i] (A(q[1]; ctx 2+i) - out[0]).
     Gradients flow to q and coef only (see include/sta_xattn.h).
     """
     return _XAttnBlend.apply(q, coef, packed, mask, scale)

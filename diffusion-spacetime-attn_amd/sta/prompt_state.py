@@ -27,7 +27,10 @@ _STATE = _State()
 def begin_prompt(local_ctx=None, first_timestep=None):
     """Announce a new prompt. `local_ctx`: list of K tensors [1, M, Dc] ("a photo of <object i>")."""
     _STATE.version += 1
-    _STATE.local_ctx = None if local_ctx is None else [c.detach() for c in local_ctx]
+    if local_ctx is None:
+        _STATE.local_ctx = None
+    else:
+        _STATE.local_ctx = [c.detach() if torch.is_tensor(c) else [t.detach() for t in c] for c in local_ctx]
     if first_timestep is not None:
         _STATE.first_timestep = int(first_timestep)
     return _STATE.version
@@ -41,16 +44,22 @@ def first_timestep():
     return _STATE.first_timestep
 
 
-def local_contexts(num_objects, device, dtype):
-    """The K local-prompt embeddings as one [K, M, Dc] tensor on `device`."""
+def local_contexts(num_objects, n_img, device, dtype):
+    """The local-prompt embeddings as one [n_img, K, M, Dc] tensor on `device` (None when K == 0).
+
+    begin_prompt() takes a list of K tensors for one image or a list of n_img such lists for a batch."""
     if num_objects == 0:
         return None
     if _STATE.local_ctx is not None:
-        if len(_STATE.local_ctx) != num_objects:
-            raise ValueError("begin_prompt() announced %d local prompts but bboxs_curr has %d objects"
-                             % (len(_STATE.local_ctx), num_objects))
-        cs = _STATE.local_ctx
-    else:                              # drop-in fallback: the reference's cwd files
+        per_img = _STATE.local_ctx
+        if n_img == 1 and (len(per_img) == 0 or torch.is_tensor(per_img[0])):
+            per_img = [per_img]
+        if len(per_img) != n_img or any(len(cs) != num_objects for cs in per_img):
+            raise ValueError("begin_prompt() announced %s local prompts but the call has %d image(s) x %d objects"
+                             % ([len(cs) for cs in per_img], n_img, num_objects))
+    else:                              # drop-in fallback: the reference's cwd files (single image only)
+        if n_img != 1:
+            raise ValueError("the file side channel carries one image; announce batches with begin_prompt()")
         from process_id import NON_EXISTING_NAME_ID
         cs = []
         for i in range(num_objects):
@@ -59,4 +68,6 @@ def local_contexts(num_objects, device, dtype):
                 raise FileNotFoundError(
                     "no local-prompt embeddings: call sta.prompt_state.begin_prompt(local_ctx) or provide %s" % path)
             cs.append(torch.load(path, map_location="cpu"))
-    return torch.cat([c.reshape(1, c.shape[-2], c.shape[-1]) for c in cs]).to(device=device, dtype=dtype)
+        per_img = [cs]
+    rows = [torch.cat([c.reshape(1, c.shape[-2], c.shape[-1]) for c in cs]) for cs in per_img]
+    return torch.stack(rows).to(device=device, dtype=dtype)

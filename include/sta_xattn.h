@@ -80,8 +80,11 @@ int sta_xattn_pack_kv(const void* k, const void* v, void* packed,
  * i.e. the pre-projection form of attention.py:278-294 (CrossAttention.forward :175-197 for each
  * context + the masked blend :284-294). Because to_out is affine and mask is per-pixel, applying
  * to_out once to `out` equals the reference's post-projection blend (bias cancels in the difference).
+ * Batching: the reference handles one image per call (n_samples must be 1, attention.py:282). Prompts are
+ * independent, so this library takes n_img >= 1 images per launch; every tensor below gains a leading
+ * image axis ([n_img][...]) and all images of a launch share K (prompts are grouped by object count).
  *   q      : [2][N][C] dtype   (to_q(norm2(x)), attention.py:178)
- *   packed : image from sta_xattn_pack_kv for n_ctx = K + 2
+ *   packed : image from sta_xattn_pack_kv for n_ctx = n_img * (K + 2) (image-major)
  *   mask   : [N] uint8 bit field, bit i set iff pixel n lies inside disc i (attention.py:251-262; the
  *            K boolean [dim,dim] masks of the reference packed into one byte per pixel, K <= 8);
  *            may be NULL iff K == 0
@@ -94,10 +97,10 @@ int sta_xattn_pack_kv(const void* k, const void* v, void* packed,
  */
 int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const float* coef,
                   void* out, float* maps,
-                  int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+                  int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
 
 /* Bytes of fp32 workspace sta_xattn_bwd needs for the given shape (deterministic dcoef reduce). */
-size_t sta_xattn_bwd_workspace_bytes(int N, int heads, int K);
+size_t sta_xattn_bwd_workspace_bytes(int n_img, int N, int heads, int K);
 
 /*
  * Backward of sta_xattn_fwd w.r.t. q and coef (K/V/context gradients are not produced: the text
@@ -110,7 +113,7 @@ size_t sta_xattn_bwd_workspace_bytes(int N, int heads, int K);
  */
 int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const float* coef,
                   const void* dout, void* dq, float* dcoef, void* workspace,
-                  int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+                  int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

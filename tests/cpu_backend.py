@@ -12,20 +12,25 @@ from oracle import xattn_oracle as orc
 
 
 class CpuPacked:
-    def __init__(self, k, v, heads):
-        self.k, self.v, self.heads = k, v, heads
-        self.n_ctx, self.M, self.C, self.dtype = k.shape[0], k.shape[1], k.shape[2], k.dtype
+    def __init__(self, k, v, heads, n_img):
+        self.k, self.v, self.heads, self.n_img = k, v, heads, n_img
+        self.n_ctx, self.M, self.C, self.dtype = k.shape[0] // n_img, k.shape[1], k.shape[2], k.dtype
 
 
-def _pack_kv(k, v, heads, out=None):
-    return CpuPacked(k.detach().clone(), v.detach().clone(), heads)
+def _pack_kv(k, v, heads, out=None, n_img=1):
+    return CpuPacked(k.detach().clone(), v.detach().clone(), heads, n_img)
 
 
 def _xattn_blend(q, coef, packed, mask, scale):
-    K = packed.n_ctx - 2
-    m = torch.stack([(mask >> i) & 1 for i in range(K)]).bool() if K else torch.zeros((0, q.shape[1]), dtype=torch.bool)
-    c = coef if K else torch.zeros(0, dtype=q.dtype)
-    return orc.fused_xattn(q, packed.k, packed.v, m, c.to(q.dtype), packed.heads, scale)
+    K, I, n = packed.n_ctx - 2, packed.n_img, packed.n_ctx
+    outs = []
+    for i in range(I):
+        mi = mask.reshape(I, -1)[i] if K else None
+        m = torch.stack([(mi >> j) & 1 for j in range(K)]).bool() if K else torch.zeros((0, q.shape[1]), dtype=torch.bool)
+        c = coef.reshape(I, K)[i] if K else torch.zeros(0, dtype=q.dtype)
+        outs.append(orc.fused_xattn(q[2 * i:2 * i + 2], packed.k[n * i:n * (i + 1)], packed.v[n * i:n * (i + 1)], m,
+                                    c.to(q.dtype), packed.heads, scale))
+    return torch.cat(outs)
 
 
 @contextlib.contextmanager

@@ -35,7 +35,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     # host-only entry points (no GPU work)
     assert L.sta_xattn_packed_kv_bytes(4, 8, 40) == 4 * 8 * 2 * (5 * 2 + 3 * 3) * 1024
     assert L.sta_xattn_packed_kv_bytes(4, 8, 168) == 0 and L.sta_xattn_packed_kv_bytes(4, 8, 20) == 0
-    assert L.sta_xattn_bwd_workspace_bytes(4096, 8, 2) >= 2 * 256 * 8 * 4
+    assert L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2) >= 2 * 256 * 8 * 4
+    assert L.sta_xattn_bwd_workspace_bytes(3, 4096, 8, 2) == 3 * L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2)
 
 
 def test_missing_gpu_fails_loudly():
@@ -98,10 +99,33 @@ def test_block_state_follows_prompt_version():
             for step in range(3):
                 blk(x, context=ctx, time=torch.tensor(981 - 20 * step), coef=torch.ones(1), bboxs_curr=[[0.5, 0.5]])
         assert len(calls) == 2
-        with pytest.raises(ValueError, match="announced 1 local prompts"):
+        with pytest.raises(ValueError, match=r"announced \[1\] local prompts"):
             blk(x, context=ctx, time=torch.tensor(1), coef=torch.ones(2), bboxs_curr=[[0.5, 0.5], [0.2, 0.2]])
-        with pytest.raises(ValueError, match="batch 2"):
+        with pytest.raises(ValueError, match="batch 2 per image"):
             blk(x[:1], context=ctx, time=torch.tensor(1), coef=torch.ones(1), bboxs_curr=[[0.5, 0.5]])
+
+
+def test_block_batch_of_images_equals_one_by_one():
+    """n_img images per call (rows interleaved [uncond_i, cond_i]) == the same images one at a time."""
+    from ldm.modules.attention import BasicTransformerBlock
+    from sta import prompt_state
+    blk = BasicTransformerBlock(64, 8, 8, context_dim=768, checkpoint=False)
+    seeded_fill_(blk, 4)
+    g = torch.Generator().manual_seed(0)
+    I, K, N = 3, 2, 64
+    x, ctx = torch.randn(2 * I, N, 64, generator=g), torch.randn(2 * I, 77, 768, generator=g)
+    local = [[torch.randn(1, 77, 768, generator=g) for _ in range(K)] for _ in range(I)]
+    boxes = [[[0.3 + 0.1 * i, 0.4], [0.7, 0.6 - 0.1 * i]] for i in range(I)]
+    coef = torch.rand(I, K, generator=g) + 1
+    with oracle_ops(), torch.no_grad():
+        prompt_state.begin_prompt(local, first_timestep=981)
+        batched = blk(x, context=ctx, time=torch.tensor(981), coef=coef, bboxs_curr=boxes)
+        for i in range(I):
+            prompt_state.begin_prompt(local[i], first_timestep=981)
+            one = blk(x[2 * i:2 * i + 2], context=ctx[2 * i:2 * i + 2], time=torch.tensor(981), coef=coef[i], bboxs_curr=boxes[i])
+            assert torch.allclose(batched[2 * i:2 * i + 2], one, atol=1e-5)
+        with pytest.raises(ValueError, match="one box list per image"):
+            blk(x, context=ctx, time=torch.tensor(981), coef=coef, bboxs_curr=boxes[:2])
 
 
 def _golden_unet():
@@ -210,6 +234,34 @@ def test_sampler_fixed_weights_path_and_result():
     with pytest.raises(AssertionError):
         sampler.sample(S=10, conditioning=c, batch_size=1, shape=[4, 16, 16], verbose=False, unconditional_guidance_scale=7.5,
                        unconditional_conditioning=gi.load_uncond(), bboxs_curr=[[0.3, 0.4]], object_names=[], seed=1)
+
+
+def test_sample_batch_equals_prompt_by_prompt():
+    """sample_batch over I prompts == sample(...) on each prompt alone (independent prompts, CFG pairs adjacent)."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    unet, _ = _golden_unet()
+    seeded_fill_(unet, 21)
+    model = LatentDiffusion(unet_config=unet)
+    I, K = 2, 2
+    cs, locs, xts, boxes = [], [], [], []
+    for i in range(I):
+        c, local_ctx, x_T = gi.unet_inputs(K, 50 + i)
+        cs.append(c), locs.append(local_ctx), xts.append(x_T[:, :, :16, :16])
+        boxes.append([[0.3 + 0.2 * i, 0.4], [0.7, 0.6 - 0.2 * i]])
+    uc = gi.load_uncond()
+    sampler = PLMSSampler(model, opt_epochs=0, use_graph=False, save_images=False)
+    with oracle_ops():
+        sampler.sample_batch(S=5, shape=[4, 16, 16], conditionings=cs, unconditional_conditionings=uc, bboxs=boxes,
+                             object_names=[["a", "b"]] * I, local_conditionings=locs, x_T=torch.cat(xts), seed=1)
+        batch = sampler.last_result["x0"].clone()
+        assert batch.shape == (I, 4, 16, 16) and sampler.last_result["W"].shape == (I, K, 5)
+        for i in range(I):
+            sampler.sample(S=5, conditioning=cs[i], batch_size=1, shape=[4, 16, 16], verbose=False, unconditional_guidance_scale=7.5,
+                           unconditional_conditioning=uc, eta=0.0, x_T=xts[i], text_index=0, curr_text="x", bboxs_curr=boxes[i],
+                           seed=1, prompt_idx=i, object_names=["a", "b"], local_conditionings=locs[i])
+            one = sampler.last_result["x0"]
+            assert torch.allclose(batch[i:i + 1], one, atol=1e-4 * float(one.abs().max())), (i, (batch[i:i + 1] - one).abs().max())
 
 
 def test_weight_optimisation_epochs_move_W():

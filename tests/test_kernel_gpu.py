@@ -128,6 +128,40 @@ def test_domain_properties_full_size():
     assert (sw - base).abs().max() <= 2 ** -6 * (1 + base.abs().max())                # (3) up to summation order
 
 
+@pytest.mark.parametrize("N,C,heads,K", [(4096, 320, 8, 2), (1024, 640, 8, 2), (64, 1280, 8, 2), (100, 128, 4, 3), (256, 192, 8, 0)])
+def test_batched_images_match_oracle_per_image(N, C, heads, K):
+    """n_img = 3 images in one launch (forward and backward) == the oracle on each image."""
+    from sta import ops
+    I, dtype, dev = 3, torch.bfloat16, "cuda"
+    cases = [_case(N, C, heads, K, dtype, seed=20 + i) for i in range(I)]
+    q = torch.cat([c[0] for c in cases]); k = torch.cat([c[1] for c in cases]); v = torch.cat([c[2] for c in cases])
+    masks = [c[3] for c in cases]; coef = torch.stack([c[4] for c in cases]) if K else None
+    scale = (C // heads) ** -0.5
+    packed = ops.pack_kv(k.to(dev), v.to(dev), heads, n_img=I)
+    mb = torch.stack([ops.mask_bits(m) for m in masks]).to(dev) if K else None
+    out, maps = ops.xattn_forward(q.to(dev), packed, mb, coef.to(dev) if K else None, scale, want_maps=True)
+    g = torch.Generator().manual_seed(3)
+    dout = torch.randn(2 * I, N, C, generator=g).to(dtype)
+    dq, dcoef = ops.xattn_backward(q.to(dev), packed, mb, coef.to(dev) if K else None, dout.to(dev), scale)
+    torch.cuda.synchronize()
+    eps = 2.0 ** -8
+    for i in range(I):
+        qi, ki, vi, mi, ci = cases[i]
+        qd = qi.double().requires_grad_(True)
+        cd = ci.double().requires_grad_(True)
+        ref, ref_maps = orc.fused_xattn(qd, ki.double(), vi.double(), mi, cd, heads, scale, want_maps=True)
+        err = (out[2 * i:2 * i + 2].float().cpu().double() - ref.detach()).abs()
+        assert (err <= 4 * eps * (1.0 + ref.detach().abs())).all(), (i, err.max())
+        assert (maps[i].cpu().double() - ref_maps.detach()).abs().max() < 1e-4
+        ref.backward(dout[2 * i:2 * i + 2].double())
+        gs = qd.grad.abs().max().item()
+        assert (dq[2 * i:2 * i + 2].float().cpu().double() - qd.grad).abs().max() <= 6 * eps * gs + 1e-6
+        if K:
+            gc = cd.grad
+            tol = 0.02 * gc.abs() + 0.005 * gc.abs().max() + 1e-4 * math.sqrt(N * C)
+            assert ((dcoef.view(I, K)[i].cpu().double() - gc).abs() <= tol).all()
+
+
 def test_autograd_function_roundtrip():
     from sta import ops
     N, C, heads, K = 256, 320, 8, 2
@@ -148,7 +182,7 @@ def test_error_convention():
     assert L.sta_version() == 0x000100
     assert L.sta_xattn_packed_kv_bytes(4, 8, 41) == 0          # d % 8 != 0
     x = torch.zeros(2, 16, 8 * 168, device="cuda", dtype=torch.bfloat16)
-    rc = L.sta_xattn_fwd(x.data_ptr(), x.data_ptr(), 0, 0, x.data_ptr(), 0, 16, 8 * 168, 8, 77, 0, 1.0, 0, 0)
+    rc = L.sta_xattn_fwd(x.data_ptr(), x.data_ptr(), 0, 0, x.data_ptr(), 0, 1, 16, 8 * 168, 8, 77, 0, 1.0, 0, 0)
     assert rc == -2 and "head dim" in lib.last_error()
     with pytest.raises(ValueError):
         ops.pack_kv(torch.zeros(2, 77, 8 * 168, device="cuda", dtype=torch.bfloat16),
