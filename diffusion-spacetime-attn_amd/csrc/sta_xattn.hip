@@ -565,15 +565,15 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
 // LDS fragment reads are hoisted into registers ahead of the MFMAs for the same reason the global
 // loads are in the other kernel. Contexts 0/1 are requested before the disc mask is known; local
 // contexts right after the tile test. If the contexts do not fit LDS at once they go in groups.
-template <typename T, int NDT, int QT>
-__global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params pin) {
+template <typename T, int NDT, int QT, int NWV>
+__global__ __launch_bounds__(64 * NWV) void xattn_fwd_staged_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)(pin.K + 2) * pin.H * pin.N * pin.M);
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NVF = NPS * NDT, NFWD = NKF + NVF;
   constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
-  constexpr int TP = 64 * QT;                     // pixels per workgroup: 4 waves x QT tiles x 16
+  constexpr int TP = 16 * NWV * QT;               // pixels per workgroup: NWV waves x QT tiles x 16
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -591,11 +591,12 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params pin)
 
   // ---- prologue: oldest first — mask bits / weights, fragments of contexts 0 and 1, Q ------------
   const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
-  unsigned tb[QT];                                 // lane <-> pixel px0 + 64*j + lane of the tile
+  constexpr int NCH = TP / 64 > 0 ? TP / 64 : 1;   // 64-pixel chunks of the tile
+  unsigned tb[NCH];                                // lane <-> pixel px0 + 64*j + lane of the tile
 #pragma unroll
-  for (int j = 0; j < QT; ++j) tb[j] = p.mask[min(px0 + 64 * j + lane, N - 1)];
-  stage_frags(img_h, smem, NFWD, wv, 4, lane);
-  stage_frags(img_h + ctx_stride, smem + CB, NFWD, wv, 4, lane);
+  for (int j = 0; j < NCH; ++j) tb[j] = p.mask[min(px0 + 64 * j + lane, N - 1)];
+  stage_frags(img_h, smem, NFWD, wv, NWV, lane);
+  stage_frags(img_h + ctx_stride, smem + CB, NFWD, wv, NWV, lane);
   // this wave's QT pixel tiles: pixels px0 + (wv*QT + qt)*16 + c16, rows 0 (uncond) and 1 (cond) of Q
   V8 q0[QT][NKS], q1[QT][NKS];
   bool valid[QT];
@@ -613,13 +614,13 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params pin)
   unsigned tile_bits = 0, wave_bits = 0, mybits[QT];
   float coefv[MAXK];
 #pragma unroll
-  for (int j = 0; j < QT; ++j) tb[j] = (px0 + 64 * j + lane < N) ? (tb[j] & ((1u << K) - 1u)) : 0u;
+  for (int j = 0; j < NCH; ++j) tb[j] = (px0 + 64 * j + lane < N && 64 * j + lane < TP) ? (tb[j] & ((1u << K) - 1u)) : 0u;
 #pragma unroll
   for (int i = 0; i < MAXK; ++i) {
     coefv[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
     if (i < K) {
 #pragma unroll
-      for (int j = 0; j < QT; ++j) {
+      for (int j = 0; j < NCH; ++j) {
         const unsigned long long bl = __ballot((tb[j] >> i) & 1u);       // pixels 64j .. 64j+63 of the tile
         if (bl) tile_bits |= 1u << i;
         // this wave's pixels are 16*QT*wv .. +16*QT-1 of the tile: the part of them inside chunk j
@@ -636,7 +637,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params pin)
     const int rel = (wv * QT + qt) * 16 + c16;
     unsigned v = 0;
 #pragma unroll
-    for (int j = 0; j < QT; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       const unsigned cand = (unsigned)__shfl((int)tb[j], rel & 63);
       v = ((rel >> 6) == j) ? cand : v;
     }
@@ -654,7 +655,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params pin)
     return 2 + (int)__builtin_ctz(rest);
   };
   for (int e = 2; e < n_active && e < G; ++e)
-    stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + e * CB, NFWD, wv, 4, lane);
+    stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + e * CB, NFWD, wv, NWV, lane);
 
   STA_T(2);
   f32x4 au[QT][NDT], ac[QT][NDT];
@@ -662,7 +663,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_staged_kernel(const Params pin)
     if (e0 > 0) {   // next group: everyone is done reading the previous one
       __syncthreads();
       for (int e = e0; e < n_active && e < e0 + G; ++e)
-        stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + (e - e0) * CB, NFWD, wv, 4, lane);
+        stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + (e - e0) * CB, NFWD, wv, NWV, lane);
     }
     wait_dma_and_sync();
     STA_T(3);
@@ -1023,17 +1024,16 @@ int check_shape(int N, int C, int heads, int M, int K) {
   return STA_OK;
 }
 
-// Pixel tiles per wave: each K/V fragment read from L2 is reused QT times, so larger QT cuts L2
-// traffic; smaller QT gives more workgroups. Take the largest QT the register budget of the head
-// dim allows that still yields >= 512 workgroups (2 per CU), else 1.
-int pick_qt(int N, int heads, int ndt) {
-  int cap = ndt <= 3 ? 4 : (ndt <= 6 ? 2 : 1);
+// Pixel tiles per wave of the wave-per-context kernel. QT > 1 reuses each fragment for more pixels but
+// measured slower at every level (register pressure: N=1024 d=80 7.2 -> 8.7 us; 8 images 39.8 -> 52.8 us),
+// so QT = 1 ships and larger values stay reachable through the tuning knob only.
+int pick_qt(int N, int heads, int ndt, int n_img) {
+  const int cap = ndt <= 3 ? 4 : (ndt <= 6 ? 2 : 1);
   if (const char* e = getenv("STA_FWD_QT")) {  // tuning knob (tools/kernel_bench.py); not used in production
     const int v = atoi(e);
     if (v == 1 || v == 2 || v == 4) return v < cap ? v : cap;
   }
-  for (int qt = cap; qt > 1; qt >>= 1)
-    if ((long)((N + 16 * qt - 1) / (16 * qt)) * heads >= 512) return qt;
+  (void)N; (void)heads; (void)n_img;
   return 1;
 }
 
@@ -1058,47 +1058,60 @@ int launch_fwd(const Params& p0, hipStream_t st) {
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd launch: %s", hipGetErrorString(e));
 }
 
-template <typename T, int NDT, int QT>
-int launch_fwd_staged_qt(const Params& p0, hipStream_t st) {
+template <typename T, int NDT, int QT, int NWV>
+int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   constexpr int CB = fwd_frags(NDT) * FRAG;
+  constexpr int TP = 16 * NWV * QT;
   Params p = p0;
-  p.ntiles = (p.N + 64 * QT - 1) / (64 * QT);
+  p.ntiles = (p.N + TP - 1) / TP;
   int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
   if (G > p.K + 2) G = p.K + 2;
   p.ntiles_aux = G;
   const int lds = G * CB;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)xattn_fwd_staged_kernel<T, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)xattn_fwd_staged_kernel<T, NDT, QT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
     attr_set = true;
   }
-  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT, QT>), dim3(p.ntiles * p.H, p.n_img), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT, QT, NWV>), dim3(p.ntiles * p.H, p.n_img), dim3(64 * NWV), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
 }
 
-// 64-pixel workgroups (one tile per wave, two workgroups per CU). The 128-pixel variant (two tiles per wave:
-// half the LDS reads per pixel, one workgroup per CU) measured SLOWER at N=4096 d=40 — 11.9 vs 9.1 us,
-// workgroup lifetime 7.4 vs 6.4 us median — the two softmax chains of a wave do not overlap as hoped;
-// it stays selectable for experiments only.
+// Workgroup shape of the LDS-resident kernel. 4 waves x 16 px (two workgroups per CU) when the launch has
+// few workgroups: latency is what matters. 8 waves x 16 px sharing one LDS image (4 waves per SIMD with two
+// workgroups per CU) when a launch carries several images and is throughput bound. Two tiles per wave
+// (QT = 2) measured slower at N=4096 d=40 (11.9 vs 9.1 us) and stays selectable for experiments only.
 template <typename T, int NDT>
 int launch_fwd_staged(const Params& p, hipStream_t st) {
+  const long w64 = (long)((p.N + 63) / 64) * p.H * p.n_img;      // 64-pixel workgroups in the launch
   int qt = 1;
-  if (const char* e = getenv("STA_FWD_STAGED_QT")) qt = atoi(e) == 2 ? 2 : 1;     // tuning knob
-  return qt == 2 ? launch_fwd_staged_qt<T, NDT, 2>(p, st) : launch_fwd_staged_qt<T, NDT, 1>(p, st);
+  int nwv = (NDT <= 6 && w64 >= (NDT <= 3 ? 1024 : 512)) ? 8 : 4;
+  if (const char* e = getenv("STA_FWD_STAGED_QT")) qt = atoi(e) == 2 ? 2 : 1;     // tuning knobs
+  if (const char* e = getenv("STA_FWD_STAGED_WAVES")) nwv = atoi(e) == 8 ? 8 : 4;
+  if constexpr (NDT <= 6) {
+    if (qt == 2) return launch_fwd_staged_cfg<T, NDT, 2, 4>(p, st);
+    if (nwv == 8) return launch_fwd_staged_cfg<T, NDT, 1, 8>(p, st);   // 128-VGPR budget: small head dims only
+  }
+  return launch_fwd_staged_cfg<T, NDT, 1, 4>(p, st);
 }
 
-// Which forward kernel (rocprofv3 kernel durations, K = 2, bf16, MI355X; profiles/r01_kernel_variants.md):
-//   N=4096 d=40 : staged 10.6 us | split 14.3-18.0 us      N=1024 d=80 : staged 10.5 | split 7.9-8.5
-//   N=256/64 d=160 : split 8.3-8.8 (staged not possible: 2 x 55 KB per context pair only)
-// -> the LDS-resident kernel for small head dims with >= 256 workgroups, the wave-per-context one else.
-bool use_staged(int N, int heads, int ndt) {
+// Which forward kernel — rocprofv3 kernel durations in us, K = 2, bf16, MI355X (profiles/r01_kernel_variants.md),
+// by images per launch I:
+//   N=4096 d=40 : I=1 staged 9.1 | split 14-18      I=2 st4 18.2 st8 15.6 | split 25.4    I=8 st4 62 st8 44.9 | split 93
+//   N=1024 d=80 : I=1 staged 10.5 | split 7.2       I=2 st4 10.7 st8 11.8 | split 13.1    I=8 st4 38 st8 28.3 | split 40
+//   N=256 d=160 : I=1 split 8.2                      I=2 st4 14.9 | split 9.5  I=4 16.3|16.2  I=8 st4 22.0 | split 29.4
+//   N=64  d=160 : split 8.8-9.5 | staged 14-15.7 at every I
+// -> LDS-resident ("staged") from 256 64-pixel workgroups per launch, 8 waves per workgroup from 1024 (d <= 48)
+//    or 512 (d <= 96) of them; the wave-per-context ("split") kernel below that.
+bool use_staged(int N, int heads, int ndt, int n_img) {
   if (const char* e = getenv("STA_FWD_KERNEL")) {  // tuning knob: "staged" / "split"
-    if (!strcmp(e, "staged")) return ndt <= 6;
+    if (!strcmp(e, "staged")) return true;
     if (!strcmp(e, "split")) return false;
   }
-  return ndt <= 3 && (long)((N + 63) / 64) * heads >= 256;
+  (void)ndt;
+  return (long)((N + 63) / 64) * heads * n_img >= 256;
 }
 
 template <typename T, int NDT>
@@ -1132,7 +1145,7 @@ int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
 template <typename T>
 int dispatch_fwd(const Params& p, hipStream_t st) {
   const int ndt = (p.d + 15) / 16;
-  if (use_staged(p.N, p.H, ndt)) {
+  if (use_staged(p.N, p.H, ndt, p.n_img)) {
     switch (ndt) {
       case 1: return launch_fwd_staged<T, 1>(p, st);
       case 2: return launch_fwd_staged<T, 2>(p, st);
@@ -1140,9 +1153,13 @@ int dispatch_fwd(const Params& p, hipStream_t st) {
       case 4: return launch_fwd_staged<T, 4>(p, st);
       case 5: return launch_fwd_staged<T, 5>(p, st);
       case 6: return launch_fwd_staged<T, 6>(p, st);
+      case 7: return launch_fwd_staged<T, 7>(p, st);
+      case 8: return launch_fwd_staged<T, 8>(p, st);
+      case 9: return launch_fwd_staged<T, 9>(p, st);
+      case 10: return launch_fwd_staged<T, 10>(p, st);
     }
   }
-  const int qt = pick_qt(p.N, p.H, ndt);
+  const int qt = pick_qt(p.N, p.H, ndt, p.n_img);
   switch (ndt) {
     case 1: return launch_fwd_qt<T, 1>(p, qt, st);
     case 2: return launch_fwd_qt<T, 2>(p, qt, st);

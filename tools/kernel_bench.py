@@ -19,18 +19,18 @@ LEVELS = {512: [(4096, 320), (1024, 640), (256, 1280), (64, 1280)],
 CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]
 
 
-def bench_level(N, C, K, heads=8, M=77, iters=200, dtype=torch.bfloat16, bwd=False):
+def bench_level(N, C, K, heads=8, M=77, iters=200, dtype=torch.bfloat16, bwd=False, imgs=1):
     dev = "cuda"
     g = torch.Generator(device="cpu").manual_seed(0)
-    q = torch.randn(2, N, C, generator=g).to(dtype).to(dev)
-    k = (torch.randn(K + 2, M, C, generator=g) * 0.78).to(dtype).to(dev)
-    v = torch.randn(K + 2, M, C, generator=g).to(dtype).to(dev)
+    q = torch.randn(2 * imgs, N, C, generator=g).to(dtype).to(dev)
+    k = (torch.randn(imgs * (K + 2), M, C, generator=g) * 0.78).to(dtype).to(dev)
+    v = torch.randn(imgs * (K + 2), M, C, generator=g).to(dtype).to(dev)
     dim = int(N ** 0.5)
-    mask = ops.disc_mask_bits(CENTRES[:K], dim).to(dev)
-    coef = torch.full((K,), 5.0 / max(K, 1), device=dev)
-    packed = ops.pack_kv(k, v, heads)
+    mask = ops.disc_mask_bits(CENTRES[:K], dim).to(dev).repeat(imgs, 1)
+    coef = torch.full((imgs, K), 5.0 / max(K, 1), device=dev)
+    packed = ops.pack_kv(k, v, heads, n_img=imgs)
     scale = (C // heads) ** -0.5
-    dout = torch.randn(2, N, C, generator=g).to(dtype).to(dev)
+    dout = torch.randn(2 * imgs, N, C, generator=g).to(dtype).to(dev)
     fn = (lambda: ops.xattn_backward(q, packed, mask, coef, dout, scale)) if bwd else \
          (lambda: ops.xattn_forward(q, packed, mask, coef, scale))
     for _ in range(10):
@@ -43,9 +43,9 @@ def bench_level(N, C, K, heads=8, M=77, iters=200, dtype=torch.bfloat16, bwd=Fal
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
-    flops = 4.0 * M * C * N * (K + 2) * (2 if bwd else 1)
-    byts = (12.0 if bwd else 8.0) * N * C + 4.0 * (K + 2) * M * C + K * N
-    return {"N": N, "C": C, "K": K, "bwd": bwd, "us": round(us, 2), "TFLOPs": round(flops / us / 1e6, 1),
+    flops = imgs * 4.0 * M * C * N * (K + 2) * (2 if bwd else 1)
+    byts = imgs * ((12.0 if bwd else 8.0) * N * C + 4.0 * (K + 2) * M * C + K * N)
+    return {"N": N, "C": C, "K": K, "imgs": imgs, "bwd": bwd, "us": round(us, 2), "TFLOPs": round(flops / us / 1e6, 1),
             "GBps": round(byts / us / 1e3, 1)}
 
 
@@ -55,6 +55,7 @@ if __name__ == "__main__":
     ap.add_argument("--K", type=int, default=2)
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--imgs", type=int, default=1)
     a = ap.parse_args()
     for N, C in LEVELS[a.res]:
-        print(json.dumps(bench_level(N, C, a.K, iters=a.iters, bwd=a.bwd)))
+        print(json.dumps(bench_level(N, C, a.K, iters=a.iters, bwd=a.bwd, imgs=a.imgs)))
