@@ -1,0 +1,282 @@
+// sta_selfattn.hip — flash-style self-attention (attn1 of BasicTransformerBlock) for gfx950.
+//
+// Reference: CrossAttention.forward with context = x (ldm/modules/attention.py:175-197, called at :274):
+//   sim = einsum(q, k) * scale; attn = softmax(sim); out = einsum(attn, v)   over N = H*W keys,
+// which materialises [16, N, N] scores (N = 4096 at 512^2: 537 MB in fp16). SURVEY.md §8f ranks this the
+// next component after the fused cross-attention: it shares the same transformer block and the same MFMA
+// tile machinery. Inference only (the weight-optimisation path keeps PyTorch's differentiable SDPA).
+//
+// Same "pixel is the MFMA column" layout as sta_xattn.hip (16x16x32 MFMA, lane = 16g + c):
+//   S^T[key][px]  = K[key][:] . Q[px][:]       A = K rows (16 B per lane straight from the [B][N][ld] rows)
+//   O^T[dcol][px] = V^T[dcol][:] . P^T[:][px]   A = V^T rows (16 B per lane from a TRANSPOSED V, [B][C][N])
+// V^T costs nothing extra: the host computes it as W_v . x^T instead of x . W_v^T (one GEMM either way).
+// The rows of an S^T tile are assigned to keys so that a lane ends up holding 8 CONSECUTIVE keys of a
+// 32-key step (tile T, row 4g+r  <->  key 32(T>>1) + 8g + 4(T&1) + r): the softmax output is then directly
+// the B operand of the PV product and the V^T fragment is one contiguous 16-byte load per lane.
+// Online softmax over 64-key blocks; K/V^T fragments of a block are copied to LDS once per workgroup by
+// LDS-DMA with per-lane source addresses (global_load_lds_dwordx4) and double-buffered.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sta_xattn.h"
+#include "sta_internal.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <typename T> struct Tr;
+template <> struct Tr<__bf16> {
+  using V8 = bf16x8;
+  using V4 = bf16x4;
+  static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Tr<_Float16> {
+  using V8 = f16x8;
+  using V4 = f16x4;
+  static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+
+constexpr int KB = 64;        // keys per block
+constexpr int FRAG = 1024;    // bytes per fragment
+
+struct SParams {
+  const void* q;    // [B][N][ldq]
+  const void* k;    // [B][N][ldk]
+  const void* vt;   // [B][C][N]
+  void* out;        // [B][N][C]
+  int B, N, C, H, d, ldq, ldk;
+  float sl2e;       // scale * log2(e)
+};
+
+extern __shared__ __attribute__((aligned(16))) char smem_sa[];
+
+__device__ __forceinline__ float bfly_max(float x) {
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  const unsigned v = __float_as_uint(m);
+  auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float bfly_sum(float x) {
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  const unsigned v = __float_as_uint(m);
+  auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// key (within a 64-key block) held by row i of S^T tile T
+__device__ __forceinline__ int tile_key(int T, int i) { return 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3); }
+
+template <typename T, int NKS, int NDT, int QT>
+__global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  constexpr int NKF = 4 * NKS;            // K fragments per block: 4 key tiles x NKS head-dim steps
+  constexpr int NVF = 2 * NDT;            // V^T fragments per block: 2 key steps x NDT head-dim tiles
+  constexpr int NFR = NKF + NVF;
+  constexpr int BB = NFR * FRAG;          // LDS bytes per block buffer
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int N = p.N, C = p.C, d = p.d;
+  const int b = blockIdx.y;
+  int tile, h;
+  if (p.H == 8) { tile = blockIdx.x >> 3; h = blockIdx.x & 7; } else { tile = blockIdx.x / p.H; h = blockIdx.x % p.H; }
+  const int px0 = (tile * 4 + wv) * 16 * QT;
+
+  const T* qb = (const T*)p.q + (size_t)b * N * p.ldq + h * d;
+  const T* kb = (const T*)p.k + (size_t)b * N * p.ldk + h * d;
+  const T* vb = (const T*)p.vt + ((size_t)b * C + h * d) * N;
+
+  // Q (B operand), zero in the padded head-dim slots so that K's padding never matters
+  V8 qf[QT][NKS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int px = px0 + 16 * qt + c16;
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+      V8 z = {};
+      const int dd = 32 * s + 8 * g;
+      qf[qt][s] = (px < N && dd < d) ? *(const V8*)(qb + (size_t)px * p.ldq + dd) : z;
+    }
+  }
+
+  // LDS-DMA of one 64-key block: every wave copies fragments wv, wv+4, ... ; per-lane source addresses,
+  // lane-linear destination. Out-of-range rows/keys are clamped to valid memory (their products are
+  // multiplied by zero Q slots, masked scores or discarded output rows).
+  auto stage = [&](int blk, char* dst) {
+    const int k0 = blk * KB;
+    for (int f = wv; f < NFR; f += 4) {
+      const T* src;
+      if (f < NKF) {
+        const int Tt = f / NKS, s = f - Tt * NKS;
+        const int key = min(k0 + tile_key(Tt, c16), N - 1);
+        const int dd = min(32 * s + 8 * g, d - 8);
+        src = kb + (size_t)key * p.ldk + dd;
+      } else {
+        const int f2 = f - NKF;
+        const int s2 = f2 / NDT, u = f2 - s2 * NDT;
+        const int row = min(16 * u + c16, d - 1);
+        const int key = min(k0 + 32 * s2 + 8 * g, N - 8);
+        src = vb + (size_t)row * N + key;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + f * FRAG), 16, 0, 0);
+    }
+  };
+
+  f32x4 o[QT][NDT];
+  float mrun[QT], lrun[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = -3.0e38f;
+    lrun[qt] = 0.f;
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) o[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int nblk = (N + KB - 1) / KB;
+  stage(0, smem_sa);
+  for (int blk = 0; blk < nblk; ++blk) {
+    char* cur = smem_sa + (blk & 1) * BB;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                   // block `blk` landed; everyone left block blk-1
+    if (blk + 1 < nblk) stage(blk + 1, smem_sa + ((blk + 1) & 1) * BB);
+    const V8* fr = (const V8*)cur + lane;
+    const bool tail = (blk + 1) * KB > N;
+
+    // S^T = K Q^T for the 4 key tiles of the block
+    V8 ka[NKF];
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
+    f32x4 st[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
+      }
+    V8 va[NVF];
+#pragma unroll
+    for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
+
+    // online softmax per pixel (lane & 15); the row sum is kept per lane and reduced once at the end
+    V8 pb[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      if (tail) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (blk * KB + tile_key(t, 4 * g + r) >= N) st[qt][t][r] = -3.0e38f;
+      }
+      float bm = fmaxf(fmaxf(fmaxf(st[qt][0][0], st[qt][0][1]), fmaxf(st[qt][0][2], st[qt][0][3])),
+                       fmaxf(fmaxf(st[qt][1][0], st[qt][1][1]), fmaxf(st[qt][1][2], st[qt][1][3])));
+      bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(st[qt][2][0], st[qt][2][1]), fmaxf(st[qt][2][2], st[qt][2][3])),
+                           fmaxf(fmaxf(st[qt][3][0], st[qt][3][1]), fmaxf(st[qt][3][2], st[qt][3][3]))));
+      bm = bfly_max(bm);
+      const float mnew = fmaxf(mrun[qt], bm);
+      const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * p.sl2e);
+      const float off = mnew * p.sl2e;
+      mrun[qt] = mnew;
+      float rs = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][t][r], p.sl2e, -off));
+          st[qt][t][r] = e;
+          rs += e;
+        }
+      lrun[qt] = lrun[qt] * alpha + rs;
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) o[qt][u] *= alpha;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pb[qt][s2][j] = (T)st[qt][2 * s2 + (j >> 2)][j & 3];
+    }
+    // O^T += V^T P^T
+#pragma unroll
+    for (int u = 0; u < NDT; ++u)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) o[qt][u] = Tr<T>::mfma(va[s2 * NDT + u], pb[qt][s2], o[qt][u]);
+  }
+
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int px = px0 + 16 * qt + c16;
+    const float inv = 1.0f / bfly_sum(lrun[qt]);
+    if (px >= N) continue;
+    T* ob = (T*)p.out + ((size_t)b * N + px) * C + h * d;
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      const int dd = 16 * u + 4 * g;
+      if (dd < d) {
+        V4 r4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r4[r] = (T)(o[qt][u][r] * inv);
+        *(V4*)(ob + dd) = r4;
+      }
+    }
+  }
+}
+
+template <typename T, int NKS, int NDT>
+int launch_sa(const SParams& p, hipStream_t st) {
+  constexpr int QT = 2;
+  constexpr int lds = 2 * (4 * NKS + 2 * NDT) * FRAG;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
+    attr_set = true;
+  }
+  const int tiles = (p.N + 64 * QT - 1) / (64 * QT);
+  hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT>), dim3(tiles * p.H, p.B), dim3(256), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn launch: %s", hipGetErrorString(e));
+}
+
+template <typename T>
+int dispatch_sa(const SParams& p, hipStream_t st) {
+  switch ((p.d + 15) / 16) {
+    case 1: return launch_sa<T, 1, 1>(p, st);
+    case 2: return launch_sa<T, 1, 2>(p, st);
+    case 3: return launch_sa<T, 2, 3>(p, st);
+    case 4: return launch_sa<T, 2, 4>(p, st);
+    case 5: return launch_sa<T, 3, 5>(p, st);
+    case 6: return launch_sa<T, 3, 6>(p, st);
+  }
+  return sta_fail(STA_E_UNSUP, "self-attention head dim %d unsupported (d <= 96)", p.d);
+}
+
+}  // namespace
+
+extern "C" int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, int B, int N, int C,
+                                int heads, int ldq, int ldk, float scale, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!q || !k || !vt || !out) return sta_fail(STA_E_ARG, "null pointer");
+  if (B < 1 || B > 65535 || N < 8 || N % 8 || C <= 0 || heads <= 0 || C % heads)
+    return sta_fail(STA_E_ARG, "bad shape B=%d N=%d C=%d heads=%d (need N %% 8 == 0)", B, N, C, heads);
+  const int d = C / heads;
+  if (d % 8 || d > 96 || ldq < C || ldk < C || ldq % 8 || ldk % 8)
+    return sta_fail(STA_E_UNSUP, "self-attention needs d %% 8 == 0, d <= 96, row strides >= C and %% 8 == 0 (d=%d)", d);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, scale * 1.4426950408889634f};
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == STA_BF16 ? dispatch_sa<__bf16>(p, st) : dispatch_sa<_Float16>(p, st);
+}

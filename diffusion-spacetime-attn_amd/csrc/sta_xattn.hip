@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "sta_xattn.h"
+#include "sta_internal.h"
 
 namespace {
 
@@ -577,7 +578,7 @@ __global__ __launch_bounds__(64 * NWV) void xattn_fwd_staged_kernel(const Params
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int L = p.head_major ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);   // see xattn_fwd_kernel
   int tile, h;
   if (p.H == 8) { tile = L >> 3; h = L & 7; } else { tile = L / p.H; h = L % p.H; }
   const int N = p.N, C = p.C, d = p.d, K = p.K;
@@ -993,16 +994,21 @@ __global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restri
 // --------------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------------
-thread_local char g_err[256] = "";
+}  // namespace
 
-int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
-int fail(int code, const char* fmt, ...) {
+// error text shared by every translation unit of the library (sta_internal.h)
+thread_local char g_sta_err[256] = "";
+int sta_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
-  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  vsnprintf(g_sta_err, sizeof g_sta_err, fmt, ap);
   va_end(ap);
   return code;
 }
+
+namespace {
+#define g_err g_sta_err
+#define fail sta_fail
 
 // waves per workgroup: the largest of {4,2,1} that still gives >= 256 workgroups (one per CU);
 // small levels (N = 64..256) fall to 1 wave so the launch spreads over as many CUs as possible.
@@ -1064,6 +1070,8 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   constexpr int TP = 16 * NWV * QT;
   Params p = p0;
   p.ntiles = (p.N + TP - 1) / TP;
+  p.head_major = (p.H % 8 == 0 && NDT >= 5) ? 1 : 0;   // one head per XCD: its K/V image is fetched by one L2 only
+  if (const char* e = getenv("STA_FWD_HEAD_MAJOR")) p.head_major = atoi(e) ? 1 : 0;
   int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
   if (G > p.K + 2) G = p.K + 2;
   p.ntiles_aux = G;

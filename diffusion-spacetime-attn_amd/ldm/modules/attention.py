@@ -70,14 +70,30 @@ class CrossAttention(nn.Module):
         if mask is not None or self_attention_region is not None:
             # dead branches on the reference's path (attention.py:187-191, :199-213 hard-code batch 6/2)
             raise NotImplementedError("mask / self_attention_region are not part of the spatial-temporal path")
+        h = self.heads
+        if context is None and not torch.is_grad_enabled() and _ops.self_attention_supported(x, h):
+            return self._self_attention_hip(x)
         context = x if context is None else context
         b, n, _ = x.shape
-        h = self.heads
         q = self.to_q(x).view(b, n, h, -1).transpose(1, 2)
         k = self.to_k(context).view(b, context.shape[1], h, -1).transpose(1, 2)
         v = self.to_v(context).view(b, context.shape[1], h, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
         return self.to_out(o.transpose(1, 2).reshape(b, n, -1))
+
+    def _self_attention_hip(self, x):
+        """attn1 without autograd: the flash-style HIP kernel (csrc/sta_selfattn.hip). q and k come out of ONE
+        GEMM against the concatenated [Wq; Wk] (the kernel takes a row stride), V is produced already
+        transposed (W_v x^T, [B, C, N]) because the PV product wants keys contiguous per channel."""
+        wq, wk = self.to_q.weight, self.to_k.weight
+        key = (wq.data_ptr(), wq._version, wk.data_ptr(), wk._version)
+        if getattr(self, "_wqk_key", None) != key:
+            self._wqk, self._wqk_key = torch.cat([wq.detach(), wk.detach()]), key
+        c = wq.shape[0]
+        qk = F.linear(x, self._wqk)                                   # [B, N, 2C]
+        vt = torch.matmul(self.to_v.weight, x.transpose(1, 2))        # [B, C, N]
+        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
+        return self.to_out(o)
 
 
 class _PromptCache:

@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, "sta_xattn.hip")]
+SOURCES = [os.path.join(CSRC, "sta_xattn.hip"), os.path.join(CSRC, "sta_selfattn.hip")]
 
 STA_BF16, STA_F16 = 0, 1
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
@@ -31,6 +31,7 @@ SYMBOLS = {
     "sta_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
 }
 
 
@@ -42,7 +43,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h")]
+    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(CSRC, "sta_internal.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -54,7 +55,7 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise StaLibraryError("hipcc not found; cannot build %s" % LIB_PATH)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", INCLUDE, *SOURCES, "-o", LIB_PATH + ".tmp"]
+           "-I", INCLUDE, "-I", CSRC, *SOURCES, "-o", LIB_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     r = subprocess.run(cmd, capture_output=True, text=True)

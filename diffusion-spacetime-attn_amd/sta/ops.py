@@ -197,3 +197,30 @@ def xattn_blend(q, coef, packed, mask, scale):
     Gradients flow to q and coef only (see include/sta_xattn.h).
     """
     return _XAttnBlend.apply(q, coef, packed, mask, scale)
+
+
+def self_attention(q, k, vt, heads, scale):
+    """Flash-style self-attention through the HIP kernel (inference only, no autograd).
+    q, k: [B, N, C] (last dim contiguous; a row stride > C is allowed, e.g. slices of a fused QKV buffer);
+    vt: [B, C, N] contiguous (V transposed). Returns [B, N, C]."""
+    B, N, C = q.shape
+    if k.shape != q.shape or tuple(vt.shape) != (B, C, N):
+        raise ValueError("shapes: q/k [B,N,C], vt [B,C,N]; got %s %s %s" % (tuple(q.shape), tuple(k.shape), tuple(vt.shape)))
+    if not q.is_cuda:
+        raise RuntimeError("self_attention needs CUDA/HIP tensors (there is no CPU path)")
+    for t in (q, k):
+        if t.stride(2) != 1 or t.stride(0) != N * t.stride(1):
+            raise ValueError("q/k must be row-major with a uniform row stride")
+    vt = vt.contiguous()
+    out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
+    L = _lib.load()
+    _lib.check(L.sta_selfattn_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, N, C, heads,
+                                  q.stride(1), k.stride(1), float(scale), _dtype_code(q), _stream(q)), "sta_selfattn_fwd")
+    return out
+
+
+def self_attention_supported(x, heads):
+    """Shapes the HIP self-attention kernel takes (the rest goes to PyTorch's SDPA)."""
+    B, N, C = x.shape
+    d = C // heads
+    return x.is_cuda and x.dtype in _DTYPES and N % 8 == 0 and N >= 64 and d % 8 == 0 and d <= 96 and C % heads == 0

@@ -115,6 +115,19 @@ int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const 
                   const void* dout, void* dq, float* dcoef, void* workspace,
                   int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
 
+/*
+ * Flash-style self-attention of the same transformer block (attn1; CrossAttention.forward with
+ * context = x, attention.py:175-197 called at :274), inference only: out = softmax(scale q k^T) v per head
+ * without materialising the [heads, N, N] scores. SURVEY.md §8f rank 2.
+ *   q   : [B][N][ldq]  dtype, head h in columns h*d .. h*d+d-1 (ldq >= C lets q live in a fused QKV buffer)
+ *   k   : [B][N][ldk]  dtype
+ *   vt  : [B][C][N]    dtype — V TRANSPOSED (the host computes W_v x^T instead of x W_v^T)
+ *   out : [B][N][C]    dtype
+ * Requires N % 8 == 0, d = C/heads <= 96, d % 8 == 0.
+ */
+int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out,
+                     int B, int N, int C, int heads, int ldq, int ldk, float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,8 @@ import sys
 
 import pytest
 
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")     # skip MIOpen's exhaustive solver benchmarking on fresh boxes
+
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, "diffusion-spacetime-attn_amd")
 for p in (REPO, PKG):

@@ -35,6 +35,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     # host-only entry points (no GPU work)
     assert L.sta_xattn_packed_kv_bytes(4, 8, 40) == 4 * 8 * 2 * (5 * 2 + 3 * 3) * 1024
     assert L.sta_xattn_packed_kv_bytes(4, 8, 168) == 0 and L.sta_xattn_packed_kv_bytes(4, 8, 20) == 0
+    assert L.sta_selfattn_fwd(0, 0, 0, 0, 2, 64, 64, 8, 64, 64, 1.0, 0, 0) == -1 and b"null" in L.sta_last_error()
     assert L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2) >= 2 * 256 * 8 * 4
     assert L.sta_xattn_bwd_workspace_bytes(3, 4096, 8, 2) == 3 * L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2)
 

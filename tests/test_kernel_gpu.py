@@ -162,6 +162,29 @@ def test_batched_images_match_oracle_per_image(N, C, heads, K):
             assert ((dcoef.view(I, K)[i].cpu().double() - gc).abs() <= tol).all()
 
 
+@pytest.mark.parametrize("B,N,C,heads", [(2, 4096, 320, 8), (4, 1024, 640, 8), (2, 144, 640, 8), (2, 576, 192, 4),
+                                          (2, 64, 64, 8), (3, 200, 256, 4), (2, 2304, 640, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_self_attention_matches_reference(B, N, C, heads, dtype):
+    """Flash-style self-attention kernel (attn1) vs softmax(q k^T scale) v in fp64 on the same 16-bit inputs;
+    q/k taken as strided slices of one [B, N, 2C] buffer, V transposed — as the block feeds them."""
+    from sta import ops
+    g = torch.Generator().manual_seed(N + C)
+    qk = torch.randn(B, N, 2 * C, generator=g).to(dtype)
+    v = torch.randn(B, N, C, generator=g).to(dtype)
+    d, scale = C // heads, (C // heads) ** -0.5
+    qk_d, vt_d = qk.cuda(), v.transpose(1, 2).contiguous().cuda()
+    out = ops.self_attention(qk_d[..., :C], qk_d[..., C:], vt_d, heads, scale)
+    torch.cuda.synchronize()
+    q64 = qk[..., :C].double().view(B, N, heads, d).transpose(1, 2)
+    k64 = qk[..., C:].double().view(B, N, heads, d).transpose(1, 2)
+    v64 = v.double().view(B, N, heads, d).transpose(1, 2)
+    ref = (torch.softmax(q64 @ k64.transpose(-1, -2) * scale, -1) @ v64).transpose(1, 2).reshape(B, N, C)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (out.float().cpu().double() - ref).abs()
+    assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
+
+
 def test_autograd_function_roundtrip():
     from sta import ops
     N, C, heads, K = 256, 320, 8, 2
