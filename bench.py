@@ -26,10 +26,13 @@ for p in (REPO, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# MIOpen's default find mode benchmarks every applicable convolution solver (including its naive reference
-# kernels) the first time a shape is seen: 3 minutes of warm-up at batch 16 on a fresh box. FAST mode picks by
-# heuristics/immediate mode; measured throughput is identical (3.344 vs 3.350 images/s), warm-up 36 s vs 207 s.
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
+
+# MIOpen benchmarks every applicable convolution solver the first time it sees a shape; its naive reference
+# solvers (50-400 ms per run at these sizes) make that 200 s of warm-up on a fresh box. Excluding only those
+# keeps the real solver search: warm-up 11 s, same steady state (3.2-3.4 images/s either way). NOTE:
+# MIOPEN_FIND_MODE=FAST is NOT an option — on a cold find-db it falls back to CK kernels that are 5x slower.
+for _k in ("FWD", "BWD", "WRW"):
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
 
 import torch  # noqa: E402
 

@@ -221,6 +221,9 @@ def self_attention(q, k, vt, heads, scale):
 
 def self_attention_supported(x, heads):
     """Shapes the HIP self-attention kernel takes (the rest goes to PyTorch's SDPA)."""
+    import os
+    if os.environ.get("STA_SELFATTN", "1") == "0":      # tuning/debug knob: fall back to PyTorch SDPA for attn1
+        return False
     B, N, C = x.shape
     d = C // heads
     return x.is_cuda and x.dtype in _DTYPES and N % 8 == 0 and N >= 64 and d % 8 == 0 and d <= 96 and C % heads == 0

@@ -3,7 +3,9 @@ import sys
 
 import pytest
 
-os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")     # skip MIOpen's exhaustive solver benchmarking on fresh boxes
+for _k in ("FWD", "BWD", "WRW"):      # keep MIOpen's naive reference solvers out of its first-use solver search
+    os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
+
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(REPO, "diffusion-spacetime-attn_amd")
