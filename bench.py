@@ -249,8 +249,8 @@ def main():
         achieved = byts / us / 1e3
         traffic = None
         pmc = os.path.join(REPO, "profiles", "xattn_fwd_hbm_traffic.json")
-        if os.path.exists(pmc) and I == 1:
-            traffic = json.load(open(pmc)).get("bytes_per_launch")
+        if os.path.exists(pmc):      # rocprofv3 --pmc passes of tools/kernel_bench.py, committed per images-per-launch
+            traffic = json.load(open(pmc)).get("by_images_per_launch", {}).get(str(I), {}).get("bytes_per_launch")
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                            "kernel": "xattn_fwd{,_staged}_kernel (fused QK^T+softmax+disc mask+blend+PV), 16 launches per UNet call, "
