@@ -133,8 +133,12 @@ class BasicTransformerBlock(nn.Module):
     @staticmethod
     def _per_image_boxes(bboxs_curr, n_img):
         """bboxs_curr is the reference's list of K [x, y] for one image, or a list of n_img such lists."""
-        boxes = [bboxs_curr] if n_img == 1 and (len(bboxs_curr) == 0 or not isinstance(bboxs_curr[0][0], (list, tuple))) \
-            else list(bboxs_curr)
+        def is_box(b):                      # [x, y]
+            return len(b) == 2 and not isinstance(b[0], (list, tuple))
+        if n_img == 1 and (len(bboxs_curr) == 0 or is_box(bboxs_curr[0])):
+            boxes = [bboxs_curr]             # the reference's form: K boxes of the one image
+        else:
+            boxes = list(bboxs_curr)         # one list of boxes per image
         if len(boxes) != n_img or any(len(b) != len(boxes[0]) for b in boxes):
             raise ValueError("need one box list per image, all with the same number of objects (got %d lists for %d images)"
                              % (len(boxes), n_img))

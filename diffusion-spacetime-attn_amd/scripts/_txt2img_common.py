@@ -54,6 +54,8 @@ def build_parser(default_dataset):
     p.add_argument("--limit", type=int, default=500)
     p.add_argument("--dtype", type=str, choices=["bf16", "fp16"], default="bf16")
     p.add_argument("--synthetic", action="store_true", help="synthetic weights/text embeddings when no checkpoint is available")
+    p.add_argument("--batch_prompts", type=int, default=1,
+                   help="sample up to this many prompts with the same object count together (one CFG batch of 2I per UNet call)")
     return p
 
 
@@ -88,10 +90,10 @@ def run(kind, default_dataset):
     seed = 1                                                            # txt2img-gpt.py:304
     shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
     todo = list(enumerate(prompts))[opt.start: opt.start + 500]
-    for j in parallel.shard_indices(len(todo), rank, world):
-        prompt_idx, prompt = todo[j]
+    mine = [todo[j] for j in parallel.shard_indices(len(todo), rank, world)]
+
+    def run_one(prompt_idx, prompt, layout):
         torch.manual_seed(seed)                                         # seed_everything(seed), :306
-        layout = datasets.layout_for(layouts, prompt, prompt_idx) or {}
         print("[rank %d] Start inference for %dth prompt: %s" % (rank, prompt_idx, prompt))
         names = list(layout.keys())
         uc, c, local_c = conditionings(model, prompt, names, dtype)
@@ -100,4 +102,31 @@ def run(kind, default_dataset):
                        unconditional_guidance_scale=opt.scale, unconditional_conditioning=uc, eta=opt.ddim_eta, x_T=x_T,
                        text_index=0, curr_text=prompt, bboxs_curr=[layout[n] for n in names], seed=seed,
                        prompt_idx=prompt_idx, object_names=names, local_conditionings=local_c)
+
+    def run_group(group):
+        """Prompts with the same number of objects share one CFG batch; every image keeps the reference's
+        per-prompt start: seed_everything(1) then randn, i.e. the same x_T for each."""
+        torch.manual_seed(seed)
+        x1 = torch.randn([1, *shape], device=dev)
+        conds = [conditionings(model, p, list(l.keys()), dtype) for _, p, l in group]
+        print("[rank %d] Start inference for prompts %s" % (rank, [i for i, _, _ in group]))
+        sampler.sample_batch(S=opt.ddim_steps, shape=shape, conditionings=[c[1] for c in conds],
+                             unconditional_conditionings=[c[0] for c in conds],
+                             bboxs=[[l[n] for n in l] for _, _, l in group], object_names=[list(l.keys()) for _, _, l in group],
+                             local_conditionings=[c[2] for c in conds], curr_texts=[p for _, p, _ in group],
+                             x_T=x1.expand(len(group), -1, -1, -1), unconditional_guidance_scale=opt.scale, eta=opt.ddim_eta,
+                             seed=seed, prompt_indices=[i for i, _, _ in group])
+
+    items = [(i, p, datasets.layout_for(layouts, p, i) or {}) for i, p in mine]
+    if opt.batch_prompts <= 1:
+        for i, p, l in items:
+            run_one(i, p, l)
+    else:
+        by_k = {}
+        for it in items:
+            by_k.setdefault(len(it[2]), []).append(it)
+        for k in sorted(by_k):
+            g = by_k[k]
+            for a in range(0, len(g), opt.batch_prompts):
+                run_group(g[a:a + opt.batch_prompts])
     parallel.barrier()

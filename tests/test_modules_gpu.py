@@ -181,6 +181,30 @@ def test_weight_optimisation_on_gpu():
     assert (step > 0.0049).float().mean() >= 0.8, step
 
 
+def test_entry_point_script_end_to_end(tmp_path):
+    """scripts/txt2img-mscoco.py on a 4-prompt dataset with a layout JSON: synthetic SD-v1 weights, fixed blend
+    weights, 3 PLMS steps; one prompt alone + batches grouped by object count; PNGs named like the reference's
+    (result_outputs/final{E}_s{seed}_index_{prompt_idx}.png, plms.py:286-288)."""
+    import subprocess
+    import sys
+    prompts = json.load(open(os.path.join(G, "prompts.json")))["mscoco64"][:4]
+    ds = tmp_path / "mscoco.txt"
+    ds.write_text("\n".join(p["prompt"] for p in prompts))
+    layout = {p["prompt"]: {o: [0.3 + 0.4 * j, 0.5] for j, o in enumerate(p["objects"])} for p in prompts[:3]}   # 4th: no objects
+    (tmp_path / "layout.json").write_text(json.dumps(layout))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(repo, "diffusion-spacetime-attn_amd", "scripts", "txt2img-mscoco.py")
+    for extra in ([], ["--batch_prompts", "4"]):
+        out = subprocess.run([sys.executable, script, "--plms", "--ddim_steps", "4", "--synthetic", "--opt_epochs", "0", "--dataset", str(ds),
+                              "--layout", str(tmp_path / "layout.json"), "--limit", "4", "--outdir", str(tmp_path / "o")] + extra,
+                             cwd=tmp_path, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+        pngs = sorted(os.listdir(tmp_path / "result_outputs"))
+        assert pngs == ["final0_s1_index_%d.png" % i for i in range(4)], pngs
+        for f in pngs:
+            os.remove(tmp_path / "result_outputs" / f)
+
+
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
