@@ -82,7 +82,10 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   constexpr int NKF = 4 * NKS;            // K fragments per block: 4 key tiles x NKS head-dim steps
   constexpr int NVF = 2 * NDT;            // V^T fragments per block: 2 key steps x NDT head-dim tiles
   constexpr int NFR = NKF + NVF;
-  constexpr int BB = NFR * FRAG;          // LDS bytes per block buffer
+  constexpr int PER = (NFR + 3) / 4;      // LDS-DMA instructions per wave per block (same for every wave: the
+  constexpr int NFRP = 4 * PER;           //   counted vmcnt below needs it) -> NFRP - NFR padding copies
+  constexpr int BB = NFRP * FRAG;         // LDS bytes per block buffer (padding copies land in its tail)
+  constexpr int DEPTH = 3;                // blocks resident in LDS: compute blk while blk+1, blk+2 are in flight
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -111,24 +114,52 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 
   // LDS-DMA of one 64-key block: every wave copies fragments wv, wv+4, ... ; per-lane source addresses,
   // lane-linear destination. Out-of-range rows/keys are clamped to valid memory (their products are
-  // multiplied by zero Q slots, masked scores or discarded output rows).
+  // multiplied by zero Q slots, masked scores or discarded output rows). The per-lane source pointers are
+  // computed ONCE and advanced by a constant per block (64 key rows of K, 64 keys along a V^T row): the
+  // address arithmetic of a naive per-block recomputation was most of the loop's instruction count.
+  const char* src[PER];
+  int step[PER];                           // bytes per block
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int f = wv + 4 * i;
+    const int fs = f < NFR ? f : 0;       // padding copy: re-read fragment 0 into the unused tail slot
+    if (fs < NKF) {
+      const int Tt = fs / NKS, s = fs - Tt * NKS;
+      src[i] = (const char*)(kb + (size_t)min(tile_key(Tt, c16), N - 1) * p.ldk + min(32 * s + 8 * g, d - 8));
+      step[i] = __builtin_amdgcn_readfirstlane(KB * p.ldk * (int)sizeof(T));     // wave-uniform -> SGPR
+    } else {
+      const int f2 = fs - NKF;
+      const int s2 = f2 / NDT, u = f2 - s2 * NDT;
+      src[i] = (const char*)(vb + (size_t)min(16 * u + c16, d - 1) * N + min(32 * s2 + 8 * g, N - 8));
+      step[i] = __builtin_amdgcn_readfirstlane(KB * (int)sizeof(T));
+    }
+  }
+  const int nfull = N / KB;                // blocks whose 64 keys all exist (the incremental pointers are exact)
   auto stage = [&](int blk, char* dst) {
-    const int k0 = blk * KB;
-    for (int f = wv; f < NFR; f += 4) {
-      const T* src;
-      if (f < NKF) {
-        const int Tt = f / NKS, s = f - Tt * NKS;
-        const int key = min(k0 + tile_key(Tt, c16), N - 1);
-        const int dd = min(32 * s + 8 * g, d - 8);
-        src = kb + (size_t)key * p.ldk + dd;
-      } else {
-        const int f2 = f - NKF;
-        const int s2 = f2 / NDT, u = f2 - s2 * NDT;
-        const int row = min(16 * u + c16, d - 1);
-        const int key = min(k0 + 32 * s2 + 8 * g, N - 8);
-        src = vb + (size_t)row * N + key;
+    if (blk < nfull) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                         (__attribute__((address_space(3))) void*)(dst + (wv + 4 * i) * FRAG), 16, 0, 0);
+        src[i] += step[i];
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+      return;
+    }
+    const int k0 = blk * KB;               // partial last block (N % 64 != 0): clamp every key
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int f = wv + 4 * i;
+      const int fs = f < NFR ? f : 0;
+      const T* sp;
+      if (fs < NKF) {
+        const int Tt = fs / NKS, s = fs - Tt * NKS;
+        sp = kb + (size_t)min(k0 + tile_key(Tt, c16), N - 1) * p.ldk + min(32 * s + 8 * g, d - 8);
+      } else {
+        const int f2 = fs - NKF;
+        const int s2 = f2 / NDT, u = f2 - s2 * NDT;
+        sp = vb + (size_t)min(16 * u + c16, d - 1) * N + min(k0 + 32 * s2 + 8 * g, N - 8);
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
                                        (__attribute__((address_space(3))) void*)(dst + f * FRAG), 16, 0, 0);
     }
   };
@@ -143,17 +174,21 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
     for (int u = 0; u < NDT; ++u) o[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
+  // 3-deep LDS ring, one barrier per block. An LDS-DMA is a pending write on the VM counter, so the wait is a
+  // COUNTED vmcnt (the PER newest DMAs — block blk+1 — may stay in flight) and the barrier is the raw s_barrier:
+  // __syncthreads() would emit vmcnt(0) and drain the ring (cdna_hip_programming.md, "Pipelining across barriers").
   const int nblk = (N + KB - 1) / KB;
   stage(0, smem_sa);
+  if (nblk > 1) stage(1, smem_sa + BB);
   for (int blk = 0; blk < nblk; ++blk) {
-    char* cur = smem_sa + (blk & 1) * BB;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                                   // block `blk` landed; everyone left block blk-1
-    if (blk + 1 < nblk) stage(blk + 1, smem_sa + ((blk + 1) & 1) * BB);
+    char* cur = smem_sa + (blk % DEPTH) * BB;
+    if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                      // block `blk` landed for every wave; everyone left block blk-1
+    if (blk + 2 < nblk) stage(blk + 2, smem_sa + ((blk + 2) % DEPTH) * BB);
+    const bool tail = (blk + 1) * KB > N;              // partial last block: mask the missing keys
     const V8* fr = (const V8*)cur + lane;
-    const bool tail = (blk + 1) * KB > N;
-
-    // S^T = K Q^T for the 4 key tiles of the block
     V8 ka[NKF];
 #pragma unroll
     for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
@@ -170,11 +205,13 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #pragma unroll
     for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
 
-    // online softmax per pixel (lane & 15); the row sum is kept per lane and reduced once at the end
     V8 pb[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       if (tail) {
+        // a real branch, taken only for a partial last block: the empty volatile asm keeps hipcc from
+        // if-converting it into 16 compare+select pairs that would execute on every block
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -188,8 +225,11 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       bm = bfly_max(bm);
       const float mnew = fmaxf(mrun[qt], bm);
       const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * p.sl2e);
-      const float off = mnew * p.sl2e;
       mrun[qt] = mnew;
+      lrun[qt] *= alpha;
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) o[qt][u] *= alpha;
+      const float off = mnew * p.sl2e;
       float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
@@ -199,9 +239,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
           st[qt][t][r] = e;
           rs += e;
         }
-      lrun[qt] = lrun[qt] * alpha + rs;
-#pragma unroll
-      for (int u = 0; u < NDT; ++u) o[qt][u] *= alpha;
+      lrun[qt] += rs;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -238,7 +276,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 template <typename T, int NKS, int NDT>
 int launch_sa(const SParams& p, hipStream_t st) {
   constexpr int QT = 2;
-  constexpr int lds = 2 * (4 * NKS + 2 * NDT) * FRAG;
+  constexpr int lds = 3 * (((4 * NKS + 2 * NDT) + 3) / 4 * 4) * FRAG;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
