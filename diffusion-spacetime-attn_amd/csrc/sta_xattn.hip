@@ -97,6 +97,8 @@ struct Params {
   int ntiles;            // pixel tiles per head
   int ntiles_aux;        // staged forward: contexts that fit LDS at once
   int head_major;        // 1: block b -> head b % H (= XCD b % 8 when H == 8); 0: XCD-contiguous tile ranges
+  int iters;             // staged forward: pixel tiles a workgroup walks with one LDS image
+  int tiles;             // staged forward: pixel tiles per head (ntiles = workgroups per head)
   int n_img;             // images in this launch (blockIdx.y); every tensor has a leading image axis
   float sl2e;            // scale * log2(e)
   float scale;
@@ -128,7 +130,7 @@ __device__ long long* g_trace = nullptr;
 // the pointer and the traced workgroup are read ONCE (STA_T_INIT); each point is then one store
 #define STA_T_INIT()                                                                       \
   long long* trace_base = g_trace;                                                          \
-  const bool trace_on = trace_base && blockIdx.x == (unsigned)trace_base[0] && (threadIdx.x & 63) == 0; \
+  const bool trace_on = trace_base && blockIdx.x == (unsigned)trace_base[0] && blockIdx.y == 0 && (threadIdx.x & 63) == 0; \
   long long* trace_row = trace_base + 8 + (threadIdx.x >> 6) * 16;                          \
   const long long trace_t0 = (long long)wall_clock64();                                    \
   if (trace_on) trace_row[15] = trace_t0
@@ -139,9 +141,9 @@ __device__ long long* g_trace = nullptr;
 #define STA_T_END()                                                                       \
   do {                                                                                     \
     if (trace_on) trace_row[14] = (long long)wall_clock64();                               \
-    if (trace_base && trace_base[1] && threadIdx.x == 0) {                                  \
-      trace_base[128 + 2 * blockIdx.x] = trace_t0;                                         \
-      trace_base[129 + 2 * blockIdx.x] = (long long)wall_clock64();                        \
+    if (trace_base && trace_base[1] && threadIdx.x == 0) {                               \
+      trace_base[128 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = trace_t0;                                         \
+      trace_base[129 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = (long long)wall_clock64();                        \
     }                                                                                      \
   } while (0)
 #else
@@ -335,6 +337,40 @@ __device__ __forceinline__ float softmax_keys_fast(f32x4 (&st)[NKT], int g, int 
   return 1.0f / l;
 }
 
+// Predicate-free softmax for the forward kernels. The scores of padded keys (key >= M) are forced to -1e30
+// through the INITIAL VALUE of the S^T accumulator (last_tile_bias; with M > 64 only the last key tile has
+// padded rows), so no per-key compare/select is left in the loop: 10 packed multiplies, 10 v_max3, the
+// two-step butterfly, 10 packed subtracts, 20 v_exp, 10 adds and one v_rcp — about a third of the VALU
+// instructions of softmax_keys_fast, which matters once a launch carries several images and the kernel is
+// VALU-issue bound instead of latency bound (profiles/r01_kernel_variants.md).
+__device__ __forceinline__ f32x4 last_tile_bias(int g, int M) {
+  f32x4 b;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) b[r] = (16 * (NKT - 1) + 4 * g + r < M) ? 0.f : -1.0e30f;
+  return b;
+}
+__device__ __forceinline__ float softmax_biased(f32x4 (&st)[NKT], float sl2e) {
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) st[t] = st[t] * sl2e;        // products are canonical: v_max3 needs no quieting
+  float ma = fmaxf(st[0][0], st[0][1]), mb = fmaxf(st[0][2], st[0][3]);
+#pragma unroll
+  for (int t = 1; t < NKT; ++t) {
+    ma = fmaxf(fmaxf(ma, st[t][0]), st[t][1]);
+    mb = fmaxf(fmaxf(mb, st[t][2]), st[t][3]);
+  }
+  const float mx = bfly_max(fmaxf(ma, mb));
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    st[t] = st[t] - mx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(st[t][r]);
+    acc = acc + st[t];
+  }
+  const float l = bfly_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
+  return __builtin_amdgcn_rcpf(l);
+}
+
 template <typename T, int NDT, int QT>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
@@ -427,6 +463,9 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
     }
   }
   if (p.aux) tile_bits = (1u << K) - 1u;          // parity mode: every map is wanted
+  // predicate-free softmax (see softmax_biased) unless maps are wanted or whole key tiles are padding
+  const bool fast = !p.aux && p.M > 16 * (NKT - 1);
+  const f32x4 kb4 = fast ? last_tile_bias(g, p.M) : f32x4{0.f, 0.f, 0.f, 0.f};
   STA_T(2);
 
   f32x4 part[QT][NDT];                            // this wave's row-1 partial (wave 0, ctx 0: A_u)
@@ -439,7 +478,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < NKT; ++t) st[qt][t] = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < NKT; ++t)
 #pragma unroll
@@ -453,7 +492,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
       V8 pb[QT][NPS];
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
-        const float inv = softmax_keys_fast(st[qt], g, p.M, p.sl2e);
+        const float inv = fast ? softmax_biased(st[qt], p.sl2e) : softmax_keys_fast(st[qt], g, p.M, p.sl2e);
         if (p.aux && px0 + 16 * qt + c16 < N) {
           float* mrow = p.aux + (((size_t)c * p.H + h) * N + (px0 + 16 * qt + c16)) * p.M;
 #pragma unroll
@@ -468,9 +507,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
         wc[qt] = inv;
         if (c >= 2) {   // this context's blend weight for the lane's pixel: coef_i * mask_i(px)
           const unsigned m = ((unsigned)__shfl((int)mbits, 16 * qt + c16) >> (c - 2)) & 1u;   // 0 for pixels >= N
-          float cw = 0.f;
-#pragma unroll
-          for (int i = 0; i < MAXK; ++i) cw = (i == c - 2) ? coefv[i] : cw;
+          const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), c - 2));
           wc[qt] = m ? inv * cw : 0.f;
         }
       }
@@ -566,23 +603,96 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
 // LDS fragment reads are hoisted into registers ahead of the MFMAs for the same reason the global
 // loads are in the other kernel. Contexts 0/1 are requested before the disc mask is known; local
 // contexts right after the tile test. If the contexts do not fit LDS at once they go in groups.
-template <typename T, int NDT, int QT, int NWV>
-__global__ __launch_bounds__(64 * NWV) void xattn_fwd_staged_kernel(const Params pin) {
+// One context of the LDS-resident kernel for the QT pixel tiles of a wave. KIND is compile time — 0: ""
+// on the uncond row (-> au), 1: global prompt on the cond row (-> ac), 2: a local prompt, ac += w (A - au) —
+// so there is no per-context select/copy of the accumulators, queries or weights left in the instruction
+// stream (the runtime-`c` version spent ~2/3 of its VALU slots on v_cndmask/v_mov and scalar branches).
+template <typename T, int NDT, int QT, int KIND>
+__device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, const typename Tr<T>::V8 (&q)[QT][nks_of(NDT)],
+                                              const f32x4 kb4, const float sl2e, const float (&w)[QT],
+                                              f32x4 (&au)[QT][NDT], f32x4 (&ac)[QT][NDT]) {
+  using V8 = typename Tr<T>::V8;
+  constexpr int NKS = nks_of(NDT);
+  constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
+  // LDS -> registers one operand side at a time, each ahead of its MFMAs (no ds_read -> wait -> mfma chains):
+  // the K side for S^T first; the V side is requested once the S^T MFMAs are issued and lands under the
+  // softmax VALU work, so at most one side (40 of the 76 fragment registers at d = 40) is live at a time.
+  // Each fragment serves QT pixel tiles, whose independent softmax chains interleave.
+  V8 ka[NKF], va[NVF];
+#pragma unroll
+  for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
+  f32x4 st[QT][NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) acc = Tr<T>::mfma(ka[t * NKS + s], q[qt][s], acc);
+      st[qt][t] = acc;
+    }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
+  float inv[QT];
+  V8 pb[QT][NPS];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    inv[qt] = softmax_biased(st[qt], sl2e);
+    tiles_to_b<T>(st[qt], pb[qt]);
+  }
+  f32x4 o[QT][NDT];
+#pragma unroll
+  for (int u = 0; u < NDT; ++u)
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc);
+      o[qt][u] = acc;
+    }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const float wi = w[qt] * inv[qt];
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      if (KIND == 0) au[qt][u] = o[qt][u] * inv[qt];
+      else if (KIND == 1) ac[qt][u] = o[qt][u] * inv[qt];
+      else ac[qt][u] = o[qt][u] * wi + (ac[qt][u] - au[qt][u] * w[qt]);
+    }
+  }
+}
+
+// A workgroup keeps the fragments of one head in LDS and walks `p.iters` consecutive pixel tiles of
+// 16*NWV*QT pixels with them: the staging traffic (L2 -> LDS, 19-55 KB per context) and the staging
+// latency are paid once per workgroup instead of once per 64/128 pixels — at 8 images per launch the
+// re-staging was MORE bytes through the per-CU vector-memory path than q and out together. After the
+// one barrier the waves run independently (no barrier per tile): while one wave waits for the q rows of
+// its next tile, the other waves of the SIMD compute.
+// MAXIT = 1 is the single-tile build for launches with few workgroups (one image): no mask bytes beyond the
+// tile's own, no prefetch code.
+constexpr int STAGED_MAXIT = 8;
+template <typename T, int NDT, int QT, int NWV, int MAXIT>
+__global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
-  const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)(pin.K + 2) * pin.H * pin.N * pin.M);
+  const Params p = for_image<T, NDT>(pin, blockIdx.y, 0);
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NVF = NPS * NDT, NFWD = NKF + NVF;
   constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
-  constexpr int TP = 16 * NWV * QT;               // pixels per workgroup: NWV waves x QT tiles x 16
+  constexpr int TP = 16 * NWV * QT;               // pixels per tile: NWV waves x QT sub-tiles x 16
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
   const int L = p.head_major ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);   // see xattn_fwd_kernel
-  int tile, h;
-  if (p.H == 8) { tile = L >> 3; h = L & 7; } else { tile = L / p.H; h = L % p.H; }
+  int wt, h;
+  if (p.H == 8) { wt = L >> 3; h = L & 7; } else { wt = L / p.H; h = L % p.H; }
   const int N = p.N, C = p.C, d = p.d, K = p.K;
-  const int px0 = tile * TP;
+  // tiles of this workgroup: wt, wt + W, wt + 2W, ... (W = workgroups per head). Strided, not consecutive:
+  // the discs are spatially compact, so consecutive tiles would make some workgroups all-local (3-4
+  // contexts per pixel) and others all-global (2) — measured lifetimes 18-30 us at 8 images per launch.
+  const int W = p.ntiles, tiles = p.tiles;
+  const int iters = MAXIT == 1 ? 1 : ((tiles - wt + W - 1) / W < p.iters ? (tiles - wt + W - 1) / W : p.iters);
   const int G = p.ntiles_aux;                     // contexts that fit LDS at once (>= 2)
   STA_T_INIT();
   STA_T(0);
@@ -590,169 +700,140 @@ __global__ __launch_bounds__(64 * NWV) void xattn_fwd_staged_kernel(const Params
   const size_t ctx_stride = (size_t)p.H * all_frags(NDT) * FRAG;
   const char* img_h = p.packed + (size_t)h * all_frags(NDT) * FRAG;
 
-  // ---- prologue: oldest first — mask bits / weights, fragments of contexts 0 and 1, Q ------------
+  // ---- prologue: oldest first — weights, mask bits of every tile, fragments of contexts 0 and 1, Q ----
   const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
-  constexpr int NCH = TP / 64 > 0 ? TP / 64 : 1;   // 64-pixel chunks of the tile
-  unsigned tb[NCH];                                // lane <-> pixel px0 + 64*j + lane of the tile
+  constexpr int CPT = TP / 64;                     // 64-pixel chunks per tile
+  constexpr int MAXCH = MAXIT * CPT;
+  unsigned span_bits = 0;                          // OR of the mask bytes of this workgroup's pixels
+  {
+    unsigned tb[MAXCH];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) tb[j] = p.mask[min(px0 + 64 * j + lane, N - 1)];
-  stage_frags(img_h, smem, NFWD, wv, NWV, lane);
-  stage_frags(img_h + ctx_stride, smem + CB, NFWD, wv, NWV, lane);
-  // this wave's QT pixel tiles: pixels px0 + (wv*QT + qt)*16 + c16, rows 0 (uncond) and 1 (cond) of Q
-  V8 q0[QT][NKS], q1[QT][NKS];
-  bool valid[QT];
+    for (int j = 0; j < MAXCH; ++j)                // unconditional, clamped
+      tb[j] = p.mask[min((wt + (j / CPT) * W) * TP + 64 * (j % CPT) + lane, N - 1)];
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int px = px0 + (wv * QT + qt) * 16 + c16;
-    valid[qt] = px < N;
-    const T* qbase = (const T*)p.q + (size_t)px * C + h * d;
-    load_b_frags<T, NKS>(qbase, valid[qt], g, d, q0[qt]);
-    load_b_frags<T, NKS>(qbase + (size_t)N * C, valid[qt], g, d, q1[qt]);
+    for (int j = 0; j < MAXCH; ++j)
+      span_bits |= (j / CPT < iters && (wt + (j / CPT) * W) * TP + 64 * (j % CPT) + lane < N) ? tb[j] : 0u;
   }
+  auto stage_first_group = [&]() {
+    stage_frags(img_h, smem, NFWD, wv, NWV, lane);
+    stage_frags(img_h + ctx_stride, smem + CB, NFWD, wv, NWV, lane);
+  };
+  stage_first_group();
+  // a wave's QT sub-tiles of its it-th tile: pixels (wt + it*W)*TP + (wv*QT + qt)*16 + c16, rows 0 (uncond)
+  // and 1 (cond). The q rows (and mask byte) of tile it+1 are requested before tile it is computed.
+  V8 q0[QT][NKS], q1[QT][NKS], q0n[QT][NKS], q1n[QT][NKS];
+  unsigned mb[QT], mbn[QT];
+  auto request_q = [&](int it, V8 (&a0)[QT][NKS], V8 (&a1)[QT][NKS], unsigned (&m)[QT]) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int px = (wt + it * W) * TP + (wv * QT + qt) * 16 + c16;
+      const bool ok = it < iters && px < N;
+      m[qt] = p.mask[ok ? px : 0];
+      const T* qbase = (const T*)p.q + (size_t)(ok ? px : 0) * C + h * d;
+      load_b_frags<T, NKS>(qbase, ok, g, d, a0[qt]);
+      load_b_frags<T, NKS>(qbase + (size_t)N * C, ok, g, d, a1[qt]);
+    }
+  };
+  request_q(0, q0, q1, mb);
   __builtin_amdgcn_sched_barrier(0);
   STA_T(1);
 
-  unsigned tile_bits = 0, wave_bits = 0, mybits[QT];
-  float coefv[MAXK];
+  // which discs touch the tiles (workgroup-uniform: every wave looked at the same bytes)
+  unsigned tile_bits = 0;
+  span_bits &= (1u << K) - 1u;
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) tb[j] = (px0 + 64 * j + lane < N && 64 * j + lane < TP) ? (tb[j] & ((1u << K) - 1u)) : 0u;
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i) {
-    coefv[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
-    if (i < K) {
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const unsigned long long bl = __ballot((tb[j] >> i) & 1u);       // pixels 64j .. 64j+63 of the tile
-        if (bl) tile_bits |= 1u << i;
-        // this wave's pixels are 16*QT*wv .. +16*QT-1 of the tile: the part of them inside chunk j
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-          const int first = (wv * QT + qt) * 16;                         // tile-relative
-          if ((first >> 6) == j && ((bl >> (first & 63)) & 0xffffull)) wave_bits |= 1u << i;
-        }
-      }
+  for (int i = 0; i < MAXK; ++i)
+    if (i < K && __ballot((span_bits >> i) & 1u)) tile_bits |= 1u << i;
+  // active contexts in order: 0, 1, then the local ones whose disc touches a tile; entry e of that list
+  // sits in LDS slot e % G. Stage the locals that still fit beside contexts 0 and 1.
+  auto stage_locals = [&](unsigned bits, int first_slot, int count) {   // lowest `count` set bits of `bits`
+    for (int n = 0; n < count && bits; ++n) {
+      const int i = __builtin_ctz(bits);
+      bits &= bits - 1;
+      stage_frags(img_h + (size_t)(2 + i) * ctx_stride, smem + (first_slot + n) * CB, NFWD, wv, NWV, lane);
     }
-  }
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {                // mask bits of this lane's own pixel in tile qt
-    const int rel = (wv * QT + qt) * 16 + c16;
-    unsigned v = 0;
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const unsigned cand = (unsigned)__shfl((int)tb[j], rel & 63);
-      v = ((rel >> 6) == j) ? cand : v;
-    }
-    mybits[qt] = v;
-  }
-  if (p.aux) { tile_bits = (1u << K) - 1u; wave_bits = tile_bits; }      // parity mode: every map
-
-  // active contexts in order: 0, 1, then the local ones whose disc touches the tile (WG-uniform);
-  // entry e of the list sits in LDS slot e % G
-  const int n_active = 2 + __builtin_popcount(tile_bits);
-  auto ctx_of = [&](int e) {                      // e-th active context
-    if (e < 2) return e;
-    unsigned rest = tile_bits;
-    for (int k = 2; k < e; ++k) rest &= rest - 1;           // drop the lowest set bits
-    return 2 + (int)__builtin_ctz(rest);
   };
-  for (int e = 2; e < n_active && e < G; ++e)
-    stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + e * CB, NFWD, wv, NWV, lane);
-
+  stage_locals(tile_bits, 2, G - 2);
+  const bool resident = 2 + __builtin_popcount(tile_bits) <= G;   // everything stays in LDS for all tiles
+  const f32x4 kb4 = last_tile_bias(g, p.M);
+  const float sl2e = p.sl2e;
   STA_T(2);
-  f32x4 au[QT][NDT], ac[QT][NDT];
-  for (int e0 = 0; e0 < n_active; e0 += G) {
-    if (e0 > 0) {   // next group: everyone is done reading the previous one
+  wait_dma_and_sync();
+  STA_T(3);
+
+  for (int it = 0; it < iters; ++it) {
+    if (it == 1) STA_T(7);
+    if (it > 0 && !resident) {   // the first group was overwritten by a later one: bring it back
       __syncthreads();
-      for (int e = e0; e < n_active && e < e0 + G; ++e)
-        stage_frags(img_h + (size_t)ctx_of(e) * ctx_stride, smem + (e - e0) * CB, NFWD, wv, NWV, lane);
+      stage_first_group();
+      stage_locals(tile_bits, 2, G - 2);
+      wait_dma_and_sync();
     }
-    wait_dma_and_sync();
-    STA_T(3);
-    for (int e = e0; e < n_active && e < e0 + G; ++e) {
-      const int c = ctx_of(e);
-      if (e == 1) STA_T(4);
-      if (e == 2) STA_T(5);
-      if (c >= 2 && !((wave_bits >> (c - 2)) & 1u)) continue;   // none of this wave's pixels inside
-      const V8* fr = (const V8*)(smem + (e - e0) * CB) + lane;
-      // LDS -> registers for the whole context, then MFMAs (no ds_read -> wait -> mfma chains); each
-      // fragment serves QT pixel tiles, whose independent softmax chains interleave
-      V8 ka[NKF], va[NVF];
+    if (MAXIT > 1) request_q(it + 1, q0n, q1n, mbn);
+    if (it == 1) STA_T(9);
+    f32x4 au[QT][NDT], ac[QT][NDT];
+    float w[QT];
 #pragma unroll
-      for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
+    for (int qt = 0; qt < QT; ++qt) w[qt] = 0.f;
+    attend_staged<T, NDT, QT, 0>((const V8*)smem + lane, q0, kb4, sl2e, w, au, ac);
+    if (it == 0) STA_T(4);
+    if (it == 1) STA_T(10);
+    attend_staged<T, NDT, QT, 1>((const V8*)(smem + CB) + lane, q1, kb4, sl2e, w, au, ac);
+    if (it == 0) STA_T(5);
+    if (it == 1) STA_T(11);
+    unsigned wave_bits = 0;                        // discs that touch THIS wave's pixels of the tile
+    bool valid[QT];
 #pragma unroll
-      for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
-      f32x4 st[QT][NKT];
+    for (int qt = 0; qt < QT; ++qt) {
+      valid[qt] = (wt + it * W) * TP + (wv * QT + qt) * 16 + c16 < N;
+      mb[qt] = valid[qt] ? mb[qt] : 0u;
 #pragma unroll
-      for (int qt = 0; qt < QT; ++qt)
+      for (int i = 0; i < MAXK; ++i)
+        if (i < K && __ballot((mb[qt] >> i) & 1u)) wave_bits |= 1u << i;
+    }
+    unsigned rest = tile_bits;
+    for (int e = 2; rest; ++e) {
+      if (e >= G && e % G == 0) {   // next group: everyone is done reading the previous one
+        __syncthreads();
+        stage_locals(rest, 0, G);
+        wait_dma_and_sync();
+      }
+      const int i = __builtin_ctz(rest);
+      rest &= rest - 1;
+      if (!((wave_bits >> i) & 1u)) continue;     // none of this wave's pixels inside the disc
+      const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
 #pragma unroll
-        for (int t = 0; t < NKT; ++t) st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int qt = 0; qt < QT; ++qt) w[qt] = ((mb[qt] >> i) & 1u) ? cw : 0.f;
+      attend_staged<T, NDT, QT, 2>((const V8*)(smem + (e % G) * CB) + lane, q1, kb4, sl2e, w, au, ac);
+    }
+    if (it == 0) STA_T(6);
+    if (it == 1) STA_T(12);
 #pragma unroll
-      for (int t = 0; t < NKT; ++t)
+    for (int qt = 0; qt < QT; ++qt) {
+      if (valid[qt]) {
+        T* obase = (T*)p.out + (size_t)((wt + it * W) * TP + (wv * QT + qt) * 16 + c16) * C + h * d;
 #pragma unroll
-        for (int s = 0; s < NKS; ++s)
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt)
-            st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], c == 0 ? q0[qt][s] : q1[qt][s], st[qt][t]);
-      float inv[QT], w[QT];
-      V8 pb[QT][NPS];
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        inv[qt] = softmax_keys_fast(st[qt], g, p.M, p.sl2e);
-        if (p.aux && valid[qt]) {
-          float* mrow = p.aux + (((size_t)c * p.H + h) * N + (px0 + (wv * QT + qt) * 16 + c16)) * p.M;
-#pragma unroll
-          for (int t = 0; t < NKT; ++t)
+        for (int u = 0; u < NDT; ++u) {
+          const int dd = 16 * u + 4 * g;
+          if (dd < d) {
+            V4 r0, r1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int key = 16 * t + 4 * g + r;
-              if (key < p.M) mrow[key] = st[qt][t][r] * inv[qt];
+              r0[r] = (T)au[qt][u][r];
+              r1[r] = (T)ac[qt][u][r];
             }
-        }
-        tiles_to_b<T>(st[qt], pb[qt]);
-        w[qt] = inv[qt];
-        if (c >= 2) {
-          float cw = 0.f;
-#pragma unroll
-          for (int i = 0; i < MAXK; ++i) cw = (i == c - 2) ? coefv[i] : cw;
-          w[qt] = ((mybits[qt] >> (c - 2)) & 1u) ? cw : 0.f;
+            *(V4*)(obase + dd) = r0;
+            *(V4*)(obase + (size_t)N * C + dd) = r1;
+          }
         }
       }
+      if (MAXIT > 1) {
+        mb[qt] = mbn[qt];
 #pragma unroll
-      for (int u = 0; u < NDT; ++u) {
-        f32x4 acc[QT];
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) acc[qt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NPS; ++s)
-#pragma unroll
-          for (int qt = 0; qt < QT; ++qt) acc[qt] = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc[qt]);
-#pragma unroll
-        for (int qt = 0; qt < QT; ++qt) {
-          if (c == 0) au[qt][u] = acc[qt] * inv[qt];
-          else if (c == 1) ac[qt][u] = acc[qt] * inv[qt];
-          else ac[qt][u] += w[qt] * (acc[qt] * inv[qt] - au[qt][u]);
+        for (int s2 = 0; s2 < NKS; ++s2) {
+          q0[qt][s2] = q0n[qt][s2];
+          q1[qt][s2] = q1n[qt][s2];
         }
-      }
-    }
-  }
-
-  STA_T(6);
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    if (!valid[qt]) continue;
-    T* obase = (T*)p.out + (size_t)(px0 + (wv * QT + qt) * 16 + c16) * C + h * d;
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      const int dd = 16 * u + 4 * g;
-      if (dd < d) {
-        V4 r0, r1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          r0[r] = (T)au[qt][u][r];
-          r1[r] = (T)ac[qt][u][r];
-        }
-        *(V4*)(obase + dd) = r0;
-        *(V4*)(obase + (size_t)N * C + dd) = r1;
       }
     }
   }
@@ -773,32 +854,77 @@ __device__ __forceinline__ void attend_bwd(const char* buf, const typename Tr<T>
                                            float sl2e) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
-  constexpr int NFWD = fwd_frags(NDT);
+  constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
+  constexpr int NFWD = NKF + NVF;
   const V8* frag = (const V8*)buf + lane;
+  // Fragments are hoisted from LDS into registers ahead of the MFMAs that consume them (no ds_read -> wait ->
+  // mfma chains). Small head dims hoist a whole phase; from d = 112 up that would not fit the register file
+  // (scratch spills measured at d = 144/160), so the hoisting granularity drops to one operand set at a time.
+  constexpr bool BIG = NDT > 6 || NDT == 3;   // d = 40 (NDT 3): whole-phase hoisting costs the second wave per SIMD
+  // phase 1: S^T = KQ.q and dP^T = VQ.G^T
   f32x4 st[NKT], dp[NKT];
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if constexpr (!BIG) {
+    V8 ka[NKF], vq[NKF];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      st[t] = Tr<T>::mfma(frag[(t * NKS + s) * 64], qf[s], st[t]);
-      dp[t] = Tr<T>::mfma(frag[(NFWD + t * NKS + s) * 64], gf[s], dp[t]);  // VQ . G^T
+    for (int f = 0; f < NKF; ++f) ka[f] = frag[f * 64];
+#pragma unroll
+    for (int f = 0; f < NKF; ++f) vq[f] = frag[(NFWD + f) * 64];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        st[t] = Tr<T>::mfma(ka[t * NKS + s], qf[s], st[t]);
+        dp[t] = Tr<T>::mfma(vq[t * NKS + s], gf[s], dp[t]);
+      }
+  } else {
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      V8 ka[NKS], vq[NKS];
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) ka[s] = frag[(t * NKS + s) * 64];
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) vq[s] = frag[(NFWD + t * NKS + s) * 64];
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        st[t] = Tr<T>::mfma(ka[s], qf[s], st[t]);
+        dp[t] = Tr<T>::mfma(vq[s], gf[s], dp[t]);
+      }
     }
   }
-  const float inv = softmax_keys(st, g, M, sl2e);
+  const float inv = softmax_keys_fast(st, g, M, sl2e);
   V8 pb[NPS];
-  if (WANT_A) {
+  if (WANT_A) {   // phase 2: A = P V (needed for the dcoef dot product)
     tiles_to_b<T>(st, pb);
+    if constexpr (!BIG) {
+      V8 va[NVF];
 #pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int f = 0; f < NVF; ++f) va[f] = frag[(NKF + f) * 64];
 #pragma unroll
-      for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(frag[(NKT * NKS + s * NDT + u) * 64], pb[s], acc);
-      o[u] = acc * inv;
+      for (int u = 0; u < NDT; ++u) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[s], acc);
+        o[u] = acc * inv;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) {
+        V8 va[NPS];
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) va[s] = frag[(NKF + s * NDT + u) * 64];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s], pb[s], acc);
+        o[u] = acc * inv;
+      }
     }
   }
-  // delta and dS (in place in st). Padded keys have st == 0, so they contribute nothing.
+  // phase 3: delta, dS (in place in st; padded keys have st == 0) and dQ^T += KP.dS^T
   float delta = 0.f;
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
@@ -807,18 +933,30 @@ __device__ __forceinline__ void attend_bwd(const char* buf, const typename Tr<T>
       st[t][r] *= inv;
       delta += st[t][r] * dp[t][r];
     }
-  delta += __shfl_xor(delta, 16);
-  delta += __shfl_xor(delta, 32);
+  delta = bfly_sum(delta);
 #pragma unroll
   for (int t = 0; t < NKT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) st[t][r] = st[t][r] * (dp[t][r] - delta) * gscale;
   tiles_to_b<T>(st, pb);
+  if constexpr (!BIG) {
+    V8 kp[NVF];
 #pragma unroll
-  for (int u = 0; u < NDT; ++u)
+    for (int f = 0; f < NVF; ++f) kp[f] = frag[(NFWD + NKF + f) * 64];
 #pragma unroll
-    for (int s = 0; s < NPS; ++s)
-      dq[u] = Tr<T>::mfma(frag[(NFWD + NKT * NKS + s * NDT + u) * 64], pb[s], dq[u]);  // KP . dS^T
+    for (int u = 0; u < NDT; ++u)
+#pragma unroll
+      for (int s = 0; s < NPS; ++s) dq[u] = Tr<T>::mfma(kp[s * NDT + u], pb[s], dq[u]);
+  } else {
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      V8 kp[NPS];
+#pragma unroll
+      for (int s = 0; s < NPS; ++s) kp[s] = frag[(NFWD + NKF + s * NDT + u) * 64];
+#pragma unroll
+      for (int s = 0; s < NPS; ++s) dq[u] = Tr<T>::mfma(kp[s], pb[s], dq[u]);
+    }
+  }
 }
 
 template <typename T, int NDT>
@@ -835,31 +973,35 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params pin) {
   const int nw = blockDim.x >> 6;
   const int g = lane >> 4, c16 = lane & 15;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int tile = L / p.H, h = L % p.H;
+  int tile, h;
+  if (p.H == 8) { tile = L >> 3; h = L & 7; } else { tile = L / p.H; h = L % p.H; }
   const int px = (tile * nw + wv) * 16 + c16;
   const bool valid = px < p.N;
   const int N = p.N, C = p.C, d = p.d, K = p.K;
-  unsigned* flags = (unsigned*)(smem + (DB ? 2 : 1) * CB);
 
+  // disc membership of the workgroup's pixels (lane <-> pixel of the 16*nw-pixel tile) and the blend weights
+  // in one vector load each; every wave derives the same workgroup bits by ballots — no LDS flag, no barrier
+  // (with K == 0 the host points mask/coef at q: readable, ignored)
+  const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
+  unsigned tb = p.mask[min(tile * nw * 16 + lane, N - 1)];
+  tb = (lane < 16 * nw && tile * nw * 16 + lane < N) ? (tb & ((1u << K) - 1u)) : 0u;
   float w[MAXK], dc[MAXK];
   float wsum = 0.f;
-  unsigned mybits = 0;
+  unsigned mybits = 0, wgbits = 0;
+  const unsigned ownbits = (unsigned)__shfl((int)tb, 16 * wv + c16);       // this lane's own pixel
 #pragma unroll
   for (int i = 0; i < MAXK; ++i) {
+    const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
     w[i] = 0.f;
     dc[i] = 0.f;
     if (i < K) {
-      const bool m = valid && ((p.mask[px] >> i) & 1u) != 0;
-      w[i] = m ? p.coef[i] : 0.f;
+      const unsigned long long bl = __ballot((tb >> i) & 1u);
+      if (bl) wgbits |= 1u << i;
+      if ((bl >> (16 * wv)) & 0xffffull) mybits |= 1u << i;
+      w[i] = ((ownbits >> i) & 1u) ? ci : 0.f;
       wsum += w[i];
-      if (__any(m)) mybits |= 1u << i;
     }
   }
-  if (threadIdx.x == 0) flags[0] = 0;
-  __syncthreads();
-  if (lane == 0 && mybits) atomicOr(flags, mybits);
-  __syncthreads();
-  const unsigned wgbits = flags[0];
 
   const size_t row1 = (size_t)N * C;
   const T* qbase = (const T*)p.q + (size_t)px * C + h * d;
@@ -938,8 +1080,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params pin) {
       for (int u = 0; u < NDT; ++u)
 #pragma unroll
         for (int r = 0; r < 4; ++r) part += g1t[u][r] * (o[u][r] - au[u][r]);
-      const bool inside = valid && ((p.mask[px] >> (c - 2)) & 1u) != 0;
-      part = inside ? part : 0.f;
+      part = ((ownbits >> (c - 2)) & 1u) ? part : 0.f;
 #pragma unroll
       for (int i = 0; i < MAXK; ++i) dc[i] += (i == c - 2) ? part : 0.f;
     }
@@ -1069,38 +1210,63 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   constexpr int CB = fwd_frags(NDT) * FRAG;
   constexpr int TP = 16 * NWV * QT;
   Params p = p0;
-  p.ntiles = (p.N + TP - 1) / TP;
   p.head_major = (p.H % 8 == 0 && NDT >= 5) ? 1 : 0;   // one head per XCD: its K/V image is fetched by one L2 only
   if (const char* e = getenv("STA_FWD_HEAD_MAJOR")) p.head_major = atoi(e) ? 1 : 0;
   int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
   if (G > p.K + 2) G = p.K + 2;
   p.ntiles_aux = G;
   const int lds = G * CB;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)xattn_fwd_staged_kernel<T, NDT, QT, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((xattn_fwd_staged_kernel<T, NDT, QT, NWV>), dim3(p.ntiles * p.H, p.n_img), dim3(64 * NWV), lds, st, p);
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
+  // Tiles per workgroup: enough that ONE round of workgroups (LDS-, wave- and register-limited residency on
+  // the 256 CUs) covers the launch, at most STAGED_MAXIT; 1 when the contexts do not fit LDS together.
+  const int tiles = (p.N + TP - 1) / TP;
+  int per_cu = (160 * 1024) / lds;
+  if (per_cu > 32 / NWV) per_cu = 32 / NWV;
+  if (NWV == 12) per_cu = 1;                     // 3 waves per SIMD by register budget
+  if (per_cu < 1) per_cu = 1;
+  long wg_per_head = (256L * per_cu) / ((long)p.H * p.n_img);   // workgroups per (head, image) in one round
+  if (wg_per_head < 1) wg_per_head = 1;
+  int iters = (int)((tiles + wg_per_head - 1) / wg_per_head);
+  if (iters > STAGED_MAXIT) iters = STAGED_MAXIT;
+  if (iters < 1 || G < p.K + 2) iters = 1;
+  if (const char* e = getenv("STA_FWD_STAGED_ITERS")) { const int v = atoi(e); if (v >= 1 && v <= STAGED_MAXIT) iters = v; }   // tuning knob
+  p.iters = iters;
+  p.tiles = tiles;
+  p.ntiles = (tiles + iters - 1) / iters;
+  auto launch = [&](auto kernel, bool& attr_set) {
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+        return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kernel, dim3(p.ntiles * p.H, p.n_img), dim3(64 * NWV), lds, st, p);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
+  };
+  static bool attr1 = false, attrn = false;      // benign race: idempotent
+  if (iters == 1) return launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, 1>, attr1);
+  return launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, STAGED_MAXIT>, attrn);
 }
 
-// Workgroup shape of the LDS-resident kernel. 4 waves x 16 px (two workgroups per CU) when the launch has
-// few workgroups: latency is what matters. 8 waves x 16 px sharing one LDS image (4 waves per SIMD with two
-// workgroups per CU) when a launch carries several images and is throughput bound. Two tiles per wave
-// (QT = 2) measured slower at N=4096 d=40 (11.9 vs 9.1 us) and stays selectable for experiments only.
+// Workgroup shape of the LDS-resident kernel (rocprofv3 durations in profiles/r01_kernel_variants.md).
+// 4 waves x 16 px when the launch has few workgroups: latency is what matters. When a launch carries several
+// images it is throughput bound and more waves share one LDS image: 12 waves (3 per SIMD, 148 VGPRs: room for
+// the q prefetch without spills) at d <= 48, 8 waves at d <= 96. Two tiles per wave (QT = 2) measured slower
+// and stays selectable for experiments only.
 template <typename T, int NDT>
 int launch_fwd_staged(const Params& p, hipStream_t st) {
   const long w64 = (long)((p.N + 63) / 64) * p.H * p.n_img;      // 64-pixel workgroups in the launch
   int qt = 1;
-  int nwv = (NDT <= 6 && w64 >= (NDT <= 3 ? 1024 : 512)) ? 8 : 4;
+  int nwv = 4;
+  if (NDT <= 3 && w64 >= 2048) nwv = 12;
+  if (NDT > 3 && NDT <= 6 && w64 >= 512) nwv = 8;
   if (const char* e = getenv("STA_FWD_STAGED_QT")) qt = atoi(e) == 2 ? 2 : 1;     // tuning knobs
-  if (const char* e = getenv("STA_FWD_STAGED_WAVES")) nwv = atoi(e) == 8 ? 8 : 4;
+  if (const char* e = getenv("STA_FWD_STAGED_WAVES")) nwv = atoi(e) == 8 ? 8 : (atoi(e) == 12 ? 12 : 4);
+  if constexpr (NDT <= 3) {
+    if (nwv == 12) return launch_fwd_staged_cfg<T, NDT, 1, 12>(p, st);
+  }
   if constexpr (NDT <= 6) {
     if (qt == 2) return launch_fwd_staged_cfg<T, NDT, 2, 4>(p, st);
-    if (nwv == 8) return launch_fwd_staged_cfg<T, NDT, 1, 8>(p, st);   // 128-VGPR budget: small head dims only
+    if (nwv == 8) return launch_fwd_staged_cfg<T, NDT, 1, 8>(p, st);
   }
   return launch_fwd_staged_cfg<T, NDT, 1, 4>(p, st);
 }
@@ -1153,7 +1319,8 @@ int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
 template <typename T>
 int dispatch_fwd(const Params& p, hipStream_t st) {
   const int ndt = (p.d + 15) / 16;
-  if (use_staged(p.N, p.H, ndt, p.n_img)) {
+  // the LDS-resident kernel has no attention-map output and assumes padded keys in the last key tile only
+  if (!p.aux && p.M > 16 * (NKT - 1) && use_staged(p.N, p.H, ndt, p.n_img)) {
     switch (ndt) {
       case 1: return launch_fwd_staged<T, 1>(p, st);
       case 2: return launch_fwd_staged<T, 2>(p, st);
@@ -1278,6 +1445,10 @@ int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const 
   const int nw = pick_waves(N, heads);
   Params p{};
   p.q = q; p.packed = (const char*)packed; p.mask = mask; p.coef = coef; p.out = dq; p.dout = dout;
+  if (K == 0) {  // unconditional prologue loads: readable (ignored) bytes
+    p.mask = (const uint8_t*)q;
+    p.coef = (const float*)q;
+  }
   p.aux = (float*)workspace; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K; p.n_img = n_img;
   p.ntiles = (N + 16 * nw - 1) / (16 * nw);
   p.scale = scale; p.sl2e = scale * 1.4426950408889634f;

@@ -102,6 +102,33 @@ def test_bwd_matches_oracle(N, C, heads, K, dtype):
         assert ((dcoef - g).abs() <= tol).all(), (dcoef, g)
 
 
+@pytest.mark.parametrize("N,C,heads,K,M", [(64, 320, 8, 2, 80), (256, 320, 8, 2, 33), (16, 64, 8, 1, 77), (1024, 640, 8, 3, 1), (48, 1280, 8, 2, 16)])
+def test_key_count_and_tiny_latents(N, C, heads, K, M):
+    """Edge cases of the key axis (M = 1 .. 80 = STA_MAX_KEYS; CLIP uses 77) and of the pixel axis (a single
+    16-pixel tile), forward and backward, against the oracle."""
+    from sta import ops
+    dtype, dev = torch.bfloat16, "cuda"
+    q, k, v, mask, coef = _case(N, C, heads, K, dtype, seed=9, M=M)
+    scale = (C // heads) ** -0.5
+    qd, cd = q.double().requires_grad_(True), coef.double().requires_grad_(True)
+    ref, ref_maps = orc.fused_xattn(qd, k.double(), v.double(), mask, cd, heads, scale, want_maps=True)
+    packed = ops.pack_kv(k.to(dev), v.to(dev), heads)
+    mb = ops.mask_bits(mask).to(dev)
+    out, maps = ops.xattn_forward(q.to(dev), packed, mb, coef.to(dev), scale, want_maps=True)
+    eps = 2.0 ** -8
+    assert ((out.float().cpu().double() - ref.detach()).abs() <= 4 * eps * (1.0 + ref.detach().abs())).all()
+    assert (maps.cpu().double() - ref_maps.detach()).abs().max() < 1e-4
+    g = torch.Generator().manual_seed(11)
+    dout = torch.randn(2, N, C, generator=g).to(dtype)
+    ref.backward(dout.double())
+    dq, dcoef = ops.xattn_backward(q.to(dev), packed, mb, coef.to(dev), dout.to(dev), scale)
+    assert (dq.float().cpu().double() - qd.grad).abs().max() <= 6 * eps * qd.grad.abs().max() + 1e-6
+    gc = cd.grad
+    assert ((dcoef.cpu().double() - gc).abs() <= 0.02 * gc.abs() + 0.005 * gc.abs().max() + 1e-4 * math.sqrt(N * C)).all()
+    with pytest.raises(RuntimeError, match="keys unsupported"):
+        ops.pack_kv(torch.zeros(2, 81, C, device=dev, dtype=dtype), torch.zeros(2, 81, C, device=dev, dtype=dtype), heads)
+
+
 def test_domain_properties_full_size():
     """Size-independent properties at the BASELINE level-0 shape (N=4096, C=320, K=2):
     (1) coef = 0 or empty discs -> plain attention of both rows; (2) out[1] is affine in coef;

@@ -7,20 +7,21 @@ sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd"))
 from sta import lib, ops  # noqa: E402
 out = os.path.join(ROOT, "gpurun_out", "libsta_trace.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSTA_TRACE", "-I", lib.INCLUDE, lib.SOURCES[0], "-o", out])
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSTA_TRACE", "-I", lib.INCLUDE, "-I", lib.CSRC, *lib.SOURCES, "-o", out])
 lib.LIB_PATH = out
 L = lib.load()
 L.sta_debug_set_trace.restype, L.sta_debug_set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
 dev = "cuda"
+I = int(sys.argv[1]) if len(sys.argv) > 1 else 1           # images per launch (stamps: image 0's workgroups)
 for (N, C) in [(4096, 320), (1024, 640), (256, 1280), (64, 1280)]:
     K, H, M = 2, 8, 77
     g = torch.Generator().manual_seed(0)
-    q = torch.randn(2, N, C, generator=g).bfloat16().to(dev)
-    k = torch.randn(K + 2, M, C, generator=g).bfloat16().to(dev)
-    v = torch.randn(K + 2, M, C, generator=g).bfloat16().to(dev)
-    mask = ops.disc_mask_bits([(0.3, 0.4), (0.7, 0.6)], int(N ** 0.5)).to(dev)
-    coef = torch.full((K,), 2.5, device=dev)
-    packed = ops.pack_kv(k, v, H)
+    q = torch.randn(2 * I, N, C, generator=g).bfloat16().to(dev)
+    k = torch.randn(I * (K + 2), M, C, generator=g).bfloat16().to(dev)
+    v = torch.randn(I * (K + 2), M, C, generator=g).bfloat16().to(dev)
+    mask = ops.disc_mask_bits([(0.3, 0.4), (0.7, 0.6)], int(N ** 0.5)).to(dev).repeat(I, 1)
+    coef = torch.full((I, K), 2.5, device=dev)
+    packed = ops.pack_kv(k, v, H, n_img=I)
     tr = torch.zeros(128 + 2 * 4096, dtype=torch.int64, device=dev)
     tr[0] = 1 << 30      # no per-wave timeline
     tr[1] = 1
