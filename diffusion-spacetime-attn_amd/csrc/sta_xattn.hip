@@ -603,6 +603,33 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
 // LDS fragment reads are hoisted into registers ahead of the MFMAs for the same reason the global
 // loads are in the other kernel. Contexts 0/1 are requested before the disc mask is known; local
 // contexts right after the tile test. If the contexts do not fit LDS at once they go in groups.
+// Epilogue stores, 16 bytes per lane. In the accumulator layout a lane holds 4 consecutive head-dim values
+// per 16-wide tile (8 bytes as bf16/f16); 8-byte stores are store-ISSUE bound (MI355X_MICROARCH.md: row-per-lane
+// dwordx2 epilogues run at ~7 B/clk/CU, dwordx4 halves the tail). One v_permlane16_swap per dword pairs the
+// lane rows g and g^1: the even row ends up with head dims 16u+4g .. +7 of tile u, the odd row with
+// 16(u+1)+4(g-1) .. +7 of tile u+1, so every store is a 16-byte piece of the pixel's head row.
+template <typename T, int NDT>
+__device__ __forceinline__ void store_row16(T* obase, const f32x4 (&a)[NDT], int g, int d) {
+  typedef __attribute__((ext_vector_type(2))) T T2;
+  const bool odd = g & 1;
+#pragma unroll
+  for (int u = 0; u < NDT; u += 2) {
+    const unsigned x0 = __builtin_bit_cast(unsigned, T2{(T)a[u][0], (T)a[u][1]});
+    const unsigned x1 = __builtin_bit_cast(unsigned, T2{(T)a[u][2], (T)a[u][3]});
+    unsigned y0 = 0, y1 = 0;
+    if (u + 1 < NDT) {
+      y0 = __builtin_bit_cast(unsigned, T2{(T)a[u + 1][0], (T)a[u + 1][1]});
+      y1 = __builtin_bit_cast(unsigned, T2{(T)a[u + 1][2], (T)a[u + 1][3]});
+    }
+    // after the swap: even rows (own tile-u pair, partner's tile-u pair); odd rows (partner's tile-u+1 pair, own)
+    auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+    auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+    const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
+    const int dd = odd ? 16 * (u + 1) + 4 * (g - 1) : 16 * u + 4 * g;
+    if (dd < d && (!odd || u + 1 < NDT)) *(u32x4*)(obase + dd) = v;
+  }
+}
+
 // One context of the LDS-resident kernel for the QT pixel tiles of a wave. KIND is compile time — 0: ""
 // on the uncond row (-> au), 1: global prompt on the cond row (-> ac), 2: a local prompt, ac += w (A - au) —
 // so there is no per-context select/copy of the accumulators, queries or weights left in the instruction
@@ -812,20 +839,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
     for (int qt = 0; qt < QT; ++qt) {
       if (valid[qt]) {
         T* obase = (T*)p.out + (size_t)((wt + it * W) * TP + (wv * QT + qt) * 16 + c16) * C + h * d;
-#pragma unroll
-        for (int u = 0; u < NDT; ++u) {
-          const int dd = 16 * u + 4 * g;
-          if (dd < d) {
-            V4 r0, r1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              r0[r] = (T)au[qt][u][r];
-              r1[r] = (T)ac[qt][u][r];
-            }
-            *(V4*)(obase + dd) = r0;
-            *(V4*)(obase + (size_t)N * C + dd) = r1;
-          }
-        }
+        store_row16<T, NDT>(obase, au[qt], g, d);
+        store_row16<T, NDT>(obase + (size_t)N * C, ac[qt], g, d);
       }
       if (MAXIT > 1) {
         mb[qt] = mbn[qt];

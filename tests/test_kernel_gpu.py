@@ -189,6 +189,44 @@ def test_batched_images_match_oracle_per_image(N, C, heads, K):
             assert ((dcoef.view(I, K)[i].cpu().double() - gc).abs() <= tol).all()
 
 
+@pytest.mark.parametrize("N,C,heads,K,I,iters", [
+    (4096, 320, 8, 2, 8, None),    # bench shape: 12-wave workgroups walking 6 strided tiles each
+    (1024, 640, 8, 2, 8, None),    # 8-wave workgroups, 2 tiles each
+    (4096, 320, 8, 2, 4, None),    # ragged tile count per workgroup (22 tiles of 192 pixels over 8 workgroups)
+    (4000, 320, 8, 3, 4, 5),       # N not a multiple of the tile, forced tile count
+    (4096, 384, 8, 6, 4, 3),       # 8 contexts do not fit LDS together: groups are re-staged for every tile
+    (256, 1280, 8, 2, 8, None),    # d = 160: two LDS groups per tile
+])
+def test_multi_tile_workgroups(N, C, heads, K, I, iters, monkeypatch):
+    """Throughput-regime launches (several images, workgroups that keep one head's fragments in LDS and walk
+    several strided pixel tiles): every image equals (a) the same image launched alone through the
+    wave-per-context kernel and (b), for the first and last image, the CPU oracle."""
+    from sta import ops
+    dtype, dev = torch.bfloat16, "cuda"
+    if iters is not None:
+        monkeypatch.setenv("STA_FWD_STAGED_ITERS", str(iters))
+        monkeypatch.setenv("STA_FWD_KERNEL", "staged")
+    cases = [_case(N, C, heads, K, dtype, seed=40 + i) for i in range(I)]
+    q = torch.cat([c[0] for c in cases]).to(dev); k = torch.cat([c[1] for c in cases]).to(dev); v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    scale = (C // heads) ** -0.5
+    out, _ = ops.xattn_forward(q, ops.pack_kv(k, v, heads, n_img=I), mb, coef, scale)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("STA_FWD_STAGED_ITERS", raising=False)
+    monkeypatch.setenv("STA_FWD_KERNEL", "split")
+    eps = 2.0 ** -8
+    for i in range(I):
+        qi, ki, vi, mi, ci = cases[i]
+        alone, _ = ops.xattn_forward(qi.to(dev), ops.pack_kv(ki.to(dev), vi.to(dev), heads), ops.mask_bits(mi).to(dev), ci.to(dev), scale)
+        a, b = out[2 * i:2 * i + 2].float(), alone.float()
+        assert ((a - b).abs() <= 2 * eps * (1.0 + b.abs())).all(), (i, (a - b).abs().max().item())
+        if i in (0, I - 1):
+            ref = orc.fused_xattn(qi.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
+            err = (a.cpu().double() - ref).abs()
+            assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
+
+
 @pytest.mark.parametrize("B,N,C,heads", [(2, 4096, 320, 8), (4, 1024, 640, 8), (2, 144, 640, 8), (2, 576, 192, 4),
                                           (2, 64, 64, 8), (3, 200, 256, 4), (2, 2304, 640, 8)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

@@ -21,14 +21,6 @@ def stats(path):
     return list(c.execute(q)), cols
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--breakdown"):
-    print("kernel,calls,total_ns,avg_ns,min_ns,max_ns,grid_x,wg_x")
-    for p in sys.argv[1:]:
-        rows, _ = stats(p)
-        for r in rows:
-            print(",".join('"%s"' % r[0][:110] if i == 0 else ("%.0f" % r[i] if isinstance(r[i], float) else str(r[i])) for i in range(len(r))))
-
-
 def pmc_stats(path):
     """Per (kernel, grid) average of every collected counter: rows (kernel, grid_x, counter, calls, avg)."""
     c = sqlite3.connect(path)
@@ -41,6 +33,20 @@ def pmc_stats(path):
          "join %s s on d.kernel_id = s.id join %s i on e.pmc_id = i.id group by s.%s, d.grid_size_x, i.name order by 5 desc"
          % (name_col, pe, kd, ks, ip, name_col))
     return list(c.execute(q))
+
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[1] == "--pmc":
+    # usage: rocpd_stats.py --pmc results.db  -> kernel,grid_x,counter,calls,avg
+    for r in pmc_stats(sys.argv[2]):
+        print("%s,%d,%s,%d,%.1f" % (r[0][:100], r[1], r[2], r[3], r[4]))
+    sys.exit(0)
+
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--breakdown"):
+    print("kernel,calls,total_ns,avg_ns,min_ns,max_ns,grid_x,wg_x")
+    for p in sys.argv[1:]:
+        rows, _ = stats(p)
+        for r in rows:
+            print(",".join('"%s"' % r[0][:110] if i == 0 else ("%.0f" % r[i] if isinstance(r[i], float) else str(r[i])) for i in range(len(r))))
 
 
 def category(n):
