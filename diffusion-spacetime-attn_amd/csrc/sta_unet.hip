@@ -1,0 +1,356 @@
+// sta_unet.hip — HBM-bound glue kernels of the UNet trunk around the cross-attention path (gfx950).
+// C-ABI in include/sta_unet.h. Every kernel is one pass over its activations with 16-byte accesses per lane,
+// fp32 arithmetic, and no LDS beyond a few floats for workgroup reductions: the roofline that bounds them is
+// HBM bandwidth (algorithmic bytes: read every input once, write every output once).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sta_xattn.h"
+#include "sta_unet.h"
+#include "sta_internal.h"
+
+namespace {
+
+template <typename T> struct V8T { typedef T type __attribute__((ext_vector_type(8))); };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// sum over the workgroup; `sh` holds NT/64 floats; every thread gets the result
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  if constexpr (NT == 64) return v;
+  __syncthreads();                       // sh may still be read from a previous reduction
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) t += sh[w];
+  return t;
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// --------------------------------------------------------------------------------------------------
+// GroupNorm (+ per-(b,c) pre-add) (+ SiLU), NCHW. One workgroup per (b, group) slab of Cg*HW contiguous
+// elements. CACHED: the slab (<= NT*NV*8 elements) stays in registers between statistics and output.
+// --------------------------------------------------------------------------------------------------
+template <typename T, int NT, int NV, bool CACHED>
+__global__ __launch_bounds__(NT) void gn_silu_kernel(const T* __restrict__ x, const float* __restrict__ add,
+                                                    const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                    T* __restrict__ y, int C, int HW, int G, float eps, int silu) {
+  using V8 = typename V8T<T>::type;
+  __shared__ float sh[NT / 64];
+  const int Cg = C / G;
+  const int b = blockIdx.x / G, g = blockIdx.x % G;
+  const size_t base = ((size_t)b * C + (size_t)g * Cg) * HW;
+  const int n = Cg * HW, nvec = n >> 3;
+  const int c0 = g * Cg;
+  const V8* xv = (const V8*)(x + base);
+  V8* yv = (V8*)(y + base);
+  const float* addb = add ? add + (size_t)b * C + c0 : nullptr;
+  const float inv_n = 1.0f / (float)n;
+
+  if constexpr (CACHED) {
+    float v[NV][8];
+    int ch[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = threadIdx.x + j * NT;
+      ch[j] = 0;
+      if (idx < nvec) {
+        const V8 r = xv[idx];
+        ch[j] = (idx << 3) / HW;
+        const float a = addb ? addb[ch[j]] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[j][e] = (float)r[e] + a;
+          s += v[j][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+      }
+    }
+    const float mean = block_sum<NT>(s, sh) * inv_n;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (threadIdx.x + j * NT < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = v[j][e] - mean;
+          q += dlt * dlt;
+        }
+      }
+    const float rstd = rsqrtf(block_sum<NT>(q, sh) * inv_n + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = threadIdx.x + j * NT;
+      if (idx < nvec) {
+        const float gm = (float)gamma[c0 + ch[j]] * rstd;
+        const float bt = (float)beta[c0 + ch[j]] - mean * gm;
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float t = v[j][e] * gm + bt;
+          if (silu) t = silu_f(t);
+          o[e] = (T)t;
+        }
+        yv[idx] = o;
+      }
+    }
+  } else {
+    float s = 0.f, q = 0.f;
+    for (int idx = threadIdx.x; idx < nvec; idx += NT) {
+      const V8 r = xv[idx];
+      const float a = addb ? addb[(idx << 3) / HW] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = (float)r[e] + a;
+        s += t;
+        q += t * t;
+      }
+    }
+    const float mean = block_sum<NT>(s, sh) * inv_n;
+    const float var = fmaxf(block_sum<NT>(q, sh) * inv_n - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + eps);
+    for (int idx = threadIdx.x; idx < nvec; idx += NT) {
+      const V8 r = xv[idx];                       // second read: L2 / Infinity Cache
+      const int ch = (idx << 3) / HW;
+      const float a = addb ? addb[ch] : 0.f;
+      const float gm = (float)gamma[c0 + ch] * rstd;
+      const float bt = (float)beta[c0 + ch] - mean * gm + a * gm;
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = (float)r[e] * gm + bt;
+        if (silu) t = silu_f(t);
+        o[e] = (T)t;
+      }
+      yv[idx] = o;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// GEGLU: y[r][j] = x[r][j] * gelu(x[r][D + j])
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void geglu_kernel(const T* __restrict__ x, T* __restrict__ y, long nvec, int Dv) {
+  using V8 = typename V8T<T>::type;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    const long r = i / Dv;
+    const int j = (int)(i - r * Dv);
+    const V8 a = ((const V8*)x)[r * 2 * Dv + j];
+    const V8 gt = ((const V8*)x)[r * 2 * Dv + Dv + j];
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gv = (float)gt[e];
+      o[e] = (T)((float)a[e] * (0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f))));
+    }
+    ((V8*)y)[i] = o;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// s = x + f + bias; y = LayerNorm(s) * gamma + beta. One wave per row, C <= 2048.
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ f,
+                                                          const T* __restrict__ bias, const T* __restrict__ gamma,
+                                                          const T* __restrict__ beta, T* s_out, T* __restrict__ y,
+                                                          long R, int C, float eps) {
+  using V8 = typename V8T<T>::type;
+  constexpr int NV = 4;                                   // vectors per lane: C <= 64 * 4 * 8
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  const int lane = threadIdx.x & 63, nvec = C >> 3;
+  const V8* xr = (const V8*)(x + row * C);
+  const V8* fr = f ? (const V8*)(f + row * C) : nullptr;
+  float v[NV][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = lane + 64 * j;
+    if (idx < nvec) {
+      const V8 a = xr[idx];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[j][e] = (float)a[e];
+      if (fr) {
+        const V8 b = fr[idx];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] += (float)b[e];
+      }
+      if (bias) {
+        const V8 c = ((const V8*)bias)[idx];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] += (float)c[e];
+      }
+      if (s_out) {   // the residual stream continues in the activation dtype: normalise what is stored
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = (T)v[j][e];
+          v[j][e] = (float)o[e];
+        }
+        ((V8*)(s_out + row * C))[idx] = o;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += v[j][e];
+    }
+  }
+  const float mean = wave_sum(sum) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (lane + 64 * j < nvec) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dlt = v[j][e] - mean;
+        q += dlt * dlt;
+      }
+    }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = lane + 64 * j;
+    if (idx < nvec) {
+      const V8 gm = ((const V8*)gamma)[idx], bt = ((const V8*)beta)[idx];
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (T)((v[j][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+      ((V8*)(y + row * C))[idx] = o;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
+// y = a + b + bias[c] over [B][C][HW]
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_bias_nchw_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                          const T* __restrict__ bias, T* __restrict__ y, long nvec,
+                                                          int C, int HWv) {
+  using V8 = typename V8T<T>::type;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    const V8 av = ((const V8*)a)[i];
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (float)av[e];
+    if (b) {
+      const V8 bv = ((const V8*)b)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += (float)bv[e];
+    }
+    if (bias) {
+      const float bc = (float)bias[(int)((i / HWv) % C)];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += bc;
+    }
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)t[e];
+    ((V8*)y)[i] = o;
+  }
+}
+
+int launched(const char* what) {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "%s launch: %s", what, hipGetErrorString(e));
+}
+
+template <typename T>
+int gn_dispatch(const void* x, const float* add, const void* gamma, const void* beta, void* y, int B, int C, int HW,
+                int G, float eps, int silu, hipStream_t st) {
+  const long nvec = (long)(C / G) * HW / 8;
+  const dim3 grid(B * G);
+#define STA_GN(NT, NV, CACHED)                                                                                     \
+  hipLaunchKernelGGL((gn_silu_kernel<T, NT, NV, CACHED>), grid, dim3(NT), 0, st, (const T*)x, add, (const T*)gamma, \
+                     (const T*)beta, (T*)y, C, HW, G, eps, silu)
+  if (nvec <= 256 * 2) STA_GN(256, 2, true);
+  else if (nvec <= 256 * 8) STA_GN(256, 8, true);
+  else if (nvec <= 1024 * 4) STA_GN(1024, 4, true);
+  else if (nvec <= 1024 * 8) STA_GN(1024, 8, true);
+  else STA_GN(1024, 1, false);
+#undef STA_GN
+  return launched("groupnorm_silu");
+}
+
+}  // namespace
+
+extern "C" {
+
+int sta_groupnorm_silu(const void* x, const float* add, const void* gamma, const void* beta, void* y, int B, int C,
+                       int HW, int G, float eps, int silu, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!x || !gamma || !beta || !y) return sta_fail(STA_E_ARG, "null pointer");
+  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || C % G || HW % 8)
+    return sta_fail(STA_E_ARG, "groupnorm: B=%d C=%d HW=%d G=%d (need C %% G == 0, HW %% 8 == 0)", B, C, HW, G);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == STA_BF16 ? gn_dispatch<__bf16>(x, add, gamma, beta, y, B, C, HW, G, eps, silu, st)
+                           : gn_dispatch<_Float16>(x, add, gamma, beta, y, B, C, HW, G, eps, silu, st);
+}
+
+int sta_geglu(const void* x, void* y, long R, int D, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!x || !y) return sta_fail(STA_E_ARG, "null pointer");
+  if (R <= 0 || D <= 0 || D % 8) return sta_fail(STA_E_ARG, "geglu: R=%ld D=%d (need D %% 8 == 0)", R, D);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const long nvec = R * (D / 8);
+  long blocks = (nvec + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(geglu_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, st, (const __bf16*)x, (__bf16*)y, nvec, D / 8);
+  else
+    hipLaunchKernelGGL(geglu_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)x, (_Float16*)y, nvec, D / 8);
+  return launched("geglu");
+}
+
+int sta_add_layernorm(const void* x, const void* f, const void* bias, const void* gamma, const void* beta, void* s,
+                      void* y, long R, int C, float eps, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!x || !gamma || !beta || !y) return sta_fail(STA_E_ARG, "null pointer");
+  if (R <= 0 || C <= 0 || C % 8 || C > 2048) return sta_fail(STA_E_ARG, "add_layernorm: R=%ld C=%d (need C %% 8 == 0, C <= 2048)", R, C);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const unsigned blocks = (unsigned)((R + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(add_layernorm_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)f,
+                       (const __bf16*)bias, (const __bf16*)gamma, (const __bf16*)beta, (__bf16*)s, (__bf16*)y, R, C, eps);
+  else
+    hipLaunchKernelGGL(add_layernorm_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)f,
+                       (const _Float16*)bias, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)s, (_Float16*)y, R, C, eps);
+  return launched("add_layernorm");
+}
+
+int sta_add_bias_nchw(const void* a, const void* b, const void* bias, void* y, int B, int C, int HW, int dtype,
+                      void* stream) {
+  g_sta_err[0] = 0;
+  if (!a || !y) return sta_fail(STA_E_ARG, "null pointer");
+  if (B <= 0 || C <= 0 || HW <= 0 || HW % 8) return sta_fail(STA_E_ARG, "add_bias: B=%d C=%d HW=%d (need HW %% 8 == 0)", B, C, HW);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const long nvec = (long)B * C * (HW / 8);
+  long blocks = (nvec + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(add_bias_nchw_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, st, (const __bf16*)a, (const __bf16*)b,
+                       (const __bf16*)bias, (__bf16*)y, nvec, C, HW / 8);
+  else
+    hipLaunchKernelGGL(add_bias_nchw_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)a, (const _Float16*)b,
+                       (const _Float16*)bias, (_Float16*)y, nvec, C, HW / 8);
+  return launched("add_bias_nchw");
+}
+
+}  // extern "C"

@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from ldm.modules.diffusionmodules.util import checkpoint, zero_module, Normalize
+from sta import fused as _fused
 from sta import ops as _ops
 from sta import prompt_state as _ps
 
@@ -34,7 +35,10 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        a, gate = self.proj(x).chunk(2, dim=-1)
+        h = self.proj(x)
+        if _fused.usable(h):
+            return _fused.geglu(h)                     # chunk + gelu + mul in one pass (csrc/sta_unet.hip)
+        a, gate = h.chunk(2, dim=-1)
         return a * F.gelu(gate)
 
 
@@ -177,7 +181,9 @@ class BasicTransformerBlock(nn.Module):
         cache.version, cache.centres = _ps.version(), centres
         return cache
 
-    def forward(self, x, context=None, time=None, text_index=None, coef=None, bboxs_curr=None):
+    def forward(self, x, context=None, time=None, text_index=None, coef=None, bboxs_curr=None, in_bias=None):
+        """`in_bias` (not in the reference): a per-channel bias the caller still owes to `x` (SpatialTransformer's
+        proj_in bias when the projection ran as a bias-free GEMM); it is added inside the first fused pass."""
         bboxs_curr = [] if bboxs_curr is None else bboxs_curr
         if context is None:
             raise ValueError("BasicTransformerBlock needs the text context")
@@ -190,12 +196,24 @@ class BasicTransformerBlock(nn.Module):
             if len(cache.centres[0]):
                 raise ValueError("coef is required when objects are present")
             coef = x.new_zeros(0, dtype=torch.float32)
-        return checkpoint(lambda xx, cc: self._forward(xx, cc, cache), (x, coef), self.parameters(), self.checkpoint)
+        return checkpoint(lambda xx, cc: self._forward(xx, cc, cache, in_bias), (x, coef), self.parameters(), self.checkpoint)
 
-    def _forward(self, x, coef, cache):
+    def _forward(self, x, coef, cache, in_bias=None):
+        c = coef if coef.numel() else None
+        if _fused.usable(x):
+            # inference: every residual add runs inside the LayerNorm pass that consumes it (sta_add_layernorm)
+            n1, n2, n3 = self.norm1, self.norm2, self.norm3
+            s, y = _fused.add_layernorm(x, None, in_bias, n1.weight, n1.bias, n1.eps, store_sum=in_bias is not None)
+            x = x if s is None else s
+            x, y = _fused.add_layernorm(x, self.attn1(y), None, n2.weight, n2.bias, n2.eps)
+            blended = _ops.xattn_blend(self.attn2.to_q(y), c, cache.packed, cache.mask, self.attn2.scale)
+            x, y = _fused.add_layernorm(x, self.attn2.to_out(blended), None, n3.weight, n3.bias, n3.eps)
+            return self.ff(y) + x
+        if in_bias is not None:
+            x = x + in_bias
         x = self.attn1(self.norm1(x)) + x
         q = self.attn2.to_q(self.norm2(x))
-        blended = _ops.xattn_blend(q, coef if coef.numel() else None, cache.packed, cache.mask, self.attn2.scale)
+        blended = _ops.xattn_blend(q, c, cache.packed, cache.mask, self.attn2.scale)
         x = self.attn2.to_out(blended) + x
         return self.ff(self.norm3(x)) + x
 
@@ -215,6 +233,8 @@ class SpatialTransformer(nn.Module):
 
     def forward(self, x, context=None, time=None, text_index=None, coef=None, bboxs_curr=None):
         b, c, h, w = x.shape
+        if _fused.usable(x):
+            return self._forward_fused(x, context, time, text_index, coef, bboxs_curr)
         t = self.proj_in(self.norm(x))
         # 'b c h w -> b (h w) c': a free view when the activation is channels_last (NHWC in memory)
         t = t.permute(0, 2, 3, 1).reshape(b, h * w, -1)
@@ -222,3 +242,21 @@ class SpatialTransformer(nn.Module):
             t = blk(t, context=context, time=time, text_index=text_index, coef=coef, bboxs_curr=bboxs_curr)
         t = t.reshape(b, h, w, -1).permute(0, 3, 1, 2)          # back to [b, c, h, w] without a copy (NHWC strides)
         return self.proj_out(t) + x
+
+    def _forward_fused(self, x, context, time, text_index, coef, bboxs_curr):
+        """Inference path on NCHW activations without a layout copy: the two 1x1 convolutions are GEMMs whose
+        transposed operand is a VIEW ('b c (hw)' read as [hw, c]; output written as [b, hw, c] resp. [b, c, hw]),
+        so neither the 'b c h w -> b (h w) c' permute copy nor its inverse exists; GroupNorm is one pass and the
+        proj_out bias and the residual are one pass (csrc/sta_unet.hip). proj_in's bias rides into the first
+        block's fused LayerNorm pass."""
+        b, c, h, w = x.shape
+        inner = self.proj_in.out_channels
+        xn = _fused.groupnorm_silu(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, silu=False)
+        w_in = self.proj_in.weight.view(inner, c)
+        t = torch.bmm(xn.view(b, c, h * w).transpose(1, 2), w_in.t().unsqueeze(0).expand(b, c, inner))     # [b, hw, inner]
+        for i, blk in enumerate(self.transformer_blocks):
+            t = blk(t, context=context, time=time, text_index=text_index, coef=coef, bboxs_curr=bboxs_curr,
+                    in_bias=self.proj_in.bias if i == 0 else None)
+        w_out = self.proj_out.weight.view(c, inner)
+        y = torch.bmm(w_out.unsqueeze(0).expand(b, c, inner), t.transpose(1, 2))                            # [b, c, hw]
+        return _fused.add_bias_nchw(y.view(b, c, h, w), x, self.proj_out.bias)

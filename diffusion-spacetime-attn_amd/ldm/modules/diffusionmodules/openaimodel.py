@@ -13,6 +13,7 @@ from torch import nn
 
 from ldm.modules.attention import SpatialTransformer
 from ldm.modules.diffusionmodules.util import checkpoint, normalization, timestep_embedding, zero_module
+from sta import fused as _fused
 
 
 class TimestepBlock(nn.Module):
@@ -87,9 +88,29 @@ class ResBlock(TimestepBlock):
         return checkpoint(self._forward, (x, emb), self.parameters(), self.use_checkpoint)
 
     def _forward(self, x, emb):
+        if _fused.usable(x):
+            return self._forward_fused(x, emb)
         h = self.in_layers(x)
         h = h + self.emb_layers(emb).type(h.dtype)[:, :, None, None]
         return self.skip_connection(x) + self.out_layers(h)
+
+    def _forward_fused(self, x, emb):
+        """Inference: GroupNorm+SiLU are one pass each; the timestep-embedding add AND conv1's bias ride into the
+        second GroupNorm pass as a per-(b, c) pre-add; conv2's bias, the skip's bias and the residual add are
+        one pass. The convolutions themselves run bias-free (no separate bias kernel). csrc/sta_unet.hip."""
+        gn1, _, conv1 = self.in_layers
+        gn2, _, _, conv2 = self.out_layers
+        h = _fused.groupnorm_silu(x, gn1.weight, gn1.bias, gn1.num_groups, gn1.eps)
+        h = F.conv2d(h, conv1.weight, None, conv1.stride, conv1.padding)
+        add = self.emb_layers(emb).float() + conv1.bias.float()                       # [B, C_out]
+        h = _fused.groupnorm_silu(h, gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, add=add)
+        h = F.conv2d(h, conv2.weight, None, conv2.stride, conv2.padding)
+        skip, bias = x, conv2.bias
+        if not isinstance(self.skip_connection, nn.Identity):
+            sc = self.skip_connection
+            skip = F.conv2d(x, sc.weight, None, sc.stride, sc.padding)
+            bias = conv2.bias + sc.bias
+        return _fused.add_bias_nchw(skip, h, bias)
 
 
 class UNetModel(nn.Module):
@@ -171,6 +192,10 @@ class UNetModel(nn.Module):
         h = self.middle_block(h, emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
         for module in self.output_blocks:
             h = module(torch.cat([h, skips.pop()], dim=1), emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
+        if _fused.usable(h):
+            gn, _, conv = self.out
+            h = _fused.groupnorm_silu(h, gn.weight, gn.bias, gn.num_groups, gn.eps)
+            return conv(h).to(x.dtype)
         return self.out(h).to(x.dtype)
 
     def transformer_blocks(self):

@@ -1,0 +1,69 @@
+"""Python face of include/sta_unet.h: one-pass HIP kernels for the elementwise / normalisation chains of the
+UNet trunk around the cross-attention path (ResBlock, SpatialTransformer, BasicTransformerBlock, GEGLU).
+
+They are inference kernels: `usable()` is False whenever autograd is recording, and the modules then run the
+reference's eager sequence (which is also what the CPU tests exercise). `STA_FUSED=0` switches them off."""
+import os
+
+import torch
+
+from . import lib
+
+_DT = {torch.bfloat16: lib.STA_BF16, torch.float16: lib.STA_F16}
+
+
+def usable(x):
+    """Fused trunk kernels apply to contiguous 16-bit CUDA activations outside autograd recording."""
+    return (x.is_cuda and x.dtype in _DT and not torch.is_grad_enabled() and x.is_contiguous()
+            and os.environ.get("STA_FUSED", "1") != "0")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def groupnorm_silu(x, weight, bias, groups, eps, add=None, silu=True):
+    """act(GroupNorm(x + add[:, :, None, None])); x [B, C, *spatial] contiguous, add [B, C] or None."""
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    if add is not None:
+        add = add.float().contiguous()
+        assert add.shape == (B, C)
+    y = torch.empty_like(x)
+    lib.check(lib.load().sta_groupnorm_silu(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                            B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()),
+              "sta_groupnorm_silu")
+    return y
+
+
+def geglu(h):
+    """h [..., 2D] -> h[..., :D] * gelu(h[..., D:])."""
+    D = h.shape[-1] // 2
+    y = torch.empty(*h.shape[:-1], D, dtype=h.dtype, device=h.device)
+    lib.check(lib.load().sta_geglu(h.data_ptr(), y.data_ptr(), h.numel() // (2 * D), D, _DT[h.dtype], _stream()), "sta_geglu")
+    return y
+
+
+def add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True):
+    """s = x + f + bias; returns (s, LayerNorm(s)); f / bias may be None; s is None if store_sum is False."""
+    C = x.shape[-1]
+    s = torch.empty_like(x) if store_sum else None
+    y = torch.empty_like(x)
+    lib.check(lib.load().sta_add_layernorm(x.data_ptr(), _ptr(f), _ptr(bias), ln_weight.data_ptr(), ln_bias.data_ptr(),
+                                           _ptr(s), y.data_ptr(), x.numel() // C, C, float(eps), _DT[x.dtype], _stream()),
+              "sta_add_layernorm")
+    return s, y
+
+
+def add_bias_nchw(a, b=None, bias=None):
+    """a + b + bias[None, :, None, None] over NCHW tensors."""
+    B, C = a.shape[0], a.shape[1]
+    HW = a.numel() // (B * C)
+    y = torch.empty_like(a)
+    lib.check(lib.load().sta_add_bias_nchw(a.data_ptr(), _ptr(b), _ptr(bias), y.data_ptr(), B, C, HW, _DT[a.dtype], _stream()),
+              "sta_add_bias_nchw")
+    return y

@@ -16,13 +16,13 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, "sta_xattn.hip"), os.path.join(CSRC, "sta_selfattn.hip")]
+SOURCES = [os.path.join(CSRC, "sta_xattn.hip"), os.path.join(CSRC, "sta_selfattn.hip"), os.path.join(CSRC, "sta_unet.hip")]
 
 STA_BF16, STA_F16 = 0, 1
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
 
-# every symbol include/sta_xattn.h declares: (restype, argtypes)
-_vp, _i, _f, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+# every symbol include/sta_xattn.h and include/sta_unet.h declare: (restype, argtypes)
+_vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 SYMBOLS = {
     "sta_version": (_i, []),
     "sta_last_error": (ctypes.c_char_p, []),
@@ -32,6 +32,10 @@ SYMBOLS = {
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_groupnorm_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "sta_geglu": (_i, [_vp, _vp, _l, _i, _i, _vp]),
+    "sta_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
+    "sta_add_bias_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
 }
 
 
@@ -43,7 +47,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(CSRC, "sta_internal.h")]
+    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

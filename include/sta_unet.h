@@ -1,0 +1,60 @@
+/*
+ * sta_unet.h — C-ABI of the HBM-bound glue kernels around the cross-attention path (same library,
+ * same conventions as sta_xattn.h: raw device pointers, caller-owned buffers, stream-ordered, 0 / STA_E_*).
+ *
+ * These replace eager-PyTorch sequences in the CALLERS of the hot path (SURVEY.md §8 rows a3/a4/a6:
+ * BasicTransformerBlock._forward, SpatialTransformer.forward, ResBlock._forward), each of which is a chain of
+ * one-pass-per-op elementwise / normalisation kernels over [2I, C, H, W] or [2I, N, C] activations:
+ * pure HBM traffic. One pass per chain instead of one per op. Inference (no autograd) only — the Python
+ * wrappers fall back to the eager ops whenever gradients are being recorded.
+ *
+ * dtype: STA_BF16 / STA_F16 for activations and affine parameters; statistics and arithmetic in fp32.
+ */
+#ifndef STA_UNET_H
+#define STA_UNET_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * y = act( GroupNorm_G( x + add[b, c] ) * gamma[c] + beta[c] ),  act = SiLU if silu != 0 else identity.
+ *   x, y  [B][C][HW] (NCHW, contiguous), HW % 8 == 0, C % G == 0;  add [B][C] fp32 or NULL;  gamma, beta [C].
+ * Replaces (reference openaimodel.py ResBlock._forward, util.py GroupNorm32, attention.py:335-337):
+ *   `h + emb_out[..., None, None]` (with the producing conv's bias folded into `add`)  ->  GroupNorm32  ->  SiLU.
+ * One workgroup per (b, group) slab; slabs up to 64 Ki elements are held in registers between the statistics
+ * and the normalisation (one HBM read, exact two-pass variance), larger ones are read twice.
+ */
+int sta_groupnorm_silu(const void* x, const float* add, const void* gamma, const void* beta, void* y,
+                       int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
+
+/*
+ * y[r][j] = x[r][j] * gelu(x[r][D + j])  (exact erf GELU), x [R][2D], y [R][D], D % 8 == 0.
+ * Replaces GEGLU.forward after the projection (attention.py:43-45): chunk + gelu + mul = 3 passes -> 1.
+ */
+int sta_geglu(const void* x, void* y, long R, int D, int dtype, void* stream);
+
+/*
+ * s = x + f + bias (row-broadcast, bias may be NULL; f may be NULL: s = x);  y = LayerNorm(s) * gamma + beta.
+ *   x, f, s, y [R][C], C % 8 == 0, C <= 2048. s may be NULL (not stored) or alias x.
+ * Replaces `x = attn(norm(x)) + x` followed by the next `norm(x)` of BasicTransformerBlock._forward
+ * (attention.py:274-299): residual add and LayerNorm in one pass. One wave per row.
+ */
+int sta_add_layernorm(const void* x, const void* f, const void* bias, const void* gamma, const void* beta,
+                      void* s, void* y, long R, int C, float eps, int dtype, void* stream);
+
+/*
+ * y = a + b + bias[c]  over NCHW tensors [B][C][HW] (HW % 8 == 0); b and/or bias may be NULL.
+ * Replaces a convolution's separate bias pass plus the residual add that follows it
+ * (`skip_connection(x) + out_layers(h)`, openaimodel.py ResBlock._forward; `proj_out(x) + x_in`, attention.py:346).
+ */
+int sta_add_bias_nchw(const void* a, const void* b, const void* bias, void* y, int B, int C, int HW,
+                      int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,101 @@
+"""GPU parity of the trunk glue kernels (include/sta_unet.h) against plain PyTorch fp32 references of the same
+chains (floating-point kernels: tolerance = a few ulps of the 16-bit output, stated per test)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+
+
+def _close(got, ref, dtype, k=3.0):
+    err = (got.float().cpu() - ref).abs()
+    tol = k * EPS[dtype] * (1.0 + ref.abs())
+    assert (err <= tol).all(), "max err %.4g at tol %.4g" % (err.max().item(), tol.max().item())
+
+
+@pytest.mark.parametrize("B,C,H,G", [
+    (2, 320, 64, 32),     # level 0, slab in registers (40960 elements)
+    (2, 960, 64, 32),     # concat input of out.9: 122880-element slab, two-pass path
+    (4, 1920, 32, 32),    # level 1 concat
+    (2, 1280, 8, 32),     # level 3: 2560-element slabs (256-thread variant)
+    (2, 2560, 16, 32),    # level 2 concat
+    (3, 64, 12, 8),       # HW = 144 (768^2 mid level), odd batch
+    (2, 320, 96, 32),     # 768^2 level 0: 92160-element slab
+])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_add,silu", [(False, True), (True, True), (False, False)])
+def test_groupnorm_silu(B, C, H, G, dtype, with_add, silu):
+    from sta import fused
+    g = torch.Generator().manual_seed(B * C + H)
+    x = (torch.randn(B, C, H, H, generator=g) * 1.7 + 0.3).to(dtype)
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    add = torch.randn(B, C, generator=g) if with_add else None
+    xin = x.float() + (add[:, :, None, None] if with_add else 0.0)
+    ref = F.group_norm(xin, G, w.float(), b.float(), 1e-5)
+    ref = F.silu(ref) if silu else ref
+    got = fused.groupnorm_silu(x.cuda(), w.cuda(), b.cuda(), G, 1e-5, add=None if add is None else add.cuda(), silu=silu)
+    torch.cuda.synchronize()
+    _close(got, ref, dtype)
+
+
+@pytest.mark.parametrize("R,D", [(4096, 1280), (1000, 2560), (64, 5120), (7, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_geglu(R, D, dtype):
+    from sta import fused
+    g = torch.Generator().manual_seed(R + D)
+    h = (torch.randn(R, 2 * D, generator=g) * 2).to(dtype)
+    a, gate = h.float().chunk(2, dim=-1)
+    got = fused.geglu(h.cuda())
+    torch.cuda.synchronize()
+    _close(got, a * F.gelu(gate), dtype)
+
+
+@pytest.mark.parametrize("R,C", [(8192, 320), (2048, 640), (513, 1280), (3, 2048), (5, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_f,with_bias", [(True, True), (True, False), (False, False), (False, True)])
+def test_add_layernorm(R, C, dtype, with_f, with_bias):
+    from sta import fused
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g).to(dtype)
+    f = (torch.randn(R, C, generator=g) * 0.5).to(dtype) if with_f else None
+    bias = (torch.randn(C, generator=g) * 0.3).to(dtype) if with_bias else None
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    s_ref = x.float() + (f.float() if with_f else 0.0) + (bias.float() if with_bias else 0.0)
+    s, y = fused.add_layernorm(x.cuda(), None if f is None else f.cuda(), None if bias is None else bias.cuda(), w.cuda(), b.cuda(), 1e-5)
+    torch.cuda.synchronize()
+    _close(s, s_ref, dtype, k=1.0)
+    # the kernel normalises the ROUNDED sum (that is what the residual stream carries on)
+    y_ref = F.layer_norm(s.float().cpu(), (C,), w.float(), b.float(), 1e-5)
+    _close(y, y_ref, dtype)
+    s2, y2 = fused.add_layernorm(x.cuda(), None if f is None else f.cuda(), None if bias is None else bias.cuda(), w.cuda(), b.cuda(), 1e-5,
+                                 store_sum=False)
+    assert s2 is None
+    _close(y2, F.layer_norm(s_ref, (C,), w.float(), b.float(), 1e-5), dtype)
+
+
+@pytest.mark.parametrize("B,C,H", [(2, 320, 64), (3, 1280, 8), (2, 64, 12)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_add_bias_nchw(B, C, H, dtype):
+    from sta import fused
+    g = torch.Generator().manual_seed(C + H)
+    a = torch.randn(B, C, H, H, generator=g).to(dtype)
+    b = torch.randn(B, C, H, H, generator=g).to(dtype)
+    bias = torch.randn(C, generator=g).to(dtype)
+    got = fused.add_bias_nchw(a.cuda(), b.cuda(), bias.cuda())
+    torch.cuda.synchronize()
+    _close(got, a.float() + b.float() + bias.float()[None, :, None, None], dtype, k=1.0)
+    _close(fused.add_bias_nchw(a.cuda(), None, bias.cuda()), a.float() + bias.float()[None, :, None, None], dtype, k=1.0)
+    _close(fused.add_bias_nchw(a.cuda(), b.cuda(), None), a.float() + b.float(), dtype, k=1.0)
+
+
+def test_fused_error_convention():
+    from sta import fused
+    x = torch.randn(2, 30, 5, 5, device="cuda", dtype=torch.bfloat16)          # HW = 25: not a multiple of 8
+    w = torch.ones(30, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="groupnorm"):
+        fused.groupnorm_silu(x, w, w, 3, 1e-5)
+    assert not fused.usable(torch.randn(4, 8))                                  # CPU tensors never take the fused path

@@ -26,7 +26,7 @@ def _load(name):
 
 def test_library_loads_and_exports_every_declared_symbol():
     from sta import lib
-    header = open(os.path.join(lib.INCLUDE, "sta_xattn.h")).read()
+    header = open(os.path.join(lib.INCLUDE, "sta_xattn.h")).read() + open(os.path.join(lib.INCLUDE, "sta_unet.h")).read()
     declared = set(re.findall(r"\b(sta_[a-z_0-9]+)\s*\(", header))
     assert declared == set(lib.SYMBOLS), (declared, set(lib.SYMBOLS))
     L = lib.load()                       # raises if the .so is missing or a symbol is absent
@@ -36,6 +36,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.sta_xattn_packed_kv_bytes(4, 8, 40) == 4 * 8 * 2 * (5 * 2 + 3 * 3) * 1024
     assert L.sta_xattn_packed_kv_bytes(4, 8, 168) == 0 and L.sta_xattn_packed_kv_bytes(4, 8, 20) == 0
     assert L.sta_selfattn_fwd(0, 0, 0, 0, 2, 64, 64, 8, 64, 64, 1.0, 0, 0) == -1 and b"null" in L.sta_last_error()
+    assert L.sta_groupnorm_silu(0, 0, 0, 0, 0, 2, 320, 4096, 32, 1e-5, 1, 0, 0) == -1 and b"null" in L.sta_last_error()
+    assert L.sta_geglu(0, 0, 4, 64, 0, 0) == -1 and L.sta_add_layernorm(0, 0, 0, 0, 0, 0, 0, 4, 64, 1e-5, 0, 0) == -1
+    assert L.sta_add_bias_nchw(0, 0, 0, 0, 2, 4, 64, 0, 0) == -1
     assert L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2) >= 2 * 256 * 8 * 4
     assert L.sta_xattn_bwd_workspace_bytes(3, 4096, 8, 2) == 3 * L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2)
 
