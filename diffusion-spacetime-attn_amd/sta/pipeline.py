@@ -41,6 +41,12 @@ def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae
         unet.to(memory_format=torch.channels_last)
         if vae is not None:
             vae.to(memory_format=torch.channels_last)
+    if torch.device(device).type == "cuda" and os.environ.get("STA_CONV_FIND", "1") != "0":
+        # Let MIOpen MEASURE its solvers per convolution shape (find mode) instead of taking the immediate-mode
+        # heuristic: at the UNet's shapes the heuristic picks asm implicit-GEMM kernels where CK kernels are up to
+        # 2x faster (37 vs 51 ms of convolutions per 3 UNet calls at 8 prompts per step). Costs ~30 s once per
+        # process at the first call of each new shape (exclude the naive reference solvers, see bench.py).
+        torch.backends.cudnn.benchmark = True
     model.eval()
     for p in model.parameters():
         p.requires_grad_(False)      # frozen: the optimisation variable is the weights tensor only (plms.py:214)

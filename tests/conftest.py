@@ -5,6 +5,7 @@ import pytest
 
 for _k in ("FWD", "BWD", "WRW"):      # keep MIOpen's naive reference solvers out of its first-use solver search
     os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _k, "0")
+os.environ.setdefault("STA_CONV_FIND", "0")   # no per-shape solver measurements here: correctness runs, not speed
 
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

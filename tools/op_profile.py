@@ -14,6 +14,8 @@ for k in ("FWD", "BWD", "WRW"):
 from sta import prompt_state  # noqa: E402
 from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings  # noqa: E402
 
+if os.environ.get("STA_CUDNN_BENCHMARK") == "1":
+    torch.backends.cudnn.benchmark = True
 I = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 shapes = "--shapes" in sys.argv
 dev, dt, K = torch.device("cuda", 0), torch.bfloat16, 2
