@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
     V8 pb[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
+      // (Measured and rejected: scores pre-scaled with packed multiplies + v_max3 + packed subtract/add — 25 % fewer
+      // VALU instructions, 7 % SLOWER (784 vs 735 us at B=16, N=4096, d=40): packed fp32 VALU next to MFMAs is an
+      // anti-lever on this chip, MI355X_MICROARCH.md "price of one filler beside MFMAs".)
       if (tail) {
         // a real branch, taken only for a partial last block: the empty volatile asm keeps hipcc from
         // if-converting it into 16 compare+select pairs that would execute on every block

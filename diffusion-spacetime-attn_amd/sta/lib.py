@@ -18,6 +18,12 @@ INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
 SOURCES = [os.path.join(CSRC, "sta_xattn.hip"), os.path.join(CSRC, "sta_selfattn.hip"), os.path.join(CSRC, "sta_unet.hip")]
 
+# Self-attention keeps its MFMA accumulators in VGPRs: hipcc otherwise parks them in AGPRs and brackets the
+# online-softmax rescale with v_accvgpr_read/write pairs (120 extra VALU instructions per key block in a kernel
+# that is VALU-issue bound: 859 -> 765 us at B=16, N=4096, d=40). The cross-attention kernels measured neutral
+# (forward) to slower (backward at d=160, 26 -> 30 us) with it, so the flag is per source.
+PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+
 STA_BF16, STA_F16 = 0, 1
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
 
@@ -58,13 +64,27 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise StaLibraryError("hipcc not found; cannot build %s" % LIB_PATH)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-I", INCLUDE, "-I", CSRC, *SOURCES, "-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
+            *os.environ.get("STA_HIPCC_FLAGS", "").split()]           # env: experiments only (tools/)
+    objs, procs = [], []
+    for src in SOURCES:                 # one hipcc per source, side by side
+        obj = os.path.join(CSRC, "." + os.path.basename(src) + ".o")
+        cmd = base + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise StaLibraryError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
     r = subprocess.run(cmd, capture_output=True, text=True)
+    for o in objs:
+        if os.path.exists(o):
+            os.remove(o)
     if r.returncode != 0:
-        raise StaLibraryError("hipcc failed:\n" + r.stdout + r.stderr)
+        raise StaLibraryError("link failed:\n" + r.stdout + r.stderr)
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

@@ -56,6 +56,7 @@ if __name__ == "__main__":
     ap.add_argument("--bwd", action="store_true")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--imgs", type=int, default=1)
+    ap.add_argument("--level", type=int, default=-1, help="only this level (0..3) of the resolution")
     a = ap.parse_args()
-    for N, C in LEVELS[a.res]:
+    for N, C in (LEVELS[a.res] if a.level < 0 else [LEVELS[a.res][a.level]]):
         print(json.dumps(bench_level(N, C, a.K, iters=a.iters, bwd=a.bwd, imgs=a.imgs)))
