@@ -54,9 +54,13 @@ def category(n):
         return "miopen-find (naive conv, warm-up only)"
     if "xattn" in n or "pack_kv" in n or "dcoef_reduce" in n:
         return "sta xattn (ours)"
+    if "selfattn_fwd" in n:
+        return "sta self-attention (ours)"
+    if "gn_silu_kernel" in n or "geglu_kernel" in n or "add_layernorm_kernel" in n or "add_bias_nchw_kernel" in n:
+        return "sta trunk glue: GroupNorm/GEGLU/LayerNorm/residual (ours)"
     if "attn_fwd" in n or "attention" in n.lower():
-        return "SDPA self-attention"
-    if "igemm" in n or "conv" in n.lower():
+        return "SDPA self-attention (d = 160 levels)"
+    if "igemm" in n or "conv" in n.lower() or "GridwiseGemm" in n and "grouped_conv" in n:
         return "conv (MIOpen/CK)"
     if "Cijk" in n or "gemm" in n.lower():
         return "GEMM (hipBLASLt/rocBLAS)"
