@@ -139,6 +139,140 @@ __global__ __launch_bounds__(NT) void gn_silu_kernel(const T* __restrict__ x, co
 }
 
 // --------------------------------------------------------------------------------------------------
+// GroupNorm (+ pre-add) (+ SiLU) on NHWC ("channels_last") activations: x, y [B][HW][C].
+// A (b, group) slab is strided here (Cg channels of every pixel), so the work is split the other way: a workgroup
+// takes a chunk of pixels of one image and ALL channels — fully coalesced rows — and a thread keeps one fixed
+// 8-channel column (16 bytes) of every R-th pixel. Kernel 1 writes per-chunk partial sums per group, kernel 2
+// folds them (tiny) and normalises. x is read twice (the second time mostly from L2 / Infinity Cache).
+// --------------------------------------------------------------------------------------------------
+constexpr int GN_NT = 512;          // threads per workgroup: C / 8 <= 512 columns
+constexpr int GN_MAXG = 64;
+
+template <typename T>
+__global__ __launch_bounds__(GN_NT) void gn_nhwc_stats_kernel(const T* __restrict__ x, const float* __restrict__ add,
+                                                             float* __restrict__ part, int C, int HW, int G, int chunk_px) {
+  using V8 = typename V8T<T>::type;
+  __shared__ float acc[2 * GN_MAXG];
+  const int CV = C >> 3, R = GN_NT / CV, Cg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int row = threadIdx.x / CV, col = threadIdx.x - row * CV;
+  if (threadIdx.x < 2 * G) acc[threadIdx.x] = 0.f;
+  __syncthreads();
+  if (row < R) {
+    float a[8], s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      a[e] = add ? add[(size_t)b * C + col * 8 + e] : 0.f;
+      s[e] = 0.f;
+      q[e] = 0.f;
+    }
+    const int p1 = min(HW, (chunk + 1) * chunk_px);
+    for (int p = chunk * chunk_px + row; p < p1; p += R) {
+      const V8 v = *(const V8*)(x + ((size_t)b * HW + p) * C + col * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float t = (float)v[e] + a[e];
+        s[e] += t;
+        q[e] += t * t;
+      }
+    }
+    // fold the 8 channels into their (at most two, Cg >= 8) groups, then one LDS atomic per group and moment
+    const int g0 = (col * 8) / Cg, g1 = (col * 8 + 7) / Cg;
+    float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool first = (col * 8 + e) / Cg == g0;
+      s0 += first ? s[e] : 0.f;
+      q0 += first ? q[e] : 0.f;
+      s1 += first ? 0.f : s[e];
+      q1 += first ? 0.f : q[e];
+    }
+    atomicAdd(&acc[2 * g0], s0);
+    atomicAdd(&acc[2 * g0 + 1], q0);
+    if (g1 != g0) {
+      atomicAdd(&acc[2 * g1], s1);
+      atomicAdd(&acc[2 * g1 + 1], q1);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * G) part[((size_t)b * gridDim.x + chunk) * 2 * G + threadIdx.x] = acc[threadIdx.x];
+}
+
+template <typename T>
+__global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restrict__ x, const float* __restrict__ add,
+                                                             const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                             const float* __restrict__ part, T* __restrict__ y, int C, int HW,
+                                                             int G, int chunk_px, float eps, int silu) {
+  using V8 = typename V8T<T>::type;
+  __shared__ float mean_s[GN_MAXG], rstd_s[GN_MAXG];
+  const int CV = C >> 3, R = GN_NT / CV, Cg = C / G;
+  const int b = blockIdx.y, chunk = blockIdx.x, nchunk = gridDim.x;
+  const int row = threadIdx.x / CV, col = threadIdx.x - row * CV;
+  if (threadIdx.x < G) {
+    float s = 0.f, q = 0.f;
+    for (int k = 0; k < nchunk; ++k) {
+      s += part[((size_t)b * nchunk + k) * 2 * G + 2 * threadIdx.x];
+      q += part[((size_t)b * nchunk + k) * 2 * G + 2 * threadIdx.x + 1];
+    }
+    const float inv_n = 1.0f / ((float)Cg * (float)HW);
+    const float mean = s * inv_n;
+    mean_s[threadIdx.x] = mean;
+    rstd_s[threadIdx.x] = rsqrtf(fmaxf(q * inv_n - mean * mean, 0.f) + eps);
+  }
+  __syncthreads();
+  if (row >= R) return;
+  float gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = col * 8 + e, g = c / Cg;
+    const float a = add ? add[(size_t)b * C + c] : 0.f;
+    gm[e] = (float)gamma[c] * rstd_s[g];
+    bt[e] = (float)beta[c] + (a - mean_s[g]) * gm[e];
+  }
+  const int p1 = min(HW, (chunk + 1) * chunk_px);
+  for (int p = chunk * chunk_px + row; p < p1; p += R) {
+    const size_t off = ((size_t)b * HW + p) * C + col * 8;
+    const V8 v = *(const V8*)(x + off);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = (float)v[e] * gm[e] + bt[e];
+      if (silu) t = silu_f(t);
+      o[e] = (T)t;
+    }
+    *(V8*)(y + off) = o;
+  }
+}
+
+// y = a + b + bias[c] over [rows][C] (NHWC activations or token tensors)
+template <typename T>
+__global__ __launch_bounds__(256) void add_bias_rows_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                          const T* __restrict__ bias, T* __restrict__ y, long nvec, int CV) {
+  using V8 = typename V8T<T>::type;
+  const long stride = (long)gridDim.x * 256;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += stride) {
+    const V8 av = ((const V8*)a)[i];
+    float t[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = (float)av[e];
+    if (b) {
+      const V8 bv = ((const V8*)b)[i];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += (float)bv[e];
+    }
+    if (bias) {
+      const V8 cv = ((const V8*)bias)[(int)(i % CV)];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] += (float)cv[e];
+    }
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)t[e];
+    ((V8*)y)[i] = o;
+  }
+}
+
+// --------------------------------------------------------------------------------------------------
 // GEGLU: y[r][j] = x[r][j] * gelu(x[r][D + j])
 // --------------------------------------------------------------------------------------------------
 template <typename T>
@@ -351,6 +485,60 @@ int sta_add_bias_nchw(const void* a, const void* b, const void* bias, void* y, i
     hipLaunchKernelGGL(add_bias_nchw_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)a, (const _Float16*)b,
                        (const _Float16*)bias, (_Float16*)y, nvec, C, HW / 8);
   return launched("add_bias_nchw");
+}
+
+static int gn_nhwc_chunks(int HW) {
+  int n = HW / 8;
+  if (n > 32) n = 32;
+  if (n < 1) n = 1;
+  return n;
+}
+
+size_t sta_groupnorm_nhwc_workspace_bytes(int B, int HW, int G) {
+  if (B <= 0 || HW <= 0 || G <= 0) return 0;
+  return (size_t)B * gn_nhwc_chunks(HW) * 2 * G * sizeof(float);
+}
+
+int sta_groupnorm_silu_nhwc(const void* x, const float* add, const void* gamma, const void* beta, void* y,
+                            void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!x || !gamma || !beta || !y || !workspace) return sta_fail(STA_E_ARG, "null pointer");
+  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || G > GN_MAXG || C % G || C % 8 || C / G < 8 || C / 8 > GN_NT)
+    return sta_fail(STA_E_ARG, "groupnorm nhwc: B=%d C=%d HW=%d G=%d (need C %% 8 == 0, 8 <= C/G, C <= %d, G <= %d)", B, C, HW,
+                    G, 8 * GN_NT, GN_MAXG);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const int nchunk = gn_nhwc_chunks(HW), chunk_px = (HW + nchunk - 1) / nchunk;
+  const dim3 grid(nchunk, B);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = (float*)workspace;
+  if (dtype == STA_BF16) {
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, add, part, C, HW, G, chunk_px);
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, add, (const __bf16*)gamma,
+                       (const __bf16*)beta, part, (__bf16*)y, C, HW, G, chunk_px, eps, silu);
+  } else {
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, add, part, C, HW, G, chunk_px);
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, add, (const _Float16*)gamma,
+                       (const _Float16*)beta, part, (_Float16*)y, C, HW, G, chunk_px, eps, silu);
+  }
+  return launched("groupnorm_silu_nhwc");
+}
+
+int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, long rows, int C, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!a || !y) return sta_fail(STA_E_ARG, "null pointer");
+  if (rows <= 0 || C <= 0 || C % 8) return sta_fail(STA_E_ARG, "add_bias_rows: rows=%ld C=%d (need C %% 8 == 0)", rows, C);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const long nvec = rows * (C / 8);
+  long blocks = (nvec + 255) / 256;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(add_bias_rows_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, st, (const __bf16*)a, (const __bf16*)b,
+                       (const __bf16*)bias, (__bf16*)y, nvec, C / 8);
+  else
+    hipLaunchKernelGGL(add_bias_rows_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, st, (const _Float16*)a, (const _Float16*)b,
+                       (const _Float16*)bias, (_Float16*)y, nvec, C / 8);
+  return launched("add_bias_rows");
 }
 
 }  // extern "C"

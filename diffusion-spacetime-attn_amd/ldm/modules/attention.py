@@ -252,11 +252,17 @@ class SpatialTransformer(nn.Module):
         b, c, h, w = x.shape
         inner = self.proj_in.out_channels
         xn = _fused.groupnorm_silu(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, silu=False)
-        w_in = self.proj_in.weight.view(inner, c)
+        w_in, w_out = self.proj_in.weight[:, :, 0, 0], self.proj_out.weight[:, :, 0, 0]          # [out, in] views
+        if _fused.is_nhwc(x):
+            # channels_last: 'b c h w -> b (h w) c' IS the memory layout; both projections are plain GEMMs
+            t = F.linear(xn.permute(0, 2, 3, 1).reshape(b, h * w, c), w_in, self.proj_in.bias)
+            for blk in self.transformer_blocks:
+                t = blk(t, context=context, time=time, text_index=text_index, coef=coef, bboxs_curr=bboxs_curr)
+            y = F.linear(t, w_out).view(b, h, w, c).permute(0, 3, 1, 2)                            # NHWC view of [b, hw, c]
+            return _fused.add_bias_nchw(y, x, self.proj_out.bias)
         t = torch.bmm(xn.view(b, c, h * w).transpose(1, 2), w_in.t().unsqueeze(0).expand(b, c, inner))     # [b, hw, inner]
         for i, blk in enumerate(self.transformer_blocks):
             t = blk(t, context=context, time=time, text_index=text_index, coef=coef, bboxs_curr=bboxs_curr,
                     in_bias=self.proj_in.bias if i == 0 else None)
-        w_out = self.proj_out.weight.view(c, inner)
         y = torch.bmm(w_out.unsqueeze(0).expand(b, c, inner), t.transpose(1, 2))                            # [b, c, hw]
         return _fused.add_bias_nchw(y.view(b, c, h, w), x, self.proj_out.bias)

@@ -195,7 +195,7 @@ class UNetModel(nn.Module):
         if _fused.usable(h):
             gn, _, conv = self.out
             h = _fused.groupnorm_silu(h, gn.weight, gn.bias, gn.num_groups, gn.eps)
-            return conv(h).to(x.dtype)
+            return conv(h).to(x.dtype).contiguous()
         return self.out(h).to(x.dtype)
 
     def transformer_blocks(self):

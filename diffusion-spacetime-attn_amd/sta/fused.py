@@ -12,9 +12,14 @@ from . import lib
 _DT = {torch.bfloat16: lib.STA_BF16, torch.float16: lib.STA_F16}
 
 
+def is_nhwc(x):
+    """A 4-D activation stored channels_last (NHWC in memory) and not also plain-contiguous."""
+    return x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
+
 def usable(x):
-    """Fused trunk kernels apply to contiguous 16-bit CUDA activations outside autograd recording."""
-    return (x.is_cuda and x.dtype in _DT and not torch.is_grad_enabled() and x.is_contiguous()
+    """Fused trunk kernels apply to dense (NCHW- or NHWC-contiguous) 16-bit CUDA activations outside autograd."""
+    return (x.is_cuda and x.dtype in _DT and not torch.is_grad_enabled() and (x.is_contiguous() or is_nhwc(x))
             and os.environ.get("STA_FUSED", "1") != "0")
 
 
@@ -33,7 +38,18 @@ def groupnorm_silu(x, weight, bias, groups, eps, add=None, silu=True):
     if add is not None:
         add = add.float().contiguous()
         assert add.shape == (B, C)
-    y = torch.empty_like(x)
+    y = torch.empty_like(x)                     # keeps the memory format
+    if is_nhwc(x):
+        L = lib.load()
+        if C % 8 or C // groups < 8 or C > 4096 or groups > 64:   # outside the NHWC kernel's limits: eager chain
+            h = x if add is None else x + add.to(x.dtype)[:, :, None, None]
+            h = torch.nn.functional.group_norm(h, groups, weight, bias, eps)
+            return torch.nn.functional.silu(h) if silu else h
+        ws = torch.empty(L.sta_groupnorm_nhwc_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)
+        lib.check(L.sta_groupnorm_silu_nhwc(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                            ws.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()),
+                  "sta_groupnorm_silu_nhwc")
+        return y
     lib.check(lib.load().sta_groupnorm_silu(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                             B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()),
               "sta_groupnorm_silu")
@@ -60,10 +76,18 @@ def add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True):
 
 
 def add_bias_nchw(a, b=None, bias=None):
-    """a + b + bias[None, :, None, None] over NCHW tensors."""
+    """a + b + bias[None, :, None, None] over 4-D activations (both NCHW-contiguous or both channels_last)."""
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // (B * C)
     y = torch.empty_like(a)
+    if is_nhwc(a):
+        if b is not None and not is_nhwc(b):
+            b = b.contiguous(memory_format=torch.channels_last)
+        lib.check(lib.load().sta_add_bias_rows(a.data_ptr(), _ptr(b), _ptr(bias), y.data_ptr(), B * HW, C, _DT[a.dtype], _stream()),
+                  "sta_add_bias_rows")
+        return y
+    if b is not None and not b.is_contiguous():
+        b = b.contiguous()
     lib.check(lib.load().sta_add_bias_nchw(a.data_ptr(), _ptr(b), _ptr(bias), y.data_ptr(), B, C, HW, _DT[a.dtype], _stream()),
               "sta_add_bias_nchw")
     return y

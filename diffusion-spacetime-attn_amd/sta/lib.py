@@ -42,6 +42,9 @@ SYMBOLS = {
     "sta_geglu": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "sta_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     "sta_add_bias_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sta_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i]),
+    "sta_groupnorm_silu_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "sta_add_bias_rows": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
 }
 
 

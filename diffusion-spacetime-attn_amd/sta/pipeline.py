@@ -34,13 +34,12 @@ def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae
     text = SyntheticTextEmbedder().to(device)
     model = LatentDiffusion(unet_config=unet, first_stage_config=vae, cond_stage_config=text).to(device)
     if channels_last and torch.device(device).type == "cuda":
-        # NHWC activations and weights: MIOpen's bf16 convolutions are NHWC kernels (the NCHW path wraps each
-        # of them in two transposes) and the b c h w <-> b (hw) c reshapes around the transformer blocks
-        # become views. Measured neutral-to-slightly-slower (3.30 vs 3.36 images/s at 8 prompts per step):
-        # PyTorch's GroupNorm makes NCHW copies of NHWC inputs, which eats the gain. Off by default.
-        unet.to(memory_format=torch.channels_last)
-        if vae is not None:
-            vae.to(memory_format=torch.channels_last)
+        # NHWC activations and weights for the UNet trunk: MIOpen's bf16 convolutions are NHWC kernels (the NCHW path
+        # wraps each of them in two transposes), the b c h w <-> b (hw) c reshapes around the transformer blocks
+        # become views and the 1x1 projections plain GEMMs. Pays only with the fused inference kernels (NHWC
+        # GroupNorm in csrc/sta_unet.hip): +2.6 % images/s at 8 prompts per step; under autograd PyTorch's
+        # GroupNorm makes NCHW copies of NHWC inputs and eats the gain, so callers enable it for fixed weights only.
+        unet.to(memory_format=torch.channels_last)      # the VAE decoder (eager GroupNorm, once per image) stays NCHW
     if torch.device(device).type == "cuda" and os.environ.get("STA_CONV_FIND", "1") != "0":
         # Let MIOpen MEASURE its solvers per convolution shape (find mode) instead of taking the immediate-mode
         # heuristic: at the UNet's shapes the heuristic picks asm implicit-GEMM kernels where CK kernels are up to

@@ -54,6 +54,20 @@ int sta_add_layernorm(const void* x, const void* f, const void* bias, const void
 int sta_add_bias_nchw(const void* a, const void* b, const void* bias, void* y, int B, int C, int HW,
                       int dtype, void* stream);
 
+/*
+ * NHWC ("channels_last") variants: x, y [B][HW][C]. GroupNorm needs a caller-owned workspace of
+ * sta_groupnorm_nhwc_workspace_bytes(B, HW, G) bytes (per-chunk partial moments; written then read inside the
+ * call, no initialisation needed). Limits: C % 8 == 0, 8 <= C / G, C <= 4096, G <= 64.
+ * MIOpen's bf16 convolutions are NHWC kernels; keeping the UNet trunk in NHWC removes the two layout transposes
+ * MIOpen wraps around every NCHW convolution and makes 'b c h w -> b (h w) c' (attention.py:338) a view.
+ */
+size_t sta_groupnorm_nhwc_workspace_bytes(int B, int HW, int G);
+int sta_groupnorm_silu_nhwc(const void* x, const float* add, const void* gamma, const void* beta, void* y,
+                            void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
+
+/* y = a + b + bias (row-broadcast) over [rows][C] tensors (NHWC activations / token tensors); b, bias may be NULL. */
+int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, long rows, int C, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,6 +92,43 @@ def test_add_bias_nchw(B, C, H, dtype):
     _close(fused.add_bias_nchw(a.cuda(), b.cuda(), None), a.float() + b.float(), dtype, k=1.0)
 
 
+@pytest.mark.parametrize("B,C,H,G", [(2, 320, 64, 32), (2, 960, 64, 32), (4, 1920, 32, 32), (2, 1280, 8, 32), (2, 2560, 16, 32),
+                                     (3, 256, 12, 32), (2, 640, 96, 32)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_add,silu", [(False, True), (True, True), (False, False)])
+def test_groupnorm_silu_channels_last(B, C, H, G, dtype, with_add, silu):
+    """NHWC variant (two kernels: per-chunk moments, then normalise): same reference, channels_last in and out."""
+    from sta import fused
+    g = torch.Generator().manual_seed(B * C + H)
+    x = (torch.randn(B, C, H, H, generator=g) * 1.7 + 0.3).to(dtype)
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    add = torch.randn(B, C, generator=g) if with_add else None
+    xin = x.float() + (add[:, :, None, None] if with_add else 0.0)
+    ref = F.group_norm(xin, G, w.float(), b.float(), 1e-5)
+    ref = F.silu(ref) if silu else ref
+    xc = x.cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        assert fused.is_nhwc(xc) and fused.usable(xc)
+    got = fused.groupnorm_silu(xc, w.cuda(), b.cuda(), G, 1e-5, add=None if add is None else add.cuda(), silu=silu)
+    torch.cuda.synchronize()
+    assert fused.is_nhwc(got)
+    _close(got, ref, dtype)
+
+
+def test_add_bias_channels_last():
+    from sta import fused
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(2, 320, 16, 16, generator=g).bfloat16()
+    b = torch.randn(2, 320, 16, 16, generator=g).bfloat16()
+    bias = torch.randn(320, generator=g).bfloat16()
+    cl = lambda t: t.cuda().contiguous(memory_format=torch.channels_last)
+    got = fused.add_bias_nchw(cl(a), cl(b), bias.cuda())
+    assert fused.is_nhwc(got)
+    _close(got, a.float() + b.float() + bias.float()[None, :, None, None], torch.bfloat16, k=1.0)
+    _close(fused.add_bias_nchw(cl(a), b.cuda(), None), a.float() + b.float(), torch.bfloat16, k=1.0)      # mixed layouts
+
+
 def test_fused_error_convention():
     from sta import fused
     x = torch.randn(2, 30, 5, 5, device="cuda", dtype=torch.bfloat16)          # HW = 25: not a multiple of 8

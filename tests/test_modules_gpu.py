@@ -87,11 +87,16 @@ def _golden_unet(dtype):
     return unet.to("cuda", dtype)
 
 
+@pytest.mark.parametrize("channels_last", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_unet_eps_vs_reference_golden(dtype):
+def test_unet_eps_vs_reference_golden(dtype, channels_last):
+    """The UNet's epsilon against the REFERENCE's own UNet output (golden), through the fused inference path, with
+    NCHW activations and with the NHWC ("channels_last") trunk (two-kernel GroupNorm, GEMM-form 1x1 convolutions)."""
     from sta import prompt_state
     g = _load("unet_eps.npz")
     unet = _golden_unet(dtype)
+    if channels_last:
+        unet = unet.to(memory_format=torch.channels_last)
     c, local_ctx, _ = gi.unet_inputs(2, int(g["input_seed"]))
     prompt_state.begin_prompt([l.cuda() for l in local_ctx], first_timestep=981)
     with torch.no_grad():

@@ -19,7 +19,7 @@ if os.environ.get("STA_CUDNN_BENCHMARK") == "1":
 I = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 8
 shapes = "--shapes" in sys.argv
 dev, dt, K = torch.device("cuda", 0), torch.bfloat16, 2
-model = build_sd_v1(dev, dt, with_vae=False, init_weights=True, seed=0)
+model = build_sd_v1(dev, dt, with_vae=False, init_weights=True, seed=0, channels_last="--channels-last" in sys.argv)
 uc, c, local_c = conditionings(model, "a photo of a cat and a dog", ["cat", "dog"], dt)
 pair = lambda u, v: torch.stack([u, v], dim=1).reshape(2 * I, *u.shape[1:])
 c_in = pair(uc.expand(I, -1, -1), c.expand(I, -1, -1)).contiguous()
