@@ -748,29 +748,35 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
   stage_first_group();
   // a wave's QT sub-tiles of its it-th tile: pixels (wt + it*W)*TP + (wv*QT + qt)*16 + c16, rows 0 (uncond)
   // and 1 (cond). The q rows (and mask byte) of tile it+1 are requested before tile it is computed.
-  V8 q0[QT][NKS], q1[QT][NKS], q0n[QT][NKS], q1n[QT][NKS];
+  V8 q0[QT][NKS], q1[QT][NKS], q1n[QT][NKS];
   unsigned mb[QT], mbn[QT];
-  auto request_q = [&](int it, V8 (&a0)[QT][NKS], V8 (&a1)[QT][NKS], unsigned (&m)[QT]) {
+  auto request_q0 = [&](int it, V8 (&a0)[QT][NKS]) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int px = (wt + it * W) * TP + (wv * QT + qt) * 16 + c16;
+      const bool ok = it < iters && px < N;
+      load_b_frags<T, NKS>((const T*)p.q + (size_t)(ok ? px : 0) * C + h * d, ok, g, d, a0[qt]);
+    }
+  };
+  auto request_q1 = [&](int it, V8 (&a1)[QT][NKS], unsigned (&m)[QT]) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       const int px = (wt + it * W) * TP + (wv * QT + qt) * 16 + c16;
       const bool ok = it < iters && px < N;
       m[qt] = p.mask[ok ? px : 0];
-      const T* qbase = (const T*)p.q + (size_t)(ok ? px : 0) * C + h * d;
-      load_b_frags<T, NKS>(qbase, ok, g, d, a0[qt]);
-      load_b_frags<T, NKS>(qbase + (size_t)N * C, ok, g, d, a1[qt]);
+      load_b_frags<T, NKS>((const T*)p.q + ((size_t)N + (ok ? px : 0)) * C + h * d, ok, g, d, a1[qt]);
     }
   };
-  request_q(0, q0, q1, mb);
+  request_q0(0, q0);
+  request_q1(0, q1, mb);
   __builtin_amdgcn_sched_barrier(0);
   STA_T(1);
 
   // which discs touch the tiles (workgroup-uniform: every wave looked at the same bytes)
   unsigned tile_bits = 0;
   span_bits &= (1u << K) - 1u;
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i)
-    if (i < K && __ballot((span_bits >> i) & 1u)) tile_bits |= 1u << i;
+  for (int i = 0; i < K; ++i)                     // K iterations, not MAXK predicated ones: fewer issue slots
+    if (__ballot((span_bits >> i) & 1u)) tile_bits |= 1u << i;
   // active contexts in order: 0, 1, then the local ones whose disc touches a tile; entry e of that list
   // sits in LDS slot e % G. Stage the locals that still fit beside contexts 0 and 1.
   auto stage_locals = [&](unsigned bits, int first_slot, int count) {   // lowest `count` set bits of `bits`
@@ -796,13 +802,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
       stage_locals(tile_bits, 2, G - 2);
       wait_dma_and_sync();
     }
-    if (MAXIT > 1) request_q(it + 1, q0n, q1n, mbn);
+    if (MAXIT > 1) request_q1(it + 1, q1n, mbn);
     if (it == 1) STA_T(9);
     f32x4 au[QT][NDT], ac[QT][NDT];
     float w[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) w[qt] = 0.f;
     attend_staged<T, NDT, QT, 0>((const V8*)smem + lane, q0, kb4, sl2e, w, au, ac);
+    if (MAXIT > 1) request_q0(it + 1, q0);        // context 0 was q0's only consumer: next tile's rows go in place
     if (it == 0) STA_T(4);
     if (it == 1) STA_T(10);
     attend_staged<T, NDT, QT, 1>((const V8*)(smem + CB) + lane, q1, kb4, sl2e, w, au, ac);
@@ -813,25 +820,28 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       valid[qt] = (wt + it * W) * TP + (wv * QT + qt) * 16 + c16 < N;
-      mb[qt] = valid[qt] ? mb[qt] : 0u;
-#pragma unroll
-      for (int i = 0; i < MAXK; ++i)
-        if (i < K && __ballot((mb[qt] >> i) & 1u)) wave_bits |= 1u << i;
+      mb[qt] = valid[qt] ? (mb[qt] & tile_bits) : 0u;
+      for (unsigned bits = tile_bits; bits; bits &= bits - 1) {   // only the discs that touch the workgroup's tiles
+        const int i = __builtin_ctz(bits);
+        if (__ballot((mb[qt] >> i) & 1u)) wave_bits |= 1u << i;
+      }
     }
     unsigned rest = tile_bits;
-    for (int e = 2; rest; ++e) {
-      if (e >= G && e % G == 0) {   // next group: everyone is done reading the previous one
+    for (int slot = 2; rest;) {
+      if (slot == G) {              // next group: everyone is done reading the previous one
         __syncthreads();
         stage_locals(rest, 0, G);
         wait_dma_and_sync();
+        slot = 0;
       }
       const int i = __builtin_ctz(rest);
       rest &= rest - 1;
+      const int myslot = slot++;
       if (!((wave_bits >> i) & 1u)) continue;     // none of this wave's pixels inside the disc
       const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) w[qt] = ((mb[qt] >> i) & 1u) ? cw : 0.f;
-      attend_staged<T, NDT, QT, 2>((const V8*)(smem + (e % G) * CB) + lane, q1, kb4, sl2e, w, au, ac);
+      attend_staged<T, NDT, QT, 2>((const V8*)(smem + myslot * CB) + lane, q1, kb4, sl2e, w, au, ac);
     }
     if (it == 0) STA_T(6);
     if (it == 1) STA_T(12);
@@ -845,10 +855,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
       if (MAXIT > 1) {
         mb[qt] = mbn[qt];
 #pragma unroll
-        for (int s2 = 0; s2 < NKS; ++s2) {
-          q0[qt][s2] = q0n[qt][s2];
-          q1[qt][s2] = q1n[qt][s2];
-        }
+        for (int s2 = 0; s2 < NKS; ++s2) q1[qt][s2] = q1n[qt][s2];
       }
     }
   }
@@ -1277,7 +1284,7 @@ int launch_fwd_staged(const Params& p, hipStream_t st) {
   if (const char* e = getenv("STA_FWD_STAGED_QT")) qt = atoi(e) == 2 ? 2 : 1;     // tuning knobs
   if (const char* e = getenv("STA_FWD_STAGED_WAVES")) nwv = atoi(e) == 8 ? 8 : (atoi(e) == 12 ? 12 : 4);
   if constexpr (NDT <= 3) {
-    if (nwv == 12) return launch_fwd_staged_cfg<T, NDT, 1, 12>(p, st);
+    if (nwv == 12) return launch_fwd_staged_cfg<T, NDT, 1, 12>(p, st);   // 16 waves at 128 VGPRs spill (88 B/lane): 44 vs 33 us
   }
   if constexpr (NDT <= 6) {
     if (qt == 2) return launch_fwd_staged_cfg<T, NDT, 2, 4>(p, st);
