@@ -1294,13 +1294,13 @@ int launch_fwd_staged(const Params& p, hipStream_t st) {
 }
 
 // Which forward kernel — rocprofv3 kernel durations in us, K = 2, bf16, MI355X (profiles/r01_kernel_variants.md),
-// by images per launch I:
-//   N=4096 d=40 : I=1 staged 9.1 | split 14-18      I=2 st4 18.2 st8 15.6 | split 25.4    I=8 st4 62 st8 44.9 | split 93
-//   N=1024 d=80 : I=1 staged 10.5 | split 7.2       I=2 st4 10.7 st8 11.8 | split 13.1    I=8 st4 38 st8 28.3 | split 40
-//   N=256 d=160 : I=1 split 8.2                      I=2 st4 14.9 | split 9.5  I=4 16.3|16.2  I=8 st4 22.0 | split 29.4
-//   N=64  d=160 : split 8.8-9.5 | staged 14-15.7 at every I
-// -> LDS-resident ("staged") from 256 64-pixel workgroups per launch, 8 waves per workgroup from 1024 (d <= 48)
-//    or 512 (d <= 96) of them; the wave-per-context ("split") kernel below that.
+// by images per launch I (staged = LDS-resident kernel above with 4 / 8 / 12 waves, split = wave per context):
+//   N=4096 d=40 : I=1 staged4 8.4 | split 14-18     I=2 staged4 13.4     I=4 staged12 20.7      I=8 staged12 32.8 | split 93
+//   N=1024 d=80 : I=1 split 7.2 | staged4 10.5      I=2 staged4 7.9      I=4 staged8 9.8        I=8 staged8 16.9 | split 40
+//   N=256 d=160 : I=1 split 8.0                      I=2 split 8.5        I=4 split 15.0         I=8 staged4 12.5 | split 29
+//   N=64  d=160 : split 7.8-8.6 | staged 14-15.7 at every I
+// -> staged from 256 64-pixel workgroups per launch (launch_fwd_staged picks the workgroup shape and the tiles per
+//    workgroup); the wave-per-context kernel below that, for attention-map output and for M <= 64.
 bool use_staged(int N, int heads, int ndt, int n_img) {
   if (const char* e = getenv("STA_FWD_KERNEL")) {  // tuning knob: "staged" / "split"
     if (!strcmp(e, "staged")) return true;
