@@ -54,6 +54,11 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue the UNet eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="(default when --opt-epochs 0) NHWC UNet trunk")
+    ap.add_argument("--checkpoint", choices=["auto", "all", "res", "none"], default="auto",
+                    help="weight optimisation: which blocks recompute their forward in backward. all = ResBlocks and "
+                         "transformer blocks (the reference); res = ResBlocks only; none = keep every activation of the 51 "
+                         "UNet calls (79.5 GiB per prompt at 512x512 — 288 GB of HBM hold two prompts). auto = none for "
+                         "<= 2 prompts per step, res for <= 4, all otherwise (sta.pipeline.set_recompute)")
     ap.add_argument("--nchw", action="store_true", help="keep the UNet trunk in NCHW (2.6%% slower at 8 prompts per step)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-calls", type=int, default=2, help="timed CPU UNet calls of the baseline sample")
@@ -150,13 +155,16 @@ def main():
     dev = torch.device("cuda", local)
     from ldm.models.diffusion.plms import PLMSSampler
     from sta import lib
-    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts
+    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, set_recompute
     lib.load()
 
     K, dt = a.objects, torch.bfloat16
+    ckpt_mode = None
     # rank 0 creates the (synthetic) frozen weights; everyone else receives them over RCCL/xGMI
     model = build_sd_v1(dev, dt, with_vae=True, init_weights=(rank == 0), seed=0, channels_last=(a.channels_last or a.opt_epochs == 0) and not a.nchw,
                         use_checkpoint=a.opt_epochs > 1)
+    if a.opt_epochs > 1:
+        ckpt_mode = set_recompute(model, a.checkpoint, a.images_per_step)
     t0 = time.perf_counter()
     nbytes = parallel.broadcast_module_(model)
     torch.cuda.synchronize()
@@ -208,6 +216,7 @@ def main():
     elapsed = parallel.max_over_ranks(elapsed, dev)
     assert torch.isfinite(r["x0"]).all() and r["image"] is not None and r["x0"].shape[0] == I
 
+    peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     if rank != 0:
         return
     out = {
@@ -221,7 +230,8 @@ def main():
                    "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt, sharded i %% %d" % world,
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
                    "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
-                   "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes},
+                   "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,
+                   "peak_hbm_gib": round(peak_gb, 1), **({"recompute": ckpt_mode} if a.opt_epochs > 1 else {})},
     }
     if not a.no_roofline:
         # in-situ per-launch times of the fused forward kernel: a few real CFG UNet calls issued eagerly

@@ -83,6 +83,9 @@ def run(kind, default_dataset):
     if ckpt is None and not opt.synthetic:
         raise SystemExit("checkpoint %s not found (pass --synthetic to run with synthetic weights)" % opt.ckpt)
     model = build_sd_v1(dev, dtype, ckpt=ckpt if rank == 0 else None, init_weights=(rank == 0), use_checkpoint=opt.opt_epochs > 1)
+    if opt.opt_epochs > 1 and torch.device(dev).type == "cuda" and opt.H * opt.W <= 512 * 512:
+        from sta.pipeline import set_recompute
+        set_recompute(model, "auto", max(opt.batch_prompts, 1))      # sized to 288 GB of HBM at 512x512; larger images keep the reference's policy
     parallel.broadcast_module_(model)                                   # one RCCL broadcast of the frozen weights
     sampler = PLMSSampler(model, opt_epochs=opt.opt_epochs, loss_model=None)
     os.makedirs(opt.outdir, exist_ok=True)

@@ -66,6 +66,28 @@ def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae
     return model
 
 
+def set_recompute(model, mode="auto", prompts_per_step=1):
+    """Which blocks re-run their forward during backward (weight-optimisation epochs only).
+
+    The reference checkpoints every ResBlock and transformer block (util.py:105-145) because its 51-call autograd
+    graph would not fit a 24-48 GB GPU. One prompt at 512x512 needs 79.5 GiB of saved activations WITHOUT any
+    recomputation and an MI355X has 288 GB, so the policy is sized to HBM instead:
+      none — keep everything (<= 2 prompts per step: 156 GiB; +22 % images/s over `all`)
+      res  — ResBlocks recompute, transformer blocks keep their activations (<= 4 prompts: 240 GiB; +8 %)
+      all  — the reference's policy (more prompts per step)
+    Returns the mode applied."""
+    if mode == "auto":
+        mode = "none" if prompts_per_step <= 2 else ("res" if prompts_per_step <= 4 else "all")
+    unet = model.model.diffusion_model
+    from ldm.modules.diffusionmodules.openaimodel import ResBlock
+    for m in unet.modules():
+        if isinstance(m, ResBlock):
+            m.use_checkpoint = mode in ("all", "res")
+    for blk in unet.transformer_blocks():
+        blk.checkpoint = mode == "all"
+    return mode
+
+
 def load_prompts(n=64):
     """The first 64 MS-COCO prompts with two noun chunks each (BASELINE config 4; datasets/mscoco.txt,
     mscoco.pkl) — text only, used as keys of the synthetic embedder when CLIP weights are absent."""
