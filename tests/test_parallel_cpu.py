@@ -27,15 +27,19 @@ def _worker(rank, world, port, out_dir):
     r, w, _ = parallel.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
     torch.manual_seed(100 + rank)                              # different garbage on every rank before the broadcast
-    net = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.LayerNorm(96), torch.nn.Linear(96, 8)).to(torch.bfloat16)
-    net.register_buffer("table", torch.randn(33))
+    def make():    # Linear + norm + a channels_last (NHWC-strided) conv weight, as in the NHWC UNet trunk + a buffer
+        m = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.LayerNorm(96), torch.nn.Linear(96, 8),
+                                torch.nn.Conv2d(16, 24, 3)).to(torch.bfloat16).to(memory_format=torch.channels_last)
+        m.register_buffer("table", torch.randn(33))
+        return m
+    net = make()
     if rank == 0:
         synth.seeded_fill_(net, 7)
     nbytes = parallel.broadcast_module_(net, src=0, bucket_bytes=4096)      # small buckets: several messages per dtype
-    ref = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.LayerNorm(96), torch.nn.Linear(96, 8)).to(torch.bfloat16)
-    ref.register_buffer("table", torch.randn(33))
+    ref = make()
     synth.seeded_fill_(ref, 7)
     same = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))
+    same = same and net[3].weight.is_contiguous(memory_format=torch.channels_last)      # the layout survives the broadcast
     mine = parallel.shard_indices(7, rank, world)
     t = parallel.max_over_ranks(float(rank + 1), torch.device("cpu"))
     parallel.barrier()
