@@ -15,6 +15,9 @@ for k in ("FWD", "BWD", "WRW"):
 from sta import prompt_state  # noqa: E402
 from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, set_recompute  # noqa: E402
 
+if os.environ.get("STA_FA_LIB"):
+    torch.backends.cuda.preferred_rocm_fa_library(os.environ["STA_FA_LIB"])
+    print("rocm fa library:", torch.backends.cuda.preferred_rocm_fa_library())
 I = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1
 dev, dt, K = torch.device("cuda", 0), torch.bfloat16, 2
 model = build_sd_v1(dev, dt, with_vae=False, init_weights=True, seed=0, use_checkpoint=True)
