@@ -665,7 +665,11 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
   V8 pb[QT][NPS];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
+#ifdef STA_ABL_NOSOFTMAX
+    inv[qt] = sl2e;                                  // ablation build: no max / exp / sum
+#else
     inv[qt] = softmax_biased(st[qt], sl2e);
+#endif
     tiles_to_b<T>(st[qt], pb[qt]);
   }
   f32x4 o[QT][NDT];
@@ -698,6 +702,7 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
 // its next tile, the other waves of the SIMD compute.
 // MAXIT = 1 is the single-tile build for launches with few workgroups (one image): no mask bytes beyond the
 // tile's own, no prefetch code.
+// -DSTA_ABL_NOSTORE / NOLOAD / NOSOFTMAX are ablation builds for profiles/r01_kernel_variants.md (never shipped).
 constexpr int STAGED_MAXIT = 8;
 template <typename T, int NDT, int QT, int NWV, int MAXIT>
 __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_kernel(const Params pin) {
@@ -802,14 +807,18 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
       stage_locals(tile_bits, 2, G - 2);
       wait_dma_and_sync();
     }
+#ifndef STA_ABL_NOLOAD
     if (MAXIT > 1) request_q1(it + 1, q1n, mbn);
+#endif
     if (it == 1) STA_T(9);
     f32x4 au[QT][NDT], ac[QT][NDT];
     float w[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) w[qt] = 0.f;
     attend_staged<T, NDT, QT, 0>((const V8*)smem + lane, q0, kb4, sl2e, w, au, ac);
+#ifndef STA_ABL_NOLOAD
     if (MAXIT > 1) request_q0(it + 1, q0);        // context 0 was q0's only consumer: next tile's rows go in place
+#endif
     if (it == 0) STA_T(4);
     if (it == 1) STA_T(10);
     attend_staged<T, NDT, QT, 1>((const V8*)(smem + CB) + lane, q1, kb4, sl2e, w, au, ac);
@@ -849,14 +858,21 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
     for (int qt = 0; qt < QT; ++qt) {
       if (valid[qt]) {
         T* obase = (T*)p.out + (size_t)((wt + it * W) * TP + (wv * QT + qt) * 16 + c16) * C + h * d;
-        store_row16<T, NDT>(obase, au[qt], g, d);
-        store_row16<T, NDT>(obase + (size_t)N * C, ac[qt], g, d);
+#ifdef STA_ABL_NOSTORE
+        if (au[qt][0][0] == 12345.f && ac[qt][0][0] == 54321.f)      // ablation build: keep the values live, store nothing
+#endif
+        {
+          store_row16<T, NDT>(obase, au[qt], g, d);
+          store_row16<T, NDT>(obase + (size_t)N * C, ac[qt], g, d);
+        }
       }
+#ifndef STA_ABL_NOLOAD
       if (MAXIT > 1) {
         mb[qt] = mbn[qt];
 #pragma unroll
         for (int s2 = 0; s2 < NKS; ++s2) q1[qt][s2] = q1n[qt][s2];
       }
+#endif
     }
   }
   STA_T(8);
