@@ -47,9 +47,10 @@ constexpr int FRAG = 1024;    // bytes per fragment
 struct SParams {
   const void* q;    // [B][N][ldq]
   const void* k;    // [B][N][ldk]
-  const void* vt;   // [B][C][N]
+  const void* vt;   // V transposed: element (b, c, n) at b*vt_bs + c*vt_rs + n
   void* out;        // [B][N][C]
   int B, N, C, H, d, ldq, ldk;
+  long vt_rs, vt_bs;   // row (channel) and batch strides of vt in elements: [B][C][N] -> (N, C*N); [C][B*N] -> (B*N, N)
   float sl2e;       // scale * log2(e)
 };
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 
   const T* qb = (const T*)p.q + (size_t)b * N * p.ldq + h * d;
   const T* kb = (const T*)p.k + (size_t)b * N * p.ldk + h * d;
-  const T* vb = (const T*)p.vt + ((size_t)b * C + h * d) * N;
+  const T* vb = (const T*)p.vt + (size_t)b * p.vt_bs + (size_t)(h * d) * p.vt_rs;
 
   // Q (B operand), zero in the padded head-dim slots so that K's padding never matters
   V8 qf[QT][NKS];
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
     } else {
       const int f2 = fs - NKF;
       const int s2 = f2 / NDT, u = f2 - s2 * NDT;
-      src[i] = (const char*)(vb + (size_t)min(16 * u + c16, d - 1) * N + min(32 * s2 + 8 * g, N - 8));
+      src[i] = (const char*)(vb + (size_t)min(16 * u + c16, d - 1) * p.vt_rs + min(32 * s2 + 8 * g, N - 8));
       step[i] = __builtin_amdgcn_readfirstlane(KB * (int)sizeof(T));
     }
   }
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       } else {
         const int f2 = fs - NKF;
         const int s2 = f2 / NDT, u = f2 - s2 * NDT;
-        sp = vb + (size_t)min(16 * u + c16, d - 1) * N + min(k0 + 32 * s2 + 8 * g, N - 8);
+        sp = vb + (size_t)min(16 * u + c16, d - 1) * p.vt_rs + min(k0 + 32 * s2 + 8 * g, N - 8);
       }
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
                                        (__attribute__((address_space(3))) void*)(dst + f * FRAG), 16, 0, 0);
@@ -308,7 +309,8 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
 }  // namespace
 
 extern "C" int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, int B, int N, int C,
-                                int heads, int ldq, int ldk, float scale, int dtype, void* stream) {
+                                int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
+                                void* stream) {
   g_sta_err[0] = 0;
   if (!q || !k || !vt || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (B < 1 || B > 65535 || N < 8 || N % 8 || C <= 0 || heads <= 0 || C % heads)
@@ -317,7 +319,9 @@ extern "C" int sta_selfattn_fwd(const void* q, const void* k, const void* vt, vo
   if (d % 8 || d > 96 || ldq < C || ldk < C || ldq % 8 || ldk % 8)
     return sta_fail(STA_E_UNSUP, "self-attention needs d %% 8 == 0, d <= 96, row strides >= C and %% 8 == 0 (d=%d)", d);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
-  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, scale * 1.4426950408889634f};
+  if (vt_row_stride < N || vt_row_stride % 8 || vt_batch_stride % 8)
+    return sta_fail(STA_E_ARG, "selfattn: vt strides (%ld, %ld) must be multiples of 8 with row stride >= N", vt_row_stride, vt_batch_stride);
+  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, scale * 1.4426950408889634f};
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_sa<__bf16>(p, st) : dispatch_sa<_Float16>(p, st);
 }

@@ -703,7 +703,7 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
 // MAXIT = 1 is the single-tile build for launches with few workgroups (one image): no mask bytes beyond the
 // tile's own, no prefetch code.
 // -DSTA_ABL_NOSTORE / NOLOAD / NOSOFTMAX are ablation builds for profiles/r01_kernel_variants.md (never shipped).
-constexpr int STAGED_MAXIT = 8;
+constexpr int STAGED_MAXIT = 12;
 template <typename T, int NDT, int QT, int NWV, int MAXIT>
 __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;

@@ -18,6 +18,7 @@ What is different by design:
     reference's in-place writes rely on (SURVEY.md §7 hard part (a)).
 """
 import math
+import os
 
 import torch
 import torch.nn.functional as F
@@ -88,14 +89,17 @@ class CrossAttention(nn.Module):
     def _self_attention_hip(self, x):
         """attn1 without autograd: the flash-style HIP kernel (csrc/sta_selfattn.hip). q and k come out of ONE
         GEMM against the concatenated [Wq; Wk] (the kernel takes a row stride), V is produced already
-        transposed (W_v x^T, [B, C, N]) because the PV product wants keys contiguous per channel."""
+        transposed because the PV product wants keys contiguous per channel: ONE plain GEMM W_v . X^T over the
+        flattened batch gives [C, B*N], which the kernel reads through (row, batch) strides. (A batched
+        `matmul(W_v, x^T)` with the weight broadcast over the batch faults inside the GEMM library from batch 40 up.)"""
         wq, wk = self.to_q.weight, self.to_k.weight
         key = (wq.data_ptr(), wq._version, wk.data_ptr(), wk._version)
         if getattr(self, "_wqk_key", None) != key:
             self._wqk, self._wqk_key = torch.cat([wq.detach(), wk.detach()]), key
         c = wq.shape[0]
         qk = F.linear(x, self._wqk)                                   # [B, N, 2C]
-        vt = torch.matmul(self.to_v.weight, x.transpose(1, 2))        # [B, C, N]
+        b, n, _ = x.shape
+        vt = torch.mm(self.to_v.weight, x.reshape(b * n, c).t()).view(c, b, n).permute(1, 0, 2)    # [B, C, N] view of [C, B*N]
         o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
         return self.to_out(o)
 
@@ -233,7 +237,7 @@ class SpatialTransformer(nn.Module):
 
     def forward(self, x, context=None, time=None, text_index=None, coef=None, bboxs_curr=None):
         b, c, h, w = x.shape
-        if _fused.usable(x):
+        if _fused.usable(x) and (_fused.is_nhwc(x) or b <= 32):     # NCHW path uses weight-broadcast bmm: see _self_attention_hip
             return self._forward_fused(x, context, time, text_index, coef, bboxs_curr)
         t = self.proj_in(self.norm(x))
         # 'b c h w -> b (h w) c': a free view when the activation is channels_last (NHWC in memory)

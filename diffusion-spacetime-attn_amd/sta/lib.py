@@ -37,7 +37,7 @@ SYMBOLS = {
     "sta_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
-    "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
     "sta_groupnorm_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "sta_geglu": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "sta_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),

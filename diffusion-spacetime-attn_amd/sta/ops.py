@@ -202,7 +202,8 @@ def xattn_blend(q, coef, packed, mask, scale):
 def self_attention(q, k, vt, heads, scale):
     """Flash-style self-attention through the HIP kernel (inference only, no autograd).
     q, k: [B, N, C] (last dim contiguous; a row stride > C is allowed, e.g. slices of a fused QKV buffer);
-    vt: [B, C, N] contiguous (V transposed). Returns [B, N, C]."""
+    vt: [B, C, N] (V transposed), last dim contiguous, any batch / channel strides that are multiples of 8 — e.g.
+    the [C, B*N] result of ONE GEMM W_v . X^T viewed as [B, C, N]. Returns [B, N, C]."""
     B, N, C = q.shape
     if k.shape != q.shape or tuple(vt.shape) != (B, C, N):
         raise ValueError("shapes: q/k [B,N,C], vt [B,C,N]; got %s %s %s" % (tuple(q.shape), tuple(k.shape), tuple(vt.shape)))
@@ -211,11 +212,13 @@ def self_attention(q, k, vt, heads, scale):
     for t in (q, k):
         if t.stride(2) != 1 or t.stride(0) != N * t.stride(1):
             raise ValueError("q/k must be row-major with a uniform row stride")
-    vt = vt.contiguous()
+    if vt.stride(2) != 1 or vt.stride(0) % 8 or vt.stride(1) % 8 or vt.stride(1) < N:
+        vt = vt.contiguous()
     out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
     L = _lib.load()
     _lib.check(L.sta_selfattn_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, N, C, heads,
-                                  q.stride(1), k.stride(1), float(scale), _dtype_code(q), _stream(q)), "sta_selfattn_fwd")
+                                  q.stride(1), k.stride(1), vt.stride(1), vt.stride(0), float(scale), _dtype_code(q), _stream(q)),
+               "sta_selfattn_fwd")
     return out
 
 

@@ -240,7 +240,12 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     d, scale = C // heads, (C // heads) ** -0.5
     qk_d, vt_d = qk.cuda(), v.transpose(1, 2).contiguous().cuda()
     out = ops.self_attention(qk_d[..., :C], qk_d[..., C:], vt_d, heads, scale)
+    # the same V as the [C, B*N] result of ONE GEMM over the flattened batch, read through (row, batch) strides
+    vt_flat = v.cuda().reshape(B * N, C).t().contiguous().view(C, B, N).permute(1, 0, 2)
+    assert not vt_flat.is_contiguous() or B == 1
+    out2 = ops.self_attention(qk_d[..., :C], qk_d[..., C:], vt_flat, heads, scale)
     torch.cuda.synchronize()
+    assert torch.equal(out, out2)
     q64 = qk[..., :C].double().view(B, N, heads, d).transpose(1, 2)
     k64 = qk[..., C:].double().view(B, N, heads, d).transpose(1, 2)
     v64 = v.double().view(B, N, heads, d).transpose(1, 2)
@@ -248,6 +253,26 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     err = (out.float().cpu().double() - ref).abs()
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
+
+
+def test_self_attention_module_large_batch():
+    """CrossAttention's inference path at CFG batch 40 (20 prompts per UNet call): q/k from one fused GEMM, V^T from ONE
+    plain GEMM over the flattened batch. (A weight-broadcast batched matmul for V^T faulted inside the GEMM library from
+    batch 40 up — this pins the replacement.) Reference: PyTorch SDPA on the same projections."""
+    from ldm.modules.attention import CrossAttention
+    from sta.synth import seeded_fill_
+    B, N, C, heads = 40, 1024, 640, 8
+    attn = CrossAttention(query_dim=C, heads=heads, dim_head=C // heads)
+    seeded_fill_(attn, 5)
+    attn = attn.cuda().to(torch.bfloat16)
+    x = torch.randn(B, N, C, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        got = attn(x)
+        q, k, v = (m(x).view(B, N, heads, -1).transpose(1, 2) for m in (attn.to_q, attn.to_k, attn.to_v))
+        ref = attn.to_out(torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, C))
+    torch.cuda.synchronize()
+    err = (got.float() - ref.float()).abs()
+    assert (err <= 2.0 ** -6 * (1.0 + ref.float().abs())).all(), err.max().item()
 
 
 def test_autograd_function_roundtrip():
