@@ -49,8 +49,9 @@ def parse():
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--ddim_steps", type=int, default=50)
     ap.add_argument("--objects", type=int, default=2)
-    ap.add_argument("--images-per-step", type=int, default=8,
-                    help="independent prompts sampled together per step (one CFG batch of 2I per UNet call)")
+    ap.add_argument("--images-per-step", type=int, default=None,
+                    help="independent prompts sampled together per step (one CFG batch of 2I per UNet call); default 16 for "
+                         "fixed weights (3 steps + 1 warm-up = the 64-prompt batch), 1 with --opt-epochs > 0")
     ap.add_argument("--no-graph", action="store_true", help="issue the UNet eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="(default when --opt-epochs 0) NHWC UNet trunk")
@@ -65,7 +66,10 @@ def parse():
     ap.add_argument("--opt-epochs", type=int, default=0,
                     help="weight-optimisation epochs (0 = fixed weights = BASELINE configs[1], the headline; 3 = configs[2] "
                          "with a CLIP stand-in loss, reported as a side measurement)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.images_per_step is None:
+        a.images_per_step = 16 if a.opt_epochs == 0 else 1
+    return a
 
 
 def xattn_units(model, K):  # per image

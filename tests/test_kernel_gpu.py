@@ -190,7 +190,8 @@ def test_batched_images_match_oracle_per_image(N, C, heads, K):
 
 
 @pytest.mark.parametrize("N,C,heads,K,I,iters", [
-    (4096, 320, 8, 2, 8, None),    # bench shape: 12-wave workgroups walking 6 strided tiles each
+    (4096, 320, 8, 2, 16, None),   # bench shape (16 prompts per step): 12-wave workgroups walking 11 strided tiles each
+    (4096, 320, 8, 2, 8, None),    # 8 prompts per step: 6 tiles each
     (1024, 640, 8, 2, 8, None),    # 8-wave workgroups, 2 tiles each
     (4096, 320, 8, 2, 4, None),    # ragged tile count per workgroup (22 tiles of 192 pixels over 8 workgroups)
     (4000, 320, 8, 3, 4, 5),       # N not a multiple of the tile, forced tile count

@@ -10,7 +10,7 @@ LEVELS = [(4096, 320, 5), (1024, 640, 5), (256, 1280, 5), (64, 1280, 1)]   # N, 
 K, M = 2, 77
 root = sys.argv[1]
 out = {"by_images_per_launch": {}}
-for I in (1, 8):
+for I in (1, 8, 16):
     rec = {"per_level_bytes": {}, "algorithmic_bytes": {}, "launches_per_unet_call": {}, "raw_KiB": {}, "kernel": {}}
     tot = n = 0
     for L, (N, C, cnt) in enumerate(LEVELS):
