@@ -38,18 +38,22 @@ def groupnorm_silu(x, weight, bias, groups, eps, add=None, silu=True):
     if add is not None:
         add = add.float().contiguous()
         assert add.shape == (B, C)
+    def eager():                                # shapes outside the kernels' limits: the reference's op chain
+        h = x if add is None else x + add.to(x.dtype)[:, :, None, None]
+        h = torch.nn.functional.group_norm(h, groups, weight, bias, eps)
+        return torch.nn.functional.silu(h) if silu else h
     y = torch.empty_like(x)                     # keeps the memory format
     if is_nhwc(x):
         L = lib.load()
-        if C % 8 or C // groups < 8 or C > 4096 or groups > 64:   # outside the NHWC kernel's limits: eager chain
-            h = x if add is None else x + add.to(x.dtype)[:, :, None, None]
-            h = torch.nn.functional.group_norm(h, groups, weight, bias, eps)
-            return torch.nn.functional.silu(h) if silu else h
+        if C % 8 or C // groups < 8 or C > 4096 or groups > 64:
+            return eager()
         ws = torch.empty(L.sta_groupnorm_nhwc_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)
         lib.check(L.sta_groupnorm_silu_nhwc(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                             ws.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()),
                   "sta_groupnorm_silu_nhwc")
         return y
+    if HW % 8 or C % groups:
+        return eager()
     lib.check(lib.load().sta_groupnorm_silu(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                             B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()),
               "sta_groupnorm_silu")
@@ -59,6 +63,9 @@ def groupnorm_silu(x, weight, bias, groups, eps, add=None, silu=True):
 def geglu(h):
     """h [..., 2D] -> h[..., :D] * gelu(h[..., D:])."""
     D = h.shape[-1] // 2
+    if D % 8:
+        a, gate = h.chunk(2, dim=-1)
+        return a * torch.nn.functional.gelu(gate)
     y = torch.empty(*h.shape[:-1], D, dtype=h.dtype, device=h.device)
     lib.check(lib.load().sta_geglu(h.data_ptr(), y.data_ptr(), h.numel() // (2 * D), D, _DT[h.dtype], _stream()), "sta_geglu")
     return y
@@ -67,6 +74,10 @@ def geglu(h):
 def add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True):
     """s = x + f + bias; returns (s, LayerNorm(s)); f / bias may be None; s is None if store_sum is False."""
     C = x.shape[-1]
+    if C % 8 or C > 2048:
+        t = x if f is None else x + f
+        t = t if bias is None else t + bias
+        return (t if store_sum else None), torch.nn.functional.layer_norm(t, (C,), ln_weight, ln_bias, eps)
     s = torch.empty_like(x) if store_sum else None
     y = torch.empty_like(x)
     lib.check(lib.load().sta_add_layernorm(x.data_ptr(), _ptr(f), _ptr(bias), ln_weight.data_ptr(), ln_bias.data_ptr(),
@@ -79,6 +90,9 @@ def add_bias_nchw(a, b=None, bias=None):
     """a + b + bias[None, :, None, None] over 4-D activations (both NCHW-contiguous or both channels_last)."""
     B, C = a.shape[0], a.shape[1]
     HW = a.numel() // (B * C)
+    if (C % 8 if is_nhwc(a) else HW % 8):
+        t = a if b is None else a + b
+        return t if bias is None else t + bias[None, :, None, None]
     y = torch.empty_like(a)
     if is_nhwc(a):
         if b is not None and not is_nhwc(b):

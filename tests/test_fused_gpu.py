@@ -129,10 +129,32 @@ def test_add_bias_channels_last():
     _close(fused.add_bias_nchw(cl(a), b.cuda(), None), a.float() + b.float(), torch.bfloat16, k=1.0)      # mixed layouts
 
 
+def test_shapes_outside_kernel_limits_take_the_eager_chain():
+    """65x65 latents (HW % 8 != 0), 12 channels (C % 8 != 0): the wrappers run the reference's op chain instead."""
+    from sta import fused
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 32, 5, 5, generator=g).bfloat16().cuda()
+    w = torch.ones(32).bfloat16().cuda()
+    y = fused.groupnorm_silu(x, w, w * 0, 4, 1e-5)
+    _close(y, F.silu(F.group_norm(x.float().cpu(), 4)), torch.bfloat16)
+    xc = torch.randn(2, 12, 8, 8, generator=g).bfloat16().cuda().contiguous(memory_format=torch.channels_last)
+    w12 = torch.ones(12).bfloat16().cuda()
+    _close(fused.groupnorm_silu(xc, w12, w12 * 0, 3, 1e-5, silu=False), F.group_norm(xc.float().cpu(), 3), torch.bfloat16)
+    _close(fused.add_bias_nchw(x, x, w), 2 * x.float().cpu() + 1.0, torch.bfloat16, k=1.0)
+    h = torch.randn(6, 24, generator=g).bfloat16().cuda()
+    a, gate = h.float().cpu().chunk(2, dim=-1)
+    _close(fused.geglu(h), a * F.gelu(gate), torch.bfloat16)
+    t = torch.randn(6, 12, generator=g).bfloat16().cuda()
+    s, y = fused.add_layernorm(t, t, None, w12, w12 * 0, 1e-5)
+    _close(s, 2 * t.float().cpu(), torch.bfloat16, k=1.0)
+    _close(y, F.layer_norm(2 * t.float().cpu(), (12,)), torch.bfloat16)
+
+
 def test_fused_error_convention():
     from sta import fused
+    from sta import lib
     x = torch.randn(2, 30, 5, 5, device="cuda", dtype=torch.bfloat16)          # HW = 25: not a multiple of 8
     w = torch.ones(30, device="cuda", dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="groupnorm"):
-        fused.groupnorm_silu(x, w, w, 3, 1e-5)
+    rc = lib.load().sta_groupnorm_silu(x.data_ptr(), 0, w.data_ptr(), w.data_ptr(), x.data_ptr(), 2, 30, 25, 3, 1e-5, 1, 0, 0)
+    assert rc == -1 and b"groupnorm" in lib.load().sta_last_error()            # the C-ABI rejects it; the wrapper never calls it
     assert not fused.usable(torch.randn(4, 8))                                  # CPU tensors never take the fused path
