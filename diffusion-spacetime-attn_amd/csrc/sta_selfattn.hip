@@ -76,7 +76,10 @@ __device__ __forceinline__ float bfly_sum(float x) {
 // key (within a 64-key block) held by row i of S^T tile T
 __device__ __forceinline__ int tile_key(int T, int i) { return 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3); }
 
-template <typename T, int NKS, int NDT, int QT>
+// SUMROW (head dims that are not a multiple of 16, e.g. 40): the first PADDED row of V^T is set to ones in
+// registers, so the PV MFMAs accumulate the softmax denominator as row d of O^T — 16 v_add per 64 keys per query
+// tile less in a kernel whose VALU pipe is 73 % busy; the running rescale covers it like any other row.
+template <typename T, int NKS, int NDT, int QT, bool SUMROW>
 __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
@@ -205,6 +208,14 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
     V8 va[NVF];
 #pragma unroll
     for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
+    if constexpr (SUMROW) {                 // A-operand row of this lane in the last head-dim tile: 16*(NDT-1) + c16
+      V8 ones;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+        if (16 * (NDT - 1) + c16 == d) va[s2 * NDT + NDT - 1] = ones;
+    }
 
     V8 pb[QT][2];
 #pragma unroll
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       const float mnew = fmaxf(mrun[qt], bm);
       const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * p.sl2e);
       mrun[qt] = mnew;
-      lrun[qt] *= alpha;
+      if constexpr (!SUMROW) lrun[qt] *= alpha;
 #pragma unroll
       for (int u = 0; u < NDT; ++u) o[qt][u] *= alpha;
       const float off = mnew * p.sl2e;
@@ -241,9 +252,9 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
         for (int r = 0; r < 4; ++r) {
           const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][t][r], p.sl2e, -off));
           st[qt][t][r] = e;
-          rs += e;
+          if constexpr (!SUMROW) rs += e;
         }
-      lrun[qt] += rs;
+      if constexpr (!SUMROW) lrun[qt] += rs;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -261,7 +272,16 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int px = px0 + 16 * qt + c16;
-    const float inv = 1.0f / bfly_sum(lrun[qt]);
+    float inv;
+    if constexpr (SUMROW) {   // denominator = row d of O^T: tile NDT-1, row d % 16 = 4*g_s + r_s, held by the lanes of lane row g_s
+      const int rs_ = d & 15, g_s = rs_ >> 2, r_s = rs_ & 3;
+      float l = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) l = (r == r_s) ? o[qt][NDT - 1][r] : l;
+      inv = 1.0f / __shfl(l, 16 * g_s + c16);
+    } else {
+      inv = 1.0f / bfly_sum(lrun[qt]);
+    }
     if (px >= N) continue;
     T* ob = (T*)p.out + ((size_t)b * N + px) * C + h * d;
 #pragma unroll
@@ -277,20 +297,29 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   }
 }
 
-template <typename T, int NKS, int NDT>
-int launch_sa(const SParams& p, hipStream_t st) {
+template <typename T, int NKS, int NDT, bool SUMROW>
+int launch_sa_cfg(const SParams& p, hipStream_t st) {
   constexpr int QT = 2;
   constexpr int lds = 3 * (((4 * NKS + 2 * NDT) + 3) / 4 * 4) * FRAG;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
     attr_set = true;
   }
   const int tiles = (p.N + 64 * QT - 1) / (64 * QT);
-  hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT>), dim3(tiles * p.H, p.B), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>), dim3(tiles * p.H, p.B), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn launch: %s", hipGetErrorString(e));
+}
+
+template <typename T, int NKS, int NDT>
+int launch_sa(const SParams& p, hipStream_t st) {
+#ifdef STA_SA_NOSUMROW   // A/B build (tools/)
+  return launch_sa_cfg<T, NKS, NDT, false>(p, st);
+#else
+  return (p.d & 15) ? launch_sa_cfg<T, NKS, NDT, true>(p, st) : launch_sa_cfg<T, NKS, NDT, false>(p, st);
+#endif
 }
 
 template <typename T>
