@@ -182,6 +182,9 @@ __global__ __launch_bounds__(64) void pack_kv_kernel(const T* __restrict__ k, co
       const int s = f2 / ndt, u = f2 % ndt;
       const int key = pv_key(s, g, j), dd = 16 * u + c;
       if (key < M && dd < d) x = pv_src[((size_t)ctx * M + key) * C + h * d + dd];
+      // forward V^T only: the first padded head-dim row (d % 16 != 0) is a row of ones over the real keys, so the
+      // PV MFMAs of the forward kernels also produce sum_key P — the softmax denominator — as row d of O^T
+      else if (!second && key < M && dd == d) x = (T)1.0f;
     }
     val[j] = x;
   }
@@ -349,7 +352,8 @@ __device__ __forceinline__ f32x4 last_tile_bias(int g, int M) {
   for (int r = 0; r < 4; ++r) b[r] = (16 * (NKT - 1) + 4 * g + r < M) ? 0.f : -1.0e30f;
   return b;
 }
-__device__ __forceinline__ float softmax_biased(f32x4 (&st)[NKT], float sl2e) {
+// `want_sum` false: the caller takes the denominator from the ones row of the packed V^T (row d of O^T) instead
+__device__ __forceinline__ float softmax_biased(f32x4 (&st)[NKT], float sl2e, bool want_sum = true) {
 #pragma unroll
   for (int t = 0; t < NKT; ++t) st[t] = st[t] * sl2e;        // products are canonical: v_max3 needs no quieting
   float ma = fmaxf(st[0][0], st[0][1]), mb = fmaxf(st[0][2], st[0][3]);
@@ -359,14 +363,16 @@ __device__ __forceinline__ float softmax_biased(f32x4 (&st)[NKT], float sl2e) {
     mb = fmaxf(fmaxf(mb, st[t][2]), st[t][3]);
   }
   const float mx = bfly_max(fmaxf(ma, mb));
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     st[t] = st[t] - mx;
 #pragma unroll
     for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(st[t][r]);
-    acc = acc + st[t];
   }
+  if (!want_sum) return 0.f;                      // wave-uniform
+  f32x4 acc = st[0];
+#pragma unroll
+  for (int t = 1; t < NKT; ++t) acc = acc + st[t];
   const float l = bfly_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
   return __builtin_amdgcn_rcpf(l);
 }
@@ -637,7 +643,7 @@ __device__ __forceinline__ void store_row16(T* obase, const f32x4 (&a)[NDT], int
 template <typename T, int NDT, int QT, int KIND>
 __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, const typename Tr<T>::V8 (&q)[QT][nks_of(NDT)],
                                               const f32x4 kb4, const float sl2e, const float (&w)[QT],
-                                              f32x4 (&au)[QT][NDT], f32x4 (&ac)[QT][NDT]) {
+                                              f32x4 (&au)[QT][NDT], f32x4 (&ac)[QT][NDT], const int sumrow) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
@@ -668,7 +674,7 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
 #ifdef STA_ABL_NOSOFTMAX
     inv[qt] = sl2e;                                  // ablation build: no max / exp / sum
 #else
-    inv[qt] = softmax_biased(st[qt], sl2e);
+    inv[qt] = softmax_biased(st[qt], sl2e, sumrow < 0);
 #endif
     tiles_to_b<T>(st[qt], pb[qt]);
   }
@@ -682,6 +688,15 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
       for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc);
       o[qt][u] = acc;
     }
+  if (sumrow >= 0) {   // denominator = row `sumrow` (= d % 16) of the last O^T tile, held by lane row sumrow >> 2
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float l = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) l = (r == (sumrow & 3)) ? o[qt][NDT - 1][r] : l;
+      inv[qt] = __builtin_amdgcn_rcpf(__shfl(l, 16 * (sumrow >> 2) + (threadIdx.x & 15)));
+    }
+  }
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const float wi = w[qt] * inv[qt];
@@ -802,6 +817,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
   const bool resident = 2 + __builtin_popcount(tile_bits) <= G;   // everything stays in LDS for all tiles
   const f32x4 kb4 = last_tile_bias(g, p.M);
   const float sl2e = p.sl2e;
+  const int sumrow = (d & 15) ? (d & 15) : -1;    // packed V^T carries a ones row at head-dim index d (pack_kv_kernel)
   STA_T(2);
   wait_dma_and_sync();
   STA_T(3);
@@ -822,13 +838,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
     float w[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) w[qt] = 0.f;
-    attend_staged<T, NDT, QT, 0>((const V8*)smem + lane, q0, kb4, sl2e, w, au, ac);
+    attend_staged<T, NDT, QT, 0>((const V8*)smem + lane, q0, kb4, sl2e, w, au, ac, sumrow);
 #ifndef STA_ABL_NOLOAD
     if (MAXIT > 1) request_q0(it + 1, q0);        // context 0 was q0's only consumer: next tile's rows go in place
 #endif
     if (it == 0) STA_T(4);
     if (it == 1) STA_T(10);
-    attend_staged<T, NDT, QT, 1>((const V8*)(smem + CB) + lane, q1, kb4, sl2e, w, au, ac);
+    attend_staged<T, NDT, QT, 1>((const V8*)(smem + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
     if (it == 0) STA_T(5);
     if (it == 1) STA_T(11);
     unsigned wave_bits = 0;                        // discs that touch THIS wave's pixels of the tile
@@ -857,7 +873,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
       const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) w[qt] = ((mb[qt] >> i) & 1u) ? cw : 0.f;
-      attend_staged<T, NDT, QT, 2>((const V8*)(smem + myslot * CB) + lane, q1, kb4, sl2e, w, au, ac);
+      attend_staged<T, NDT, QT, 2>((const V8*)(smem + myslot * CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
     }
     if (it == 0) STA_T(6);
     if (it == 1) STA_T(12);
