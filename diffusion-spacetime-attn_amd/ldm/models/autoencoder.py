@@ -8,6 +8,15 @@ import torch.nn.functional as F
 from torch import nn
 
 from ldm.modules.diffusionmodules.util import Normalize
+from sta import fused as _fused
+
+
+def _norm_silu(norm, x):
+    """GroupNorm + SiLU: one pass through csrc/sta_unet.hip outside autograd (the image decode of fixed-weight
+    sampling and of the last epoch), the eager pair otherwise (the loss path of the tracked epochs)."""
+    if _fused.usable(x):
+        return _fused.groupnorm_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps)
+    return F.silu(norm(x))
 
 
 class ResnetBlock(nn.Module):
@@ -22,8 +31,8 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1)
 
     def forward(self, x):
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv1(_norm_silu(self.norm1, x))
+        h = self.conv2(_norm_silu(self.norm2, h))
         return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
 
 
@@ -94,7 +103,7 @@ class Decoder(nn.Module):
                 h = blk(h)
             if i_level != 0:
                 h = lvl.upsample(h)
-        return self.conv_out(F.silu(self.norm_out(h)))
+        return self.conv_out(_norm_silu(self.norm_out, h))
 
 
 class AutoencoderKL(nn.Module):
