@@ -342,10 +342,10 @@ __device__ __forceinline__ float softmax_keys_fast(f32x4 (&st)[NKT], int g, int 
 
 // Predicate-free softmax for the forward kernels. The scores of padded keys (key >= M) are forced to -1e30
 // through the INITIAL VALUE of the S^T accumulator (last_tile_bias; with M > 64 only the last key tile has
-// padded rows), so no per-key compare/select is left in the loop: 10 packed multiplies, 10 v_max3, the
-// two-step butterfly, 10 packed subtracts, 20 v_exp, 10 adds and one v_rcp — about a third of the VALU
-// instructions of softmax_keys_fast, which matters once a launch carries several images and the kernel is
-// VALU-issue bound instead of latency bound (profiles/r01_kernel_variants.md).
+// padded rows), so no per-key compare/select is left in the loop: 10 v_max3, the two-step butterfly, 10 packed
+// fmas, 20 v_exp, and — unless the denominator comes from the ones row of the packed V^T — 10 adds and one v_rcp:
+// about a quarter of the VALU instructions of softmax_keys_fast, which matters once a launch carries several
+// images and the kernel is VALU-issue bound instead of latency bound (profiles/r01_kernel_variants.md).
 __device__ __forceinline__ f32x4 last_tile_bias(int g, int M) {
   f32x4 b;
 #pragma unroll
@@ -354,18 +354,20 @@ __device__ __forceinline__ f32x4 last_tile_bias(int g, int M) {
 }
 // `want_sum` false: the caller takes the denominator from the ones row of the packed V^T (row d of O^T) instead
 __device__ __forceinline__ float softmax_biased(f32x4 (&st)[NKT], float sl2e, bool want_sum = true) {
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) st[t] = st[t] * sl2e;        // products are canonical: v_max3 needs no quieting
+  // This file is compiled with -ffinite-math-only (sta/lib.py): fmaxf on raw MFMA outputs then needs no quieting
+  // v_max x,x, so the maximum runs on the unscaled scores and scale*log2(e) folds into ONE packed fma per score
+  // pair (exp2(s*c - max*c)); pre-scaling the scores first cost 10 more VALU per context (level 0: 53.2 -> 49.4 us).
   float ma = fmaxf(st[0][0], st[0][1]), mb = fmaxf(st[0][2], st[0][3]);
 #pragma unroll
   for (int t = 1; t < NKT; ++t) {
     ma = fmaxf(fmaxf(ma, st[t][0]), st[t][1]);
     mb = fmaxf(fmaxf(mb, st[t][2]), st[t][3]);
   }
-  const float mx = bfly_max(fmaxf(ma, mb));
+  const float off = bfly_max(fmaxf(ma, mb)) * sl2e;
+  const f32x4 offv = {off, off, off, off}, sv = {sl2e, sl2e, sl2e, sl2e};
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
-    st[t] = st[t] - mx;
+    st[t] = __builtin_elementwise_fma(st[t], sv, -offv);
 #pragma unroll
     for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(st[t][r]);
   }
