@@ -653,22 +653,47 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
   // the K side for S^T first; the V side is requested once the S^T MFMAs are issued and lands under the
   // softmax VALU work, so at most one side (40 of the 76 fragment registers at d = 40) is live at a time.
   // Each fragment serves QT pixel tiles, whose independent softmax chains interleave.
-  V8 ka[NKF], va[NVF];
-#pragma unroll
-  for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
+  // Large head dims (JIT: NDT >= 7) fetch fragments per key tile / per head-dim tile right before their MFMAs, two
+  // tiles in flight: 8*NKS + 24 fragment registers instead of 20*NKS + 12*NDT (220 at d = 160), which is what lets
+  // EIGHT waves share one LDS image there (2 waves per SIMD need <= 256 registers each).
+  constexpr bool JIT = NDT >= 7;
   f32x4 st[QT][NKT];
+  V8 va[JIT ? 1 : NVF];
+  if constexpr (JIT) {
+    V8 kt[2][NKS];
 #pragma unroll
-  for (int t = 0; t < NKT; ++t)
+    for (int s = 0; s < NKS; ++s) kt[0][s] = fr[s * 64];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NKT; ++t) {
+      if (t + 1 < NKT) {
 #pragma unroll
-      for (int s = 0; s < NKS; ++s) acc = Tr<T>::mfma(ka[t * NKS + s], q[qt][s], acc);
-      st[qt][t] = acc;
+        for (int s = 0; s < NKS; ++s) kt[(t + 1) & 1][s] = fr[((t + 1) * NKS + s) * 64];
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) acc = Tr<T>::mfma(kt[t & 1][s], q[qt][s], acc);
+        st[qt][t] = acc;
+      }
     }
-  __builtin_amdgcn_sched_barrier(0);
+  } else {
+    V8 ka[NKF];
 #pragma unroll
-  for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
+    for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) acc = Tr<T>::mfma(ka[t * NKS + s], q[qt][s], acc);
+        st[qt][t] = acc;
+      }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
+  }
   float inv[QT];
   V8 pb[QT][NPS];
 #pragma unroll
@@ -681,15 +706,35 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
     tiles_to_b<T>(st[qt], pb[qt]);
   }
   f32x4 o[QT][NDT];
+  if constexpr (JIT) {
+    V8 vt[2][NPS];
 #pragma unroll
-  for (int u = 0; u < NDT; ++u)
+    for (int s = 0; s < NPS; ++s) vt[0][s] = fr[(NKF + s * NDT) * 64];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NDT; ++u) {
+      if (u + 1 < NDT) {
 #pragma unroll
-      for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc);
-      o[qt][u] = acc;
+        for (int s = 0; s < NPS; ++s) vt[(u + 1) & 1][s] = fr[(NKF + s * NDT + u + 1) * 64];
+      }
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(vt[u & 1][s], pb[qt][s], acc);
+        o[qt][u] = acc;
+      }
     }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NDT; ++u)
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc);
+        o[qt][u] = acc;
+      }
+  }
   if (sumrow >= 0) {   // denominator = row `sumrow` (= d % 16) of the last O^T tile, held by lane row sumrow >> 2
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -1316,7 +1361,8 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
 // Workgroup shape of the LDS-resident kernel (rocprofv3 durations in profiles/r01_kernel_variants.md).
 // 4 waves x 16 px when the launch has few workgroups: latency is what matters. When a launch carries several
 // images it is throughput bound and more waves share one LDS image: 12 waves (3 per SIMD, 148 VGPRs: room for
-// the q prefetch without spills) at d <= 48, 8 waves at d <= 96. Two tiles per wave (QT = 2) measured slower
+// the q prefetch without spills) at d <= 48, 8 waves above (from d = 112 up with per-tile fragment fetches, which
+// is what keeps a wave under 256 registers there). Two tiles per wave (QT = 2) measured slower
 // and stays selectable for experiments only.
 template <typename T, int NDT>
 int launch_fwd_staged(const Params& p, hipStream_t st) {
@@ -1324,7 +1370,7 @@ int launch_fwd_staged(const Params& p, hipStream_t st) {
   int qt = 1;
   int nwv = 4;
   if (NDT <= 3 && w64 >= 2048) nwv = 12;
-  if (NDT > 3 && NDT <= 6 && w64 >= 512) nwv = 8;
+  if (NDT > 3 && w64 >= 512) nwv = 8;             // d = 160: 25.0 -> 18.3 us at 16 images (fragments fetched per tile: 188 VGPRs)
   if (const char* e = getenv("STA_FWD_STAGED_QT")) qt = atoi(e) == 2 ? 2 : 1;     // tuning knobs
   if (const char* e = getenv("STA_FWD_STAGED_WAVES")) nwv = atoi(e) == 8 ? 8 : (atoi(e) == 12 ? 12 : 4);
   if constexpr (NDT <= 3) {
@@ -1332,8 +1378,8 @@ int launch_fwd_staged(const Params& p, hipStream_t st) {
   }
   if constexpr (NDT <= 6) {
     if (qt == 2) return launch_fwd_staged_cfg<T, NDT, 2, 4>(p, st);
-    if (nwv == 8) return launch_fwd_staged_cfg<T, NDT, 1, 8>(p, st);
   }
+  if (nwv == 8) return launch_fwd_staged_cfg<T, NDT, 1, 8>(p, st);
   return launch_fwd_staged_cfg<T, NDT, 1, 4>(p, st);
 }
 
