@@ -301,12 +301,8 @@ template <typename T, int NKS, int NDT, bool SUMROW>
 int launch_sa_cfg(const SParams& p, hipStream_t st) {
   constexpr int QT = 2;
   constexpr int lds = 3 * (((4 * NKS + 2 * NDT) + 3) / 4 * 4) * FRAG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
-    attr_set = true;
-  }
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
   const int tiles = (p.N + 64 * QT - 1) / (64 * QT);
   hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>), dim3(tiles * p.H, p.B), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
@@ -315,11 +311,7 @@ int launch_sa_cfg(const SParams& p, hipStream_t st) {
 
 template <typename T, int NKS, int NDT>
 int launch_sa(const SParams& p, hipStream_t st) {
-#ifdef STA_SA_NOSUMROW   // A/B build (tools/)
-  return launch_sa_cfg<T, NKS, NDT, false>(p, st);
-#else
   return (p.d & 15) ? launch_sa_cfg<T, NKS, NDT, true>(p, st) : launch_sa_cfg<T, NKS, NDT, false>(p, st);
-#endif
 }
 
 template <typename T>

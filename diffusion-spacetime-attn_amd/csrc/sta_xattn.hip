@@ -30,128 +30,9 @@
 #include <string.h>
 #include "sta_xattn.h"
 #include "sta_internal.h"
+#include "sta_xattn_dev.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-constexpr int NKT = 5;      // key tiles of 16 for S^T (M <= 80)
-constexpr int NPS = 3;      // key steps of 32 for PV (96 slots; slots of tile 5 are zero)
-constexpr int FRAG = 1024;  // bytes of one operand fragment (64 lanes x 16 B)
-constexpr int MAXK = STA_MAX_OBJECTS;
-
-template <typename T> struct Tr;
-template <> struct Tr<__bf16> {
-  using V8 = bf16x8;
-  using V4 = bf16x4;
-  static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct Tr<_Float16> {
-  using V8 = f16x8;
-  using V4 = f16x4;
-  static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
-  }
-};
-
-// Number of fragments per (ctx, head): forward part [KQ | VP], backward part [VQ | KP].
-__host__ __device__ constexpr int nks_of(int ndt) { return (ndt + 1) / 2; }
-__host__ __device__ constexpr int fwd_frags(int ndt) { return NKT * nks_of(ndt) + NPS * ndt; }
-__host__ __device__ constexpr int all_frags(int ndt) { return 2 * fwd_frags(ndt); }
-// The backward stages both halves of a context; two of them fit the 160 KiB LDS only up to d = 96.
-__host__ __device__ constexpr bool bwd_double_buffered(int ndt) {
-  return 2 * all_frags(ndt) * 1024 + 16 <= 160 * 1024;
-}
-
-// Key held by k-slot (g, j) of PV step s: slots follow the S^T accumulator order.
-__host__ __device__ __forceinline__ int pv_key(int s, int g, int j) {
-  return 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
-}
-
-// Block id -> logical work id so that each XCD (block b runs on XCD b % 8) owns a CONTIGUOUS range
-// of logical ids: the `heads` workgroups of one pixel tile then share one L2, and the partially used
-// 128-B lines of the [N][C] rows (a head touches d*2 bytes of each row) are fetched from HBM once.
-// Bijective for every grid size (cdna_hip_programming.md §5, "XCD swizzle must be bijective").
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  const int X = 8;
-  const int q = nwg / X, r = nwg % X;
-  const int xcd = bid % X, j = bid / X;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
-}
-
-struct Params {
-  const void* q;         // [2][N][C]
-  const char* packed;    // fragment image
-  const uint8_t* mask;   // [K][N]
-  const float* coef;     // [K]
-  void* out;             // fwd: out [2][N][C];  bwd: dq [2][N][C]
-  const void* dout;      // bwd only
-  float* aux;            // fwd: maps or null; bwd: dcoef partials workspace
-  int N, C, H, d, M, K;
-  int ntiles;            // pixel tiles per head
-  int ntiles_aux;        // staged forward: contexts that fit LDS at once
-  int head_major;        // 1: block b -> head b % H (= XCD b % 8 when H == 8); 0: XCD-contiguous tile ranges
-  int iters;             // staged forward: pixel tiles a workgroup walks with one LDS image
-  int tiles;             // staged forward: pixel tiles per head (ntiles = workgroups per head)
-  int n_img;             // images in this launch (blockIdx.y); every tensor has a leading image axis
-  float sl2e;            // scale * log2(e)
-  float scale;
-};
-
-extern __shared__ __attribute__((aligned(16))) char smem[];
-
-// Launches cover n_img independent images (prompts) at once: blockIdx.y selects the image and every
-// pointer is advanced to that image's slice ([I][2][N][C] activations, [I][K+2] packed contexts,
-// [I][N] mask bits, [I][K] weights, ...). Scalar arithmetic only.
-template <typename T, int NDT>
-__device__ __forceinline__ Params for_image(const Params& p, int img, size_t aux_per_img) {
-  Params r = p;
-  const size_t act = (size_t)2 * p.N * p.C * sizeof(T);
-  r.q = (const char*)p.q + img * act;
-  r.out = (char*)p.out + img * act;
-  if (p.dout) r.dout = (const char*)p.dout + img * act;
-  r.packed = p.packed + (size_t)img * (p.K + 2) * p.H * all_frags(NDT) * FRAG;
-  r.mask = p.mask + (size_t)img * p.N;
-  r.coef = p.coef + (size_t)img * p.K;
-  if (p.aux) r.aux = p.aux + img * aux_per_img;
-  return r;
-}
-
-// Optional in-kernel timeline (build with -DSTA_TRACE, tools/trace_fwd.py): lane 0 of every wave of
-// workgroup `STA_TRACE_WG` stores s_memtime at a few points. Compiled out of the product library.
-#ifdef STA_TRACE
-__device__ long long* g_trace = nullptr;
-// the pointer and the traced workgroup are read ONCE (STA_T_INIT); each point is then one store
-#define STA_T_INIT()                                                                       \
-  long long* trace_base = g_trace;                                                          \
-  const bool trace_on = trace_base && blockIdx.x == (unsigned)trace_base[0] && blockIdx.y == 0 && (threadIdx.x & 63) == 0; \
-  long long* trace_row = trace_base + 8 + (threadIdx.x >> 6) * 16;                          \
-  const long long trace_t0 = (long long)wall_clock64();                                    \
-  if (trace_on) trace_row[15] = trace_t0
-#define STA_T(i)                                                                           \
-  do {                                                                                     \
-    if (trace_on) __builtin_nontemporal_store((long long)__builtin_readcyclecounter(), trace_row + (i)); \
-  } while (0)
-#define STA_T_END()                                                                       \
-  do {                                                                                     \
-    if (trace_on) trace_row[14] = (long long)wall_clock64();                               \
-    if (trace_base && trace_base[1] && threadIdx.x == 0) {                               \
-      trace_base[128 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = trace_t0;                                         \
-      trace_base[129 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = (long long)wall_clock64();                        \
-    }                                                                                      \
-  } while (0)
-#else
-#define STA_T_INIT() do {} while (0)
-#define STA_T_END() do {} while (0)
-#define STA_T(i) do {} while (0)
-#endif
-
 // --------------------------------------------------------------------------------------------------
 // pack: K,V [n_ctx][M][C] -> fragment image. One 64-lane block per fragment.
 // --------------------------------------------------------------------------------------------------
@@ -194,87 +75,6 @@ __global__ __launch_bounds__(64) void pack_kv_kernel(const T* __restrict__ k, co
 }
 
 // --------------------------------------------------------------------------------------------------
-// shared helpers
-// --------------------------------------------------------------------------------------------------
-// Issue the LDS-DMA copy of `nfr` consecutive fragments (1 KiB each) from global to LDS. The image is
-// already in lane order, so destination = wave-uniform base + lane*16 is exactly what
-// global_load_lds_dwordx4 writes. Waves take fragments round-robin.
-__device__ __forceinline__ void stage_frags(const char* gsrc, char* ldst, int nfr, int wv, int nw,
-                                            int lane) {
-  for (int f = wv; f < nfr; f += nw) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(gsrc + (size_t)f * FRAG + lane * 16),
-        (__attribute__((address_space(3))) void*)(ldst + f * FRAG), 16, 0, 0);
-  }
-}
-
-__device__ __forceinline__ void wait_dma_and_sync() {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-}
-
-// Softmax over the key axis of S^T tiles held as st[t][r] <-> key 16t + 4g + r, pixel = lane&15.
-// On return st holds exp2((s - max) * sl2e) (0 for key >= M) and the return value is 1 / sum.
-__device__ __forceinline__ float softmax_keys(f32x4 (&st)[NKT], int g, int M, float sl2e) {
-  float mx = -3.0e38f;
-#pragma unroll
-  for (int t = 0; t < NKT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (16 * t + 4 * g + r < M) mx = fmaxf(mx, st[t][r]);
-  mx = fmaxf(mx, __shfl_xor(mx, 16));
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  float l = 0.f;
-#pragma unroll
-  for (int t = 0; t < NKT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float e = (16 * t + 4 * g + r < M) ? __builtin_amdgcn_exp2f((st[t][r] - mx) * sl2e) : 0.f;
-      st[t][r] = e;
-      l += e;
-    }
-  l += __shfl_xor(l, 16);
-  l += __shfl_xor(l, 32);
-  return 1.0f / l;
-}
-
-// S^T accumulator tiles -> B operands of the 3 key steps of a PV-style product.
-template <typename T>
-__device__ __forceinline__ void tiles_to_b(const f32x4 (&st)[NKT], typename Tr<T>::V8 (&pb)[NPS]) {
-#pragma unroll
-  for (int s = 0; s < NPS; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int t = 2 * s + (j >> 2);
-      pb[s][j] = (t < NKT) ? (T)st[t][j & 3] : (T)0.0f;
-    }
-}
-
-// Buffer (SRD) loads: one instruction per 16-byte access — per-lane byte offset in a VGPR, the
-// per-fragment offset in an SGPR/immediate — instead of a 64-bit VALU address computation per load.
-// Offsets past `bytes` read as zero, which doubles as the predicate for pixels >= N.
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p, unsigned bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, bytes, 0x00020000);
-}
-template <typename V8>
-__device__ __forceinline__ V8 srd_load16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(V8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-
-template <typename T, int NKS>
-__device__ __forceinline__ void load_b_frags(const T* base, bool valid, int g, int d,
-                                             typename Tr<T>::V8 (&f)[NKS]) {
-  using V8 = typename Tr<T>::V8;
-#pragma unroll
-  for (int s = 0; s < NKS; ++s) {
-    V8 z = {};
-    const int dd = 32 * s + 8 * g;
-    f[s] = (valid && dd < d) ? *(const V8*)(base + dd) : z;
-  }
-}
-
-// --------------------------------------------------------------------------------------------------
 // forward: one wave per CONTEXT, operand fragments straight from L2, one LDS combine
 // --------------------------------------------------------------------------------------------------
 // Workgroup = 4 waves = one (pixel tile of 16*QT pixels, head). Wave w attends contexts w, w+4, ...
@@ -296,89 +96,6 @@ __device__ __forceinline__ void load_b_frags(const T* base, bool valid, int g, i
 // Local waves request their fragments speculatively (before the tile test) — a wasted 10-25 KB of L2
 // reads when the tile misses the disc, in exchange for one round trip less when it does not.
 constexpr int NSLOT = 5;   // LDS slots: 0 = A_u (row 0), 1 + w = row-1 partial of wave w
-
-// butterfly partners without LDS: v_permlane16_swap / v_permlane32_swap exchange 16- and 32-lane rows
-__device__ __forceinline__ float bfly_max(float x) {
-  const unsigned u = __float_as_uint(x);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
-  const unsigned v = __float_as_uint(m);
-  auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
-}
-__device__ __forceinline__ float bfly_sum(float x) {
-  const unsigned u = __float_as_uint(x);
-  auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-  const float m = __uint_as_float(a[0]) + __uint_as_float(a[1]);
-  const unsigned v = __float_as_uint(m);
-  auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
-}
-
-// softmax over keys with tree-shaped (not chained) reductions; see softmax_keys for the layout
-__device__ __forceinline__ float softmax_keys_fast(f32x4 (&st)[NKT], int g, int M, float sl2e) {
-  float m4[NKT];
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (16 * t + 4 * g + r < M) ? st[t][r] : -3.0e38f;
-    m4[t] = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-  }
-  float mx = fmaxf(fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])), m4[4]);
-  mx = bfly_max(mx);
-  const float off = mx * sl2e;
-  float s4[NKT];
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      st[t][r] = (16 * t + 4 * g + r < M) ? __builtin_amdgcn_exp2f(__builtin_fmaf(st[t][r], sl2e, -off)) : 0.f;
-    s4[t] = (st[t][0] + st[t][1]) + (st[t][2] + st[t][3]);
-  }
-  const float l = bfly_sum(((s4[0] + s4[1]) + (s4[2] + s4[3])) + s4[4]);
-  return 1.0f / l;
-}
-
-// Predicate-free softmax for the forward kernels. The scores of padded keys (key >= M) are forced to -1e30
-// through the INITIAL VALUE of the S^T accumulator (last_tile_bias; with M > 64 only the last key tile has
-// padded rows), so no per-key compare/select is left in the loop: 10 v_max3, the two-step butterfly, 10 packed
-// fmas, 20 v_exp, and — unless the denominator comes from the ones row of the packed V^T — 10 adds and one v_rcp:
-// about a quarter of the VALU instructions of softmax_keys_fast, which matters once a launch carries several
-// images and the kernel is VALU-issue bound instead of latency bound (profiles/r01_kernel_variants.md).
-__device__ __forceinline__ f32x4 last_tile_bias(int g, int M) {
-  f32x4 b;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) b[r] = (16 * (NKT - 1) + 4 * g + r < M) ? 0.f : -1.0e30f;
-  return b;
-}
-// `want_sum` false: the caller takes the denominator from the ones row of the packed V^T (row d of O^T) instead
-__device__ __forceinline__ float softmax_biased(f32x4 (&st)[NKT], float sl2e, bool want_sum = true) {
-  // This file is compiled with -ffinite-math-only (sta/lib.py): fmaxf on raw MFMA outputs then needs no quieting
-  // v_max x,x, so the maximum runs on the unscaled scores and scale*log2(e) folds into ONE packed fma per score
-  // pair (exp2(s*c - max*c)); pre-scaling the scores first cost 10 more VALU per context (level 0: 53.2 -> 49.4 us).
-  float ma = fmaxf(st[0][0], st[0][1]), mb = fmaxf(st[0][2], st[0][3]);
-#pragma unroll
-  for (int t = 1; t < NKT; ++t) {
-    ma = fmaxf(fmaxf(ma, st[t][0]), st[t][1]);
-    mb = fmaxf(fmaxf(mb, st[t][2]), st[t][3]);
-  }
-  const float off = bfly_max(fmaxf(ma, mb)) * sl2e;
-  const f32x4 offv = {off, off, off, off}, sv = {sl2e, sl2e, sl2e, sl2e};
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    st[t] = __builtin_elementwise_fma(st[t], sv, -offv);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(st[t][r]);
-  }
-  if (!want_sum) return 0.f;                      // wave-uniform
-  f32x4 acc = st[0];
-#pragma unroll
-  for (int t = 1; t < NKT; ++t) acc = acc + st[t];
-  const float l = bfly_sum((acc[0] + acc[1]) + (acc[2] + acc[3]));
-  return __builtin_amdgcn_rcpf(l);
-}
-
 template <typename T, int NDT, int QT>
 __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
@@ -611,151 +328,6 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
 // LDS fragment reads are hoisted into registers ahead of the MFMAs for the same reason the global
 // loads are in the other kernel. Contexts 0/1 are requested before the disc mask is known; local
 // contexts right after the tile test. If the contexts do not fit LDS at once they go in groups.
-// Epilogue stores, 16 bytes per lane. In the accumulator layout a lane holds 4 consecutive head-dim values
-// per 16-wide tile (8 bytes as bf16/f16); 8-byte stores are store-ISSUE bound (MI355X_MICROARCH.md: row-per-lane
-// dwordx2 epilogues run at ~7 B/clk/CU, dwordx4 halves the tail). One v_permlane16_swap per dword pairs the
-// lane rows g and g^1: the even row ends up with head dims 16u+4g .. +7 of tile u, the odd row with
-// 16(u+1)+4(g-1) .. +7 of tile u+1, so every store is a 16-byte piece of the pixel's head row.
-template <typename T, int NDT>
-__device__ __forceinline__ void store_row16(T* obase, const f32x4 (&a)[NDT], int g, int d) {
-  typedef __attribute__((ext_vector_type(2))) T T2;
-  const bool odd = g & 1;
-#pragma unroll
-  for (int u = 0; u < NDT; u += 2) {
-    const unsigned x0 = __builtin_bit_cast(unsigned, T2{(T)a[u][0], (T)a[u][1]});
-    const unsigned x1 = __builtin_bit_cast(unsigned, T2{(T)a[u][2], (T)a[u][3]});
-    unsigned y0 = 0, y1 = 0;
-    if (u + 1 < NDT) {
-      y0 = __builtin_bit_cast(unsigned, T2{(T)a[u + 1][0], (T)a[u + 1][1]});
-      y1 = __builtin_bit_cast(unsigned, T2{(T)a[u + 1][2], (T)a[u + 1][3]});
-    }
-    // after the swap: even rows (own tile-u pair, partner's tile-u pair); odd rows (partner's tile-u+1 pair, own)
-    auto s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-    auto s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-    const u32x4 v = {s0[0], s1[0], s0[1], s1[1]};
-    const int dd = odd ? 16 * (u + 1) + 4 * (g - 1) : 16 * u + 4 * g;
-    if (dd < d && (!odd || u + 1 < NDT)) *(u32x4*)(obase + dd) = v;
-  }
-}
-
-// One context of the LDS-resident kernel for the QT pixel tiles of a wave. KIND is compile time — 0: ""
-// on the uncond row (-> au), 1: global prompt on the cond row (-> ac), 2: a local prompt, ac += w (A - au) —
-// so there is no per-context select/copy of the accumulators, queries or weights left in the instruction
-// stream (the runtime-`c` version spent ~2/3 of its VALU slots on v_cndmask/v_mov and scalar branches).
-template <typename T, int NDT, int QT, int KIND>
-__device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, const typename Tr<T>::V8 (&q)[QT][nks_of(NDT)],
-                                              const f32x4 kb4, const float sl2e, const float (&w)[QT],
-                                              f32x4 (&au)[QT][NDT], f32x4 (&ac)[QT][NDT], const int sumrow) {
-  using V8 = typename Tr<T>::V8;
-  constexpr int NKS = nks_of(NDT);
-  constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
-  // LDS -> registers one operand side at a time, each ahead of its MFMAs (no ds_read -> wait -> mfma chains):
-  // the K side for S^T first; the V side is requested once the S^T MFMAs are issued and lands under the
-  // softmax VALU work, so at most one side (40 of the 76 fragment registers at d = 40) is live at a time.
-  // Each fragment serves QT pixel tiles, whose independent softmax chains interleave.
-  // Large head dims (JIT: NDT >= 7) fetch fragments per key tile / per head-dim tile right before their MFMAs, two
-  // tiles in flight: 8*NKS + 24 fragment registers instead of 20*NKS + 12*NDT (220 at d = 160), which is what lets
-  // EIGHT waves share one LDS image there (2 waves per SIMD need <= 256 registers each).
-  constexpr bool JIT = NDT >= 7;
-  f32x4 st[QT][NKT];
-  V8 va[JIT ? 1 : NVF];
-  if constexpr (JIT) {
-    V8 kt[2][NKS];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) kt[0][s] = fr[s * 64];
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      if (t + 1 < NKT) {
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) kt[(t + 1) & 1][s] = fr[((t + 1) * NKS + s) * 64];
-      }
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) acc = Tr<T>::mfma(kt[t & 1][s], q[qt][s], acc);
-        st[qt][t] = acc;
-      }
-    }
-  } else {
-    V8 ka[NKF];
-#pragma unroll
-    for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
-#pragma unroll
-    for (int t = 0; t < NKT; ++t)
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) acc = Tr<T>::mfma(ka[t * NKS + s], q[qt][s], acc);
-        st[qt][t] = acc;
-      }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
-  }
-  float inv[QT];
-  V8 pb[QT][NPS];
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-#ifdef STA_ABL_NOSOFTMAX
-    inv[qt] = sl2e;                                  // ablation build: no max / exp / sum
-#else
-    inv[qt] = softmax_biased(st[qt], sl2e, sumrow < 0);
-#endif
-    tiles_to_b<T>(st[qt], pb[qt]);
-  }
-  f32x4 o[QT][NDT];
-  if constexpr (JIT) {
-    V8 vt[2][NPS];
-#pragma unroll
-    for (int s = 0; s < NPS; ++s) vt[0][s] = fr[(NKF + s * NDT) * 64];
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      if (u + 1 < NDT) {
-#pragma unroll
-        for (int s = 0; s < NPS; ++s) vt[(u + 1) & 1][s] = fr[(NKF + s * NDT + u + 1) * 64];
-      }
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(vt[u & 1][s], pb[qt][s], acc);
-        o[qt][u] = acc;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < NDT; ++u)
-#pragma unroll
-      for (int qt = 0; qt < QT; ++qt) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[qt][s], acc);
-        o[qt][u] = acc;
-      }
-  }
-  if (sumrow >= 0) {   // denominator = row `sumrow` (= d % 16) of the last O^T tile, held by lane row sumrow >> 2
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt) {
-      float l = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) l = (r == (sumrow & 3)) ? o[qt][NDT - 1][r] : l;
-      inv[qt] = __builtin_amdgcn_rcpf(__shfl(l, 16 * (sumrow >> 2) + (threadIdx.x & 15)));
-    }
-  }
-#pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const float wi = w[qt] * inv[qt];
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      if (KIND == 0) au[qt][u] = o[qt][u] * inv[qt];
-      else if (KIND == 1) ac[qt][u] = o[qt][u] * inv[qt];
-      else ac[qt][u] = o[qt][u] * wi + (ac[qt][u] - au[qt][u] * w[qt]);
-    }
-  }
-}
-
 // A workgroup keeps the fragments of one head in LDS and walks `p.iters` consecutive pixel tiles of
 // 16*NWV*QT pixels with them: the staging traffic (L2 -> LDS, 19-55 KB per context) and the staging
 // latency are paid once per workgroup instead of once per 64/128 pixels — at 8 images per launch the
@@ -764,7 +336,6 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
 // its next tile, the other waves of the SIMD compute.
 // MAXIT = 1 is the single-tile build for launches with few workgroups (one image): no mask bytes beyond the
 // tile's own, no prefetch code.
-// -DSTA_ABL_NOSTORE / NOLOAD / NOSOFTMAX are ablation builds for profiles/r01_kernel_variants.md (never shipped).
 constexpr int STAGED_MAXIT = 12;
 template <typename T, int NDT, int QT, int NWV, int MAXIT>
 __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_kernel(const Params pin) {
@@ -877,18 +448,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
       stage_locals(tile_bits, 2, G - 2);
       wait_dma_and_sync();
     }
-#ifndef STA_ABL_NOLOAD
     if (MAXIT > 1) request_q1(it + 1, q1n, mbn);
-#endif
     if (it == 1) STA_T(9);
     f32x4 au[QT][NDT], ac[QT][NDT];
     float w[QT];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) w[qt] = 0.f;
     attend_staged<T, NDT, QT, 0>((const V8*)smem + lane, q0, kb4, sl2e, w, au, ac, sumrow);
-#ifndef STA_ABL_NOLOAD
     if (MAXIT > 1) request_q0(it + 1, q0);        // context 0 was q0's only consumer: next tile's rows go in place
-#endif
     if (it == 0) STA_T(4);
     if (it == 1) STA_T(10);
     attend_staged<T, NDT, QT, 1>((const V8*)(smem + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
@@ -928,21 +495,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
     for (int qt = 0; qt < QT; ++qt) {
       if (valid[qt]) {
         T* obase = (T*)p.out + (size_t)((wt + it * W) * TP + (wv * QT + qt) * 16 + c16) * C + h * d;
-#ifdef STA_ABL_NOSTORE
-        if (au[qt][0][0] == 12345.f && ac[qt][0][0] == 54321.f)      // ablation build: keep the values live, store nothing
-#endif
-        {
-          store_row16<T, NDT>(obase, au[qt], g, d);
-          store_row16<T, NDT>(obase + (size_t)N * C, ac[qt], g, d);
-        }
+        store_row16<T, NDT>(obase, au[qt], g, d);
+        store_row16<T, NDT>(obase + (size_t)N * C, ac[qt], g, d);
       }
-#ifndef STA_ABL_NOLOAD
       if (MAXIT > 1) {
         mb[qt] = mbn[qt];
 #pragma unroll
         for (int s2 = 0; s2 < NKS; ++s2) q1[qt][s2] = q1n[qt][s2];
       }
-#endif
     }
   }
   STA_T(8);
@@ -1247,6 +807,8 @@ __global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restri
 
 // error text shared by every translation unit of the library (sta_internal.h)
 thread_local char g_sta_err[256] = "";
+// kernel-selection overrides (sta_set_option): 0 = automatic. Written by tests/tools only, read at launch.
+int g_sta_opt[STA_OPT_COUNT] = {};
 int sta_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -1284,8 +846,7 @@ int check_shape(int N, int C, int heads, int M, int K) {
 // so QT = 1 ships and larger values stay reachable through the tuning knob only.
 int pick_qt(int N, int heads, int ndt, int n_img) {
   const int cap = ndt <= 3 ? 4 : (ndt <= 6 ? 2 : 1);
-  if (const char* e = getenv("STA_FWD_QT")) {  // tuning knob (tools/kernel_bench.py); not used in production
-    const int v = atoi(e);
+  if (const int v = g_sta_opt[STA_OPT_SPLIT_QT]) {
     if (v == 1 || v == 2 || v == 4) return v < cap ? v : cap;
   }
   (void)N; (void)heads; (void)n_img;
@@ -1299,15 +860,11 @@ int launch_fwd(const Params& p0, hipStream_t st) {
   // 7 extra copies of the fragment image (one per further XCD) vs the partial-line over-fetch of q
   // (a head's d*2-byte segment of each row straddles 128-B lines): head-major wins from d = 80 up
   p.head_major = (p.H % 8 == 0 && NDT >= 5) ? 1 : 0;
-  if (const char* e = getenv("STA_FWD_HEAD_MAJOR")) p.head_major = atoi(e) ? 1 : 0;   // tuning knob
+  if (g_sta_opt[STA_OPT_HEAD_MAJOR]) p.head_major = g_sta_opt[STA_OPT_HEAD_MAJOR] == 1 ? 1 : 0;
   const int lds = NSLOT * 16 * QT * (p.d + 4) * (int)sizeof(float);
-  static bool attr_set = false;  // benign race: idempotent
-  if (!attr_set) {
-    constexpr int lds_max = NSLOT * 16 * QT * (16 * NDT + 4) * (int)sizeof(float);
-    if (hipFuncSetAttribute((const void*)xattn_fwd_kernel<T, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_max) != hipSuccess)
-      return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd) failed");
-    attr_set = true;
-  }
+  static StaLdsAttr attr;
+  constexpr int lds_max = NSLOT * 16 * QT * (16 * NDT + 4) * (int)sizeof(float);
+  if (!attr.ensure((const void*)xattn_fwd_kernel<T, NDT, QT>, lds_max)) return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd) failed");
   hipLaunchKernelGGL((xattn_fwd_kernel<T, NDT, QT>), dim3(p.ntiles * p.H, p.n_img), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd launch: %s", hipGetErrorString(e));
@@ -1319,7 +876,7 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   constexpr int TP = 16 * NWV * QT;
   Params p = p0;
   p.head_major = (p.H % 8 == 0 && NDT >= 5) ? 1 : 0;   // one head per XCD: its K/V image is fetched by one L2 only
-  if (const char* e = getenv("STA_FWD_HEAD_MAJOR")) p.head_major = atoi(e) ? 1 : 0;
+  if (g_sta_opt[STA_OPT_HEAD_MAJOR]) p.head_major = g_sta_opt[STA_OPT_HEAD_MAJOR] == 1 ? 1 : 0;
   int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
   if (G > p.K + 2) G = p.K + 2;
   p.ntiles_aux = G;
@@ -1336,24 +893,20 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   int iters = (int)((tiles + wg_per_head - 1) / wg_per_head);
   if (iters > STAGED_MAXIT) iters = STAGED_MAXIT;
   if (iters < 1 || G < p.K + 2) iters = 1;
-  if (const char* e = getenv("STA_FWD_STAGED_ITERS")) { const int v = atoi(e); if (v >= 1 && v <= STAGED_MAXIT) iters = v; }   // tuning knob
+  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) { if (v >= 1 && v <= STAGED_MAXIT) iters = v; }
   p.iters = iters;
   p.tiles = tiles;
   p.ntiles = (tiles + iters - 1) / iters;
   // multi-tile launches carry several images: with the grid-wide XCD-contiguous map an XCD owns whole (image, tile
   // group) units — all 8 heads, so q lines AND the image's K/V fragments are fetched by one L2 only
-  if (iters > 1 && !getenv("STA_FWD_HEAD_MAJOR")) p.head_major = 0;
-  auto launch = [&](auto kernel, bool& attr_set) {
-    if (!attr_set) {
-      if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-        return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
-      attr_set = true;
-    }
+  if (iters > 1 && !g_sta_opt[STA_OPT_HEAD_MAJOR]) p.head_major = 0;
+  auto launch = [&](auto kernel, StaLdsAttr& attr) {
+    if (!attr.ensure((const void*)kernel, 160 * 1024)) return fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd staged) failed");
     hipLaunchKernelGGL(kernel, dim3(p.ntiles * p.H, p.n_img), dim3(64 * NWV), lds, st, p);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
   };
-  static bool attr1 = false, attrn = false;      // benign race: idempotent
+  static StaLdsAttr attr1, attrn;
   if (iters == 1) return launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, 1>, attr1);
   return launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, STAGED_MAXIT>, attrn);
 }
@@ -1371,8 +924,8 @@ int launch_fwd_staged(const Params& p, hipStream_t st) {
   int nwv = 4;
   if (NDT <= 3 && w64 >= 2048) nwv = 12;
   if (NDT > 3 && w64 >= 512) nwv = 8;             // d = 160: 25.0 -> 18.3 us at 16 images (fragments fetched per tile: 188 VGPRs)
-  if (const char* e = getenv("STA_FWD_STAGED_QT")) qt = atoi(e) == 2 ? 2 : 1;     // tuning knobs
-  if (const char* e = getenv("STA_FWD_STAGED_WAVES")) nwv = atoi(e) == 8 ? 8 : (atoi(e) == 12 ? 12 : 4);
+  if (g_sta_opt[STA_OPT_STAGED_QT]) qt = g_sta_opt[STA_OPT_STAGED_QT] == 2 ? 2 : 1;
+  if (const int v = g_sta_opt[STA_OPT_STAGED_WAVES]) nwv = v == 8 ? 8 : (v == 12 ? 12 : 4);
   if constexpr (NDT <= 3) {
     if (nwv == 12) return launch_fwd_staged_cfg<T, NDT, 1, 12>(p, st);   // 16 waves at 128 VGPRs spill (88 B/lane): 44 vs 33 us
   }
@@ -1392,10 +945,8 @@ int launch_fwd_staged(const Params& p, hipStream_t st) {
 // -> staged from 256 64-pixel workgroups per launch (launch_fwd_staged picks the workgroup shape and the tiles per
 //    workgroup); the wave-per-context kernel below that, for attention-map output and for M <= 64.
 bool use_staged(int N, int heads, int ndt, int n_img) {
-  if (const char* e = getenv("STA_FWD_KERNEL")) {  // tuning knob: "staged" / "split"
-    if (!strcmp(e, "staged")) return true;
-    if (!strcmp(e, "split")) return false;
-  }
+  if (g_sta_opt[STA_OPT_FWD_KERNEL] == 1) return true;
+  if (g_sta_opt[STA_OPT_FWD_KERNEL] == 2) return false;
   (void)ndt;
   return (long)((N + 63) / 64) * heads * n_img >= 256;
 }
@@ -1410,12 +961,8 @@ int launch_fwd_qt(const Params& p, int qt, hipStream_t st) {
 template <typename T, int NDT>
 int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
   constexpr int lds = (bwd_double_buffered(NDT) ? 2 : 1) * all_frags(NDT) * FRAG + 16;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)xattn_bwd_kernel<T, NDT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return fail(STA_E_LAUNCH, "hipFuncSetAttribute(bwd) failed");
-    attr_set = true;
-  }
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)xattn_bwd_kernel<T, NDT>, lds)) return fail(STA_E_LAUNCH, "hipFuncSetAttribute(bwd) failed");
   const int nwg = p.ntiles * p.H;
   hipLaunchKernelGGL((xattn_bwd_kernel<T, NDT>), dim3(nwg, p.n_img), dim3(64 * nw), lds, st, p);
   hipError_t e = hipGetLastError();
@@ -1491,6 +1038,13 @@ int sta_debug_set_trace(void* buf) {
 #endif
 
 int sta_version(void) { return STA_VERSION; }
+
+int sta_set_option(int key, int value) {
+  g_err[0] = 0;
+  if (key < 0 || key >= STA_OPT_COUNT) return fail(STA_E_ARG, "unknown option %d", key);
+  g_sta_opt[key] = value;
+  return STA_OK;
+}
 
 const char* sta_last_error(void) { return g_err; }
 

@@ -1,0 +1,376 @@
+// sta_xattn_proj.hip — spatial-temporal cross-attention forward WITH the query projection inside
+// (gfx950 only). C-ABI: sta_xattn_pack_wq / sta_xattn_pack_kv_proj / sta_xattn_fwd_proj.
+//
+// What it replaces (reference, attention_optimization/stable-diffusion/ldm/modules/attention.py):
+//   :178      q = self.to_q(x)                       (x = norm2(hidden), recomputed K+1 times there)
+//   :175-197  CrossAttention.forward for the K+2 (row, context) pairs that reach the output
+//   :278-294  the disc-masked, coef-weighted global/local blend
+// i.e. sta_xattn_fwd plus the GEMM in front of it: the [2][N][C] query tensor never exists in HBM.
+//
+// Why: the attention alone has 154 flop per HBM byte (below the 310 flop/B ridge of an MI355X) and its
+// instruction stream is VALU bound (softmax: ~9 VALU per MFMA, matrix pipe 14 % busy). The projection is pure
+// MFMA work on the SAME pixels: 2*C flop per activation byte more, no extra HBM traffic (y in instead of q in),
+// and its MFMAs issue in the shadow of the other waves' softmax VALU.
+//
+// Everything stays "swapped" (pixel = MFMA column, see sta_xattn.hip):
+//   Q^T[dd][px] = Wq_h[dd][:] . y[px][:]     A = Wq fragments (LDS), B = y rows (global, 16 B per lane)
+// The accumulator of head-dim tile u holds Q^T[16u + 4g + r][px = c]; packed as 16-bit pairs it IS the B
+// operand of S^T = K.Q^T once the head-dim axis of the K fragments is permuted at pack time
+// (k-slot 8g+j of step s  <->  head dim 32s + 16(j>>2) + 4g + (j&3), the same permutation the PV product uses
+// for its keys): no LDS round trip and no cross-lane traffic between the projection and the attention.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sta_xattn.h"
+#include "sta_internal.h"
+#include "sta_xattn_dev.h"
+
+namespace {
+
+constexpr int RING = 5;   // k-steps (32 channels each) of y in flight per batch row; C % (32 * RING) == 0
+
+// to_q.weight [C][C] (row = output channel h*d + dd, col = input channel) -> per head [s][u] fragments:
+// lane (g, c) of fragment (s, u) holds Wq[h*d + 16u + c][32s + 8g .. +7]; rows 16u + c >= d are zero.
+template <typename T>
+__global__ __launch_bounds__(64) void pack_wq_kernel(const T* __restrict__ wq, T* __restrict__ packed, int C, int d,
+                                                     int ndt) {
+  const int f = blockIdx.x, h = blockIdx.y;
+  const int s = f / ndt, u = f % ndt;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const int row = 16 * u + c;
+  typename Tr<T>::V8 val;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int col = 32 * s + 8 * g + j;
+    val[j] = (row < d && col < C) ? wq[((size_t)h * d + row) * C + col] : (T)0.0f;
+  }
+  *((typename Tr<T>::V8*)((char*)packed + ((size_t)h * gridDim.x + f) * FRAG) + lane) = val;
+}
+
+// K,V [n_ctx][M][C] -> forward-only fragment image [ctx][head][KQ' | VP]; KQ' = the K rows with the head-dim
+// axis in projected-query order (see the file header), VP exactly as in sta_xattn.hip (incl. the ones row).
+template <typename T>
+__global__ __launch_bounds__(64) void pack_kv_proj_kernel(const T* __restrict__ k, const T* __restrict__ v,
+                                                          T* __restrict__ packed, int M, int C, int H, int d, int ndt) {
+  const int nks = nks_of(ndt);
+  const int f = blockIdx.x;               // 0 .. fwd_frags(ndt) - 1
+  const int ch = blockIdx.y;              // ctx * H + h
+  const int ctx = ch / H, h = ch % H;
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  typename Tr<T>::V8 val;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    T x = (T)0.0f;
+    if (f < NKT * nks) {
+      const int t = f / nks, s = f % nks;
+      const int key = 16 * t + c, dd = pv_key(s, g, j);      // head dim held by k-slot (g, j) of step s
+      if (key < M && dd < d) x = k[((size_t)ctx * M + key) * C + h * d + dd];
+    } else {
+      const int f2 = f - NKT * nks;
+      const int s = f2 / ndt, u = f2 % ndt;
+      const int key = pv_key(s, g, j), dd = 16 * u + c;
+      if (key < M && dd < d) x = v[((size_t)ctx * M + key) * C + h * d + dd];
+      else if (key < M && dd == d) x = (T)1.0f;             // ones row: softmax denominator out of the PV MFMAs
+    }
+    val[j] = x;
+  }
+  *((typename Tr<T>::V8*)((char*)packed + ((size_t)ch * gridDim.x + f) * FRAG) + lane) = val;
+}
+
+struct PParams {
+  const void* y;         // [I][2][N][C]  norm2(hidden)
+  const char* wq;        // packed to_q.weight: [H][nkc][NDT] fragments
+  const char* kv;        // forward-only K/V image: [I][K+2][H][KQ' | VP]
+  const uint8_t* mask;   // [I][N] bit field
+  const float* coef;     // [I][K]
+  void* out;             // [I][2][N][C]
+  int N, C, H, d, M, K;
+  int nkc;               // k-steps of the projection: C / 32
+  int W;                 // workgroups per (head, image)
+  int tiles;             // pixel tiles per head
+  int iters;             // pixel tiles a workgroup walks at most
+  float sl2e;
+};
+
+// One workgroup = NWV waves x 16 pixels, one head, one image. It copies the head's Wq slice and the fragments of
+// ALL K+2 contexts into LDS once (LDS-DMA; 30 + 19 (K+2) KiB at d = 40), passes one barrier and then walks
+// `iters` strided pixel tiles: per tile and wave
+//   projection  : NDT * nkc * 2 MFMAs (both batch rows share every Wq fragment read), y rows streamed through a
+//                 RING-deep register ring — the loads of k-step s + RING are issued when step s is consumed, and
+//                 the first RING steps of the NEXT tile right after the last one, so they land under the attention
+//   attention   : contexts 0, 1 and the local contexts whose disc touches the wave's pixels, from LDS
+//                 (attend_staged, shared with sta_xattn.hip) — blend in registers, 16-byte stores.
+// No barrier after the prologue: waves drift apart, one wave's projection MFMAs run beside another's softmax VALU.
+template <typename T, int NDT, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_kernel(const PParams p) {
+  using V8 = typename Tr<T>::V8;
+  constexpr int NKS = nks_of(NDT);
+  constexpr int NFWD = fwd_frags(NDT);
+  constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
+  constexpr int TP = 16 * NWV;                    // pixels per tile
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  // block -> (image, tile group, head): XCD-contiguous over the whole grid, so that the 8 heads of a tile group —
+  // which read the SAME y rows — share one L2 (y is fetched from HBM once, the other 7 reads are L2 hits)
+  const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int Lg = xcd_remap(lin, (int)(gridDim.x * gridDim.y));
+  const int img = Lg / (int)gridDim.x;
+  const int L = Lg - img * (int)gridDim.x;
+  int wt, h;
+  if (p.H == 8) { wt = L >> 3; h = L & 7; } else { wt = L / p.H; h = L % p.H; }
+  const int N = p.N, C = p.C, d = p.d, K = p.K, nkc = p.nkc, W = p.W;
+  const unsigned row_bytes = (unsigned)C * (unsigned)sizeof(T);
+  const size_t act = (size_t)2 * N * row_bytes;
+  const char* yb = (const char*)p.y + img * act;
+  T* ob = (T*)((char*)p.out + img * act);
+  const size_t ctx_stride = (size_t)p.H * CB;
+  const char* kv = p.kv + ((size_t)img * (K + 2) * p.H + h) * CB;
+  const uint8_t* mask = p.mask + (size_t)img * N;
+  const float coef_lane = p.coef[(size_t)img * K + min(lane, K > 0 ? K - 1 : 0)];
+  const int nwq = NDT * nkc;                      // Wq fragments of this head
+  char* lds_ctx = smem + (size_t)nwq * FRAG;
+
+  // ---- prologue: LDS-DMA of Wq_h and every context, first y steps of the first tile -------------------------
+  stage_frags(p.wq + (size_t)h * nwq * FRAG, smem, nwq, wv, NWV, lane);
+  for (int c = 0; c < K + 2; ++c) stage_frags(kv + c * ctx_stride, lds_ctx + c * CB, NFWD, wv, NWV, lane);
+
+  const int mine = (p.tiles - wt + W - 1) / W;    // tiles wt, wt + W, ... of this workgroup
+  const int iters = mine < p.iters ? mine : p.iters;
+  const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
+  const unsigned row1 = (unsigned)N * row_bytes;
+  // pixels >= N (and tiles past the end) are pushed out of the descriptor's range: they read as zeros
+  auto voff_of = [&](int it) -> unsigned {
+    const int px = (wt + it * W) * TP + wv * 16 + c16;
+    return (it < iters && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
+  };
+  auto mask_of = [&](int it) -> unsigned {
+    const int px = (wt + it * W) * TP + wv * 16 + c16;
+    return mask[(it < iters && px < N) ? px : 0];
+  };
+  V8 yr0[RING], yr1[RING];
+  unsigned voff = voff_of(0);
+  unsigned mb = mask_of(0);
+#pragma unroll
+  for (int j = 0; j < RING; ++j) {
+    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
+    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
+  }
+  const f32x4 kb4 = last_tile_bias(g, p.M);
+  const float sl2e = p.sl2e;
+  const int sumrow = (d & 15) ? (d & 15) : -1;
+  const unsigned kmask = (1u << K) - 1u;
+  wait_dma_and_sync();
+
+  for (int it = 0; it < iters; ++it) {
+    // ---- projection: Q^T tiles of both batch rows --------------------------------------------------------
+    f32x4 qa0[NDT], qa1[NDT];
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      qa0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      qa1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const V8* wf = (const V8*)smem + lane;
+    for (int s0 = 0; s0 < nkc; s0 += RING) {
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        const int s = s0 + j;
+        V8 a[NDT];
+#pragma unroll
+        for (int u = 0; u < NDT; ++u) a[u] = wf[(s * NDT + u) * 64];
+#pragma unroll
+        for (int u = 0; u < NDT; ++u) {
+          qa0[u] = Tr<T>::mfma(a[u], yr0[j], qa0[u]);
+          qa1[u] = Tr<T>::mfma(a[u], yr1[j], qa1[u]);
+        }
+        if (s + RING < nkc) {                     // scalar condition: refill this ring slot with step s + RING
+          yr0[j] = srd_load16<V8>(y_srd, voff, 64u * (s + RING));
+          yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * (s + RING));
+        }
+      }
+    }
+    // the first RING steps of the next tile (zeros past the last tile) land while this tile attends
+    const bool valid = (wt + it * W) * TP + wv * 16 + c16 < N;
+    voff = voff_of(it + 1);
+    const unsigned mbn = mask_of(it + 1);
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+      yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
+      yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
+    }
+    // accumulators -> B operands of S^T (rounded to T once, as a GEMM epilogue would)
+    V8 q0[1][NKS], q1[1][NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 2 * s + (j >> 2);
+        q0[0][s][j] = (t < NDT) ? (T)qa0[t][j & 3] : (T)0.0f;
+        q1[0][s][j] = (t < NDT) ? (T)qa1[t][j & 3] : (T)0.0f;
+      }
+
+    // ---- attention + blend -------------------------------------------------------------------------------
+    f32x4 au[1][NDT], ac[1][NDT];
+    float w[1] = {0.f};
+    attend_staged<T, NDT, 1, 0>((const V8*)lds_ctx + lane, q0, kb4, sl2e, w, au, ac, sumrow);
+    attend_staged<T, NDT, 1, 1>((const V8*)(lds_ctx + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
+    const unsigned mbits = valid ? (mb & kmask) : 0u;
+    for (int i = 0; i < K; ++i) {
+      if (!__ballot((mbits >> i) & 1u)) continue;  // none of this wave's pixels inside disc i
+      const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+      w[0] = ((mbits >> i) & 1u) ? cw : 0.f;
+      attend_staged<T, NDT, 1, 2>((const V8*)(lds_ctx + (size_t)(2 + i) * CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
+    }
+    if (valid) {
+      T* obase = ob + (size_t)((wt + it * W) * TP + wv * 16 + c16) * C + h * d;
+      store_row16<T, NDT>(obase, au[0], g, d);
+      store_row16<T, NDT>(obase + (size_t)N * C, ac[0], g, d);
+    }
+    mb = mbn;
+  }
+}
+
+template <typename T, int NDT, int NWV>
+int launch_proj_cfg(PParams p, int n_img, int lds, hipStream_t st) {
+  constexpr int TP = 16 * NWV;
+  p.tiles = (p.N + TP - 1) / TP;
+  // one workgroup per CU (its LDS image takes most of the 160 KiB): enough tiles per workgroup that ONE round of
+  // workgroups covers the launch
+  long wg_per_head = 256L / ((long)p.H * n_img);
+  if (wg_per_head < 1) wg_per_head = 1;
+  if (wg_per_head > p.tiles) wg_per_head = p.tiles;
+  p.iters = (int)((p.tiles + wg_per_head - 1) / wg_per_head);
+  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
+  p.W = (p.tiles + p.iters - 1) / p.iters;
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)xattn_fwd_proj_kernel<T, NDT, NWV>, 160 * 1024))
+    return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj) failed");
+  hipLaunchKernelGGL((xattn_fwd_proj_kernel<T, NDT, NWV>), dim3(p.W * p.H, n_img), dim3(64 * NWV), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj launch: %s", hipGetErrorString(e));
+}
+
+template <typename T, int NDT>
+int launch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
+  int nwv = 8;
+  if (const int v = g_sta_opt[STA_OPT_STAGED_WAVES]) nwv = v == 12 ? 12 : (v == 4 ? 4 : 8);
+  if (nwv == 12) return launch_proj_cfg<T, NDT, 12>(p, n_img, lds, st);
+  if (nwv == 4) return launch_proj_cfg<T, NDT, 4>(p, n_img, lds, st);
+  return launch_proj_cfg<T, NDT, 8>(p, n_img, lds, st);
+}
+
+template <typename T>
+int dispatch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
+  switch ((p.d + 15) / 16) {
+    case 1: return launch_proj<T, 1>(p, n_img, lds, st);
+    case 2: return launch_proj<T, 2>(p, n_img, lds, st);
+    case 3: return launch_proj<T, 3>(p, n_img, lds, st);
+    case 4: return launch_proj<T, 4>(p, n_img, lds, st);
+    case 5: return launch_proj<T, 5>(p, n_img, lds, st);
+    case 6: return launch_proj<T, 6>(p, n_img, lds, st);
+  }
+  return sta_fail(STA_E_UNSUP, "head dim %d unsupported by the projection-fused forward", p.d);
+}
+
+int proj_lds_bytes(int C, int heads, int K) {
+  const int d = C / heads, ndt = (d + 15) / 16;
+  return (ndt * (C / 32) + (K + 2) * fwd_frags(ndt)) * FRAG;
+}
+
+int check_proj_shape(int N, int C, int heads, int M, int K) {
+  if (N <= 0 || C <= 0 || heads <= 0 || M <= 0 || K < 0) return sta_fail(STA_E_ARG, "non-positive dimension");
+  if (C % heads) return sta_fail(STA_E_ARG, "C=%d not divisible by heads=%d", C, heads);
+  const int d = C / heads;
+  if (d % 8 || d > 96) return sta_fail(STA_E_UNSUP, "head dim %d unsupported by the projection-fused forward (d %% 8 == 0, d <= 96)", d);
+  if (C % (32 * RING)) return sta_fail(STA_E_UNSUP, "C=%d unsupported by the projection-fused forward (need C %% %d == 0)", C, 32 * RING);
+  if (M > STA_MAX_KEYS || M <= 16 * (NKT - 1)) return sta_fail(STA_E_UNSUP, "M=%d keys unsupported (65..%d)", M, STA_MAX_KEYS);
+  if (K > STA_MAX_OBJECTS) return sta_fail(STA_E_UNSUP, "K=%d objects unsupported (max %d)", K, STA_MAX_OBJECTS);
+  if (proj_lds_bytes(C, heads, K) > 160 * 1024)
+    return sta_fail(STA_E_UNSUP, "Wq slice + %d contexts need %d bytes of LDS (160 KiB per CU)", K + 2, proj_lds_bytes(C, heads, K));
+  return STA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sta_xattn_fwd_proj_supported(int C, int heads, int M, int K) {
+  const int rc = check_proj_shape(16, C, heads, M, K);
+  g_sta_err[0] = 0;
+  return rc == STA_OK;
+}
+
+size_t sta_xattn_packed_wq_bytes(int C, int heads) {
+  if (C <= 0 || heads <= 0 || C % heads || C % 32) return 0;
+  const int d = C / heads;
+  if (d % 8 || d > STA_MAX_HEAD_DIM) return 0;
+  return (size_t)heads * ((d + 15) / 16) * (C / 32) * FRAG;
+}
+
+int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!wq || !packed) return sta_fail(STA_E_ARG, "null pointer");
+  if (sta_xattn_packed_wq_bytes(C, heads) == 0) return sta_fail(STA_E_UNSUP, "C=%d heads=%d unsupported", C, heads);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const int d = C / heads, ndt = (d + 15) / 16;
+  const dim3 grid(ndt * (C / 32), heads);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(pack_wq_kernel<__bf16>, grid, dim3(64), 0, st, (const __bf16*)wq, (__bf16*)packed, C, d, ndt);
+  else
+    hipLaunchKernelGGL(pack_wq_kernel<_Float16>, grid, dim3(64), 0, st, (const _Float16*)wq, (_Float16*)packed, C, d, ndt);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_wq launch: %s", hipGetErrorString(e));
+}
+
+size_t sta_xattn_packed_kv_proj_bytes(int n_ctx, int heads, int d) {
+  if (n_ctx <= 0 || heads <= 0 || d <= 0 || d % 8 || d > STA_MAX_HEAD_DIM) return 0;
+  return (size_t)n_ctx * heads * fwd_frags((d + 15) / 16) * FRAG;
+}
+
+int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype,
+                           void* stream) {
+  g_sta_err[0] = 0;
+  if (!k || !v || !packed) return sta_fail(STA_E_ARG, "null pointer");
+  if (n_ctx <= 0) return sta_fail(STA_E_ARG, "n_ctx=%d", n_ctx);
+  if (C <= 0 || heads <= 0 || C % heads) return sta_fail(STA_E_ARG, "C=%d heads=%d", C, heads);
+  const int d = C / heads, ndt = (d + 15) / 16;
+  if (sta_xattn_packed_kv_proj_bytes(n_ctx, heads, d) == 0) return sta_fail(STA_E_UNSUP, "head dim %d unsupported", d);
+  if (M <= 0 || M > STA_MAX_KEYS) return sta_fail(STA_E_UNSUP, "M=%d keys unsupported (max %d)", M, STA_MAX_KEYS);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const dim3 grid(fwd_frags(ndt), n_ctx * heads);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(pack_kv_proj_kernel<__bf16>, grid, dim3(64), 0, st, (const __bf16*)k, (const __bf16*)v,
+                       (__bf16*)packed, M, C, heads, d, ndt);
+  else
+    hipLaunchKernelGGL(pack_kv_proj_kernel<_Float16>, grid, dim3(64), 0, st, (const _Float16*)k, (const _Float16*)v,
+                       (_Float16*)packed, M, C, heads, d, ndt);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_kv_proj launch: %s", hipGetErrorString(e));
+}
+
+int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                       const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
+                       int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!y || !packed_wq || !packed_kv || !out) return sta_fail(STA_E_ARG, "null pointer");
+  if (n_img < 1 || n_img > 65535) return sta_fail(STA_E_ARG, "n_img=%d", n_img);
+  if (int rc = check_proj_shape(N, C, heads, M, K)) return rc;
+  if (K > 0 && (!mask || !coef)) return sta_fail(STA_E_ARG, "mask/coef required when K > 0");
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  if ((size_t)2 * N * C * 2 >= 0xfffffff0ull) return sta_fail(STA_E_UNSUP, "one image of activations must stay below 4 GiB");
+  PParams p{};
+  p.y = y; p.wq = (const char*)packed_wq; p.kv = (const char*)packed_kv; p.mask = mask; p.coef = coef; p.out = out;
+  if (K == 0) {  // unconditional prologue loads: readable (ignored) bytes
+    p.mask = (const uint8_t*)y;
+    p.coef = (const float*)y;
+  }
+  p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K; p.nkc = C / 32;
+  p.sl2e = scale * 1.4426950408889634f;
+  const int lds = proj_lds_bytes(C, heads, K);
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == STA_BF16 ? dispatch_proj<__bf16>(p, n_img, lds, st) : dispatch_proj<_Float16>(p, n_img, lds, st);
+}
+
+}  // extern "C"

@@ -30,29 +30,61 @@ mode = _ps.MODE
 class DCLIPLoss(torch.nn.Module):
     """1 - cos(CLIP(image), CLIP(text)) with the reference's two image front-ends:
     `forward_2` (global): x7 nearest upsample then 16x16 average pool -> 224^2 for a 512^2 image (:36-44);
-    `forward_3` (local crop): bilinear resize to 224^2 (:28-35).
-    The CLIP model is third-party (OpenAI CLIP ViT-B/32, unpinned in the reference) and must be
-    supplied: any object with `encode_image(img[1,3,224,224])` and `encode_text(str)`."""
+    `forward_3` (local crop): bilinear resize to 224^2 (:28-35, torchvision `Resize((224, 224))`).
+    The CLIP model is third-party (OpenAI CLIP ViT-B/32, unpinned in the reference) and must be supplied: any
+    object with `encode_image(img[1,3,224,224])` and `encode_text(tokens)`. `tokenize` is the reference's
+    `clip.tokenize` (:31,:38): a callable list[str] -> token tensor; None hands the raw string to `encode_text`
+    (stand-in models). See `load_clip_model` for how the entry points obtain both."""
 
-    def __init__(self, clip_model=None):
+    def __init__(self, clip_model=None, tokenize=None):
         super().__init__()
         if clip_model is None:
             raise RuntimeError("DCLIPLoss needs a CLIP model (encode_image/encode_text); none is bundled. "
                                "Pass loss_model=... to PLMSSampler, or opt_epochs=0 for fixed weights.")
         self.model = clip_model
+        self.tokenize = tokenize if tokenize is not None else getattr(clip_model, "tokenize", None)
         self.upsample = torch.nn.Upsample(scale_factor=7)
         self.avg_pool = torch.nn.AvgPool2d(kernel_size=16)
 
+    def _text(self, text, device):
+        if self.tokenize is None:
+            return text
+        return self.tokenize([text]).to(device)                      # :31, :38
+
     def _loss(self, image224, text):
-        fi, ft = self.model.encode_image(image224), self.model.encode_text(text)
+        fi, ft = self.model.encode_image(image224), self.model.encode_text(self._text(text, image224.device))
         return 1 - torch.nn.functional.cosine_similarity(fi, ft)
 
     def forward_2(self, image, text):
         return self._loss(self.avg_pool(self.upsample(image.unsqueeze(0))), text)
 
     def forward_3(self, image, text):
+        # torchvision Resize on a tensor = bilinear, align_corners=False, antialiased when shrinking
         img = torch.nn.functional.interpolate(image.unsqueeze(0), size=(224, 224), mode="bilinear", antialias=True)
         return self._loss(img, text)
+
+
+def load_clip_model(spec=None, device="cuda"):
+    """(model, tokenize) for the fidelity loss.
+      spec None           the reference's own call: `clip.load("ViT-B/32")` + `clip.tokenize` (plms.py:24,31) — needs the
+                          OpenAI `clip` package and its weights on disk;
+      "module:callable"   import `module`, call `callable(device)` -> model or (model, tokenize);
+      path to a .pt file  `clip.load(path)`.
+    Raises with the reason when nothing can be loaded — callers do this BEFORE sampling (a trajectory is 51 UNet
+    calls; the reference would fail at import time, plms.py:11)."""
+    import importlib
+    if spec and ":" in spec and not os.path.exists(spec):
+        mod, fn = spec.split(":", 1)
+        got = getattr(importlib.import_module(mod), fn)(device)
+        return got if isinstance(got, tuple) else (got, getattr(got, "tokenize", None))
+    try:
+        clip = importlib.import_module("clip")
+    except ImportError as e:
+        raise RuntimeError("the fidelity loss needs a CLIP model: the OpenAI `clip` package is not installed; pass "
+                           "--clip module:callable (returns an object with encode_image/encode_text, optionally a "
+                           "tokenizer), or --opt_epochs 0 for fixed blend weights") from e
+    model, _ = clip.load(spec or "ViT-B/32", device=device)
+    return model, clip.tokenize
 
 
 def object_crop_box(centre, height, width, half=0.2):
@@ -171,6 +203,8 @@ class PLMSSampler(object):
         W = torch.full((b, K, S), self.weight_init / K if K else 0.0, device=device, dtype=torch.float32)   # :204-209
         W.requires_grad_(self.opt_epochs > 0 and K > 0)
         optimizer = torch.optim.Adam([W], lr=self.lr) if W.requires_grad else None
+        if W.requires_grad and self.opt_epochs > 1 and self.clip_loss_model is None:      # before the first trajectory, not after it
+            raise RuntimeError("opt_epochs > 0 needs a loss_model (see DCLIPLoss / load_clip_model); use opt_epochs=0 for fixed weights")
 
         epochs = max(self.opt_epochs, 1)
         result = {}

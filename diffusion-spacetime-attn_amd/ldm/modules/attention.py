@@ -108,11 +108,12 @@ class _PromptCache:
     """What a block keeps per prompt for one (N, K) shape: the packed K/V image of the K+2 contexts
     and the disc masks. Buffers are allocated once per shape and refilled in place for later prompts,
     so a captured hipGraph that holds their addresses stays valid across prompts."""
-    __slots__ = ("version", "packed", "mask", "centres")
+    __slots__ = ("version", "packed", "packed_proj", "mask", "centres")
 
     def __init__(self):
         self.version = -1
         self.packed = None
+        self.packed_proj = None      # forward-only image for the projection-fused kernel (None: shape not taken)
         self.mask = None
         self.centres = None
 
@@ -129,6 +130,8 @@ class BasicTransformerBlock(nn.Module):
         self.checkpoint = checkpoint
         self._caches = {}            # (N, K) -> _PromptCache
         self._last_n = None
+        self.keep_maps = False       # parity hook: keep the kernel's [K+2, heads, N, 77] attention maps of the last call
+        self.last_maps = None
 
     # -- per-prompt state (reference: the `time == 981` branch, attention.py:240-263) ---------------
     def _stale(self, cache, centres, time):
@@ -176,6 +179,10 @@ class BasicTransformerBlock(nn.Module):
             k = self.attn2.to_k(ctxs)
             v = self.attn2.to_v(ctxs)
             cache.packed = _ops.pack_kv(k, v, self.attn2.heads, out=cache.packed, n_img=n_img)
+            if k.is_cuda and _ops.proj_supported(k.shape[2], self.attn2.heads, k.shape[1], K, N=n, n_img=n_img):
+                cache.packed_proj = _ops.pack_kv_proj(k, v, self.attn2.heads, out=cache.packed_proj, n_img=n_img)
+            else:
+                cache.packed_proj = None
             if K:
                 m = torch.stack([_ops.disc_mask_bits(c, dim) for c in centres]).to(context.device)   # [I, N]
                 if cache.mask is None:
@@ -210,16 +217,38 @@ class BasicTransformerBlock(nn.Module):
             s, y = _fused.add_layernorm(x, None, in_bias, n1.weight, n1.bias, n1.eps, store_sum=in_bias is not None)
             x = x if s is None else s
             x, y = _fused.add_layernorm(x, self.attn1(y), None, n2.weight, n2.bias, n2.eps)
-            blended = _ops.xattn_blend(self.attn2.to_q(y), c, cache.packed, cache.mask, self.attn2.scale)
+            if cache.packed_proj is not None and not self.keep_maps:
+                # to_q runs INSIDE the attention kernel: no [2I, N, C] query round trip through HBM
+                blended = _ops.xattn_forward_proj(y, self._wq_fragments(), cache.packed_proj, cache.mask, c, self.attn2.scale)
+            else:
+                q = self.attn2.to_q(y)
+                self._keep_maps(q, c, cache)
+                blended = _ops.xattn_blend(q, c, cache.packed, cache.mask, self.attn2.scale)
             x, y = _fused.add_layernorm(x, self.attn2.to_out(blended), None, n3.weight, n3.bias, n3.eps)
             return self.ff(y) + x
         if in_bias is not None:
             x = x + in_bias
         x = self.attn1(self.norm1(x)) + x
         q = self.attn2.to_q(self.norm2(x))
+        self._keep_maps(q, c, cache)
         blended = _ops.xattn_blend(q, c, cache.packed, cache.mask, self.attn2.scale)
         x = self.attn2.to_out(blended) + x
         return self.ff(self.norm3(x)) + x
+
+    def _wq_fragments(self):
+        """to_q.weight of attn2 in MFMA operand order, repacked only when the weight tensor changes."""
+        w = self.attn2.to_q.weight
+        key = (w.data_ptr(), w._version, w.dtype)
+        if getattr(self, "_wq_key", None) != key:
+            self._wq_frag, self._wq_key = _ops.pack_wq(w, self.attn2.heads), key
+        return self._wq_frag
+
+    def _keep_maps(self, q, coef, cache):
+        """Parity hook (off by default): the per-step attention maps are a local of the reference's forward
+        (attention.py:194); the kernel can write them out ([K+2, heads, N, 77] fp32) for the tests that pin them."""
+        if self.keep_maps:
+            with torch.no_grad():
+                _, self.last_maps = _ops.xattn_forward(q.detach(), cache.packed, cache.mask, coef, self.attn2.scale, want_maps=True)
 
 
 class SpatialTransformer(nn.Module):

@@ -74,7 +74,10 @@ class _Recompute(torch.autograd.Function):
         ctx.fn = fn
         ctx.inputs = list(args[:n_inputs])
         ctx.params = list(args[n_inputs:])
-        with torch.no_grad():
+        from sta import fused as _fused
+        # same op chain as the re-run in backward (eager ops + the differentiable fused cross-attention): the
+        # inference-only kernels round differently, and the gradient must belong to the activations of THIS forward
+        with torch.no_grad(), _fused.held():
             return fn(*ctx.inputs)
 
     @staticmethod

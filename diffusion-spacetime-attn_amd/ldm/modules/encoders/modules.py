@@ -36,17 +36,36 @@ class SyntheticTextEmbedder(nn.Module):
 
 
 class FrozenCLIPEmbedder(nn.Module):
-    """HF CLIP text transformer, frozen; output = last_hidden_state for 77 padded tokens."""
+    """HF CLIP text transformer, frozen; output = last_hidden_state for 77 padded tokens
+    (reference ldm/modules/encoders/modules.py:137-162).
 
-    def __init__(self, version="openai/clip-vit-large-patch14", device="cuda", max_length=77):
+    `from_config=True` builds the ViT-L/14 text tower from its architecture constants WITHOUT weights (they
+    then come from the `cond_stage_model.transformer.*` keys of the SD-v1-4 checkpoint, which is how
+    sta.pipeline.build_sd_v1 uses it); otherwise the weights are read from the local HF cache. The tokenizer's
+    vocabulary files must be on disk either way (`tokenizer_path` or the HF cache): there is no network here, and a
+    missing tokenizer raises instead of conditioning the UNet on something else."""
+
+    VIT_L14_TEXT = dict(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                        num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu",
+                        layer_norm_eps=1e-5, projection_dim=768)
+
+    def __init__(self, version="openai/clip-vit-large-patch14", device="cuda", max_length=77, from_config=False,
+                 tokenizer_path=None):
         super().__init__()
-        from transformers import CLIPTextModel, CLIPTokenizer
+        from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
         try:
-            self.tokenizer = CLIPTokenizer.from_pretrained(version, local_files_only=True)
-            self.transformer = CLIPTextModel.from_pretrained(version, local_files_only=True)
-        except Exception as e:   # no weights on disk and no network
-            raise RuntimeError("CLIP text encoder weights for %s are not available locally; use "
-                               "SyntheticTextEmbedder or provide the HF cache" % version) from e
+            self.tokenizer = CLIPTokenizer.from_pretrained(tokenizer_path or version, local_files_only=True)
+        except Exception as e:   # no vocabulary on disk and no network
+            raise RuntimeError("CLIP tokenizer files for %s are not available locally (pass tokenizer_path= / "
+                               "--clip_tokenizer, or provide the HF cache); refusing to fall back to synthetic text "
+                               "embeddings for a real checkpoint" % (tokenizer_path or version)) from e
+        if from_config:
+            self.transformer = CLIPTextModel(CLIPTextConfig(**self.VIT_L14_TEXT))
+        else:
+            try:
+                self.transformer = CLIPTextModel.from_pretrained(version, local_files_only=True)
+            except Exception as e:
+                raise RuntimeError("CLIP text encoder weights for %s are not available locally" % version) from e
         self.device_name, self.max_length = device, max_length
         self.eval()
         for p in self.parameters():

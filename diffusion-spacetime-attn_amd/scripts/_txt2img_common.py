@@ -4,7 +4,8 @@ in the dataset they read (scripts/txt2img-gpt.py vs -mscoco.py vs -vsr.py: lines
 Kept from the reference CLI (txt2img-gpt.py:105-247): --plms --ddim_steps --H --W --C --f --n_samples --scale
 --ddim_eta --fixed_code --config --ckpt --precision --outdir --seed --process_id (+ the flags it parses and
 ignores, accepted for compatibility). Added: --layout (JSON replacing the layout-predictor call),
---dataset (path override), --opt_epochs (0 = fixed weights), --limit/--start, --dtype, --synthetic.
+--dataset (path override), --opt_epochs (0 = fixed weights), --limit/--start, --dtype, --synthetic,
+--clip (the fidelity-loss model; checked BEFORE sampling), --clip_tokenizer (vocabulary of the text encoder).
 With torch.distributed.run the prompts are sharded round-robin over the ranks (one GPU each).
 """
 import argparse
@@ -52,7 +53,13 @@ def build_parser(default_dataset):
     p.add_argument("--opt_epochs", type=int, default=3, help="weight-optimisation epochs (reference: 3; 0 = fixed weights)")
     p.add_argument("--start", type=int, default=0)
     p.add_argument("--limit", type=int, default=500)
-    p.add_argument("--dtype", type=str, choices=["bf16", "fp16"], default="bf16")
+    p.add_argument("--dtype", type=str, choices=["bf16", "fp16"], default="fp16",
+                   help="fp16 = the reference's autocast type and the one within 1e-3 on the attention maps (DESIGN.md section 2)")
+    p.add_argument("--clip", type=str, default=None,
+                   help="fidelity-loss model for --opt_epochs > 0: 'module:callable' (called with the device, returns a model with "
+                        "encode_image/encode_text or (model, tokenize)), a CLIP .pt path, or 'synthetic' (frozen stand-in, for "
+                        "timing the gradient path). Default: clip.load('ViT-B/32') as the reference (plms.py:24)")
+    p.add_argument("--clip_tokenizer", type=str, default=None, help="directory with the CLIP tokenizer files (with --ckpt)")
     p.add_argument("--synthetic", action="store_true", help="synthetic weights/text embeddings when no checkpoint is available")
     p.add_argument("--batch_prompts", type=int, default=1,
                    help="sample up to this many prompts with the same object count together (one CFG batch of 2I per UNet call)")
@@ -82,12 +89,24 @@ def run(kind, default_dataset):
     ckpt = opt.ckpt if (os.path.exists(opt.ckpt) and not opt.synthetic) else None
     if ckpt is None and not opt.synthetic:
         raise SystemExit("checkpoint %s not found (pass --synthetic to run with synthetic weights)" % opt.ckpt)
-    model = build_sd_v1(dev, dtype, ckpt=ckpt if rank == 0 else None, init_weights=(rank == 0), use_checkpoint=opt.opt_epochs > 1)
+    loss_model = None
+    if opt.opt_epochs > 0:        # fail here, not after the first 51-call trajectory
+        from ldm.models.diffusion.plms import DCLIPLoss, load_clip_model
+        if opt.clip == "synthetic":
+            from sta.synth import SyntheticCLIP
+            loss_model = DCLIPLoss(SyntheticCLIP().to(dev))
+        else:
+            try:
+                loss_model = DCLIPLoss(*load_clip_model(opt.clip, dev))
+            except Exception as e:
+                raise SystemExit("--opt_epochs %d: %s" % (opt.opt_epochs, e))
+    model = build_sd_v1(dev, dtype, ckpt=ckpt if rank == 0 else None, init_weights=(rank == 0), use_checkpoint=opt.opt_epochs > 1,
+                        clip_tokenizer=opt.clip_tokenizer, real_text_encoder=ckpt is not None)
     if opt.opt_epochs > 1 and torch.device(dev).type == "cuda" and opt.H * opt.W <= 512 * 512:
         from sta.pipeline import set_recompute
         set_recompute(model, "auto", max(opt.batch_prompts, 1))      # sized to 288 GB of HBM at 512x512; larger images keep the reference's policy
     parallel.broadcast_module_(model)                                   # one RCCL broadcast of the frozen weights
-    sampler = PLMSSampler(model, opt_epochs=opt.opt_epochs, loss_model=None)
+    sampler = PLMSSampler(model, opt_epochs=opt.opt_epochs, loss_model=loss_model)
     os.makedirs(opt.outdir, exist_ok=True)
 
     seed = 1                                                            # txt2img-gpt.py:304

@@ -2,14 +2,30 @@
 UNet trunk around the cross-attention path (ResBlock, SpatialTransformer, BasicTransformerBlock, GEGLU).
 
 They are inference kernels: `usable()` is False whenever autograd is recording, and the modules then run the
-reference's eager sequence (which is also what the CPU tests exercise). `STA_FUSED=0` switches them off."""
-import os
+reference's eager sequence (which is also what the CPU tests exercise). `fused.ENABLED = False` (tools/, tests) switches
+them off."""
 
 import torch
 
 from . import lib
 
 _DT = {torch.bfloat16: lib.STA_BF16, torch.float16: lib.STA_F16}
+ENABLED = True          # A/B switch for tools/ and tests; nothing reads the environment
+_hold = 0               # > 0 inside `held()`: the forward of a block that will be re-run under autograd
+
+
+class held:
+    """Context in which the inference-only kernels (this module, HIP self-attention) are not used although
+    autograd is off: the no-grad forward of a recomputed block must run the SAME op chain as its re-run in
+    backward, otherwise gradients are taken at activations the forward never produced (util._Recompute)."""
+
+    def __enter__(self):
+        global _hold
+        _hold += 1
+
+    def __exit__(self, *exc):
+        global _hold
+        _hold -= 1
 
 
 def is_nhwc(x):
@@ -20,7 +36,7 @@ def is_nhwc(x):
 def usable(x):
     """Fused trunk kernels apply to dense (NCHW- or NHWC-contiguous) 16-bit CUDA activations outside autograd."""
     return (x.is_cuda and x.dtype in _DT and not torch.is_grad_enabled() and (x.is_contiguous() or is_nhwc(x))
-            and os.environ.get("STA_FUSED", "1") != "0")
+            and ENABLED and not _hold)
 
 
 def _stream():

@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, "sta_xattn.hip"), os.path.join(CSRC, "sta_selfattn.hip"), os.path.join(CSRC, "sta_unet.hip")]
+SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_selfattn.hip", "sta_unet.hip")]
 
 # Self-attention keeps its MFMA accumulators in VGPRs: hipcc otherwise parks them in AGPRs and brackets the
 # online-softmax rescale with v_accvgpr_read/write pairs (120 extra VALU instructions per key block in a kernel
@@ -26,9 +26,11 @@ SOURCES = [os.path.join(CSRC, "sta_xattn.hip"), os.path.join(CSRC, "sta_selfattn
 # it, masks are finite sentinels): fmaxf on MFMA outputs then compiles to bare v_max3 without quieting moves.
 # (Self-attention likewise: 1387 -> 1325 us at B=32, N=4096, d=40.)
 PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
-                    "sta_xattn.hip": ["-ffinite-math-only"]}
+                    "sta_xattn.hip": ["-ffinite-math-only"], "sta_xattn_proj.hip": ["-ffinite-math-only"]}
 
 STA_BF16, STA_F16 = 0, 1
+OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_FUSE_Q = range(7)
+FWD_STAGED, FWD_SPLIT = 1, 2
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
 
 # every symbol include/sta_xattn.h and include/sta_unet.h declare: (restype, argtypes)
@@ -36,9 +38,16 @@ _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_s
 SYMBOLS = {
     "sta_version": (_i, []),
     "sta_last_error": (ctypes.c_char_p, []),
+    "sta_set_option": (_i, [_i, _i]),
     "sta_xattn_packed_kv_bytes": (_sz, [_i, _i, _i]),
     "sta_xattn_pack_kv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sta_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_xattn_fwd_proj_supported": (_i, [_i, _i, _i, _i]),
+    "sta_xattn_packed_wq_bytes": (_sz, [_i, _i]),
+    "sta_xattn_pack_wq": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sta_xattn_packed_kv_proj_bytes": (_sz, [_i, _i, _i]),
+    "sta_xattn_pack_kv_proj": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sta_xattn_fwd_proj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
@@ -60,7 +69,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h")]
+    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
@@ -120,6 +129,11 @@ def load():
         fn.restype, fn.argtypes = res, args
     _lib = lib
     return lib
+
+
+def set_option(key, value):
+    """sta_set_option: override a launch heuristic (tests / tools only; 0 = automatic)."""
+    check(load().sta_set_option(int(key), int(value)), "sta_set_option")
 
 
 def last_error():

@@ -125,6 +125,8 @@ def _check_inputs(q, packed, mask, coef):
     return I, N, C, K
 
 
+SELFATTN_ENABLED = True      # A/B switch for tools/ (False: attn1 through PyTorch SDPA); nothing reads the environment
+
 # bench.py's roofline leg: when set to a list, every forward launch is bracketed by its own HIP-event pair
 # on the launch stream and (e0, e1, n_img, N, C, K) is appended — in situ, inside real UNet calls.
 EVENT_LOG = None
@@ -147,7 +149,7 @@ def xattn_forward(q, packed, mask, coef, scale, want_maps=False):
                                _stream(q)), "sta_xattn_fwd")
     if EVENT_LOG is not None:
         e1.record()
-        EVENT_LOG.append((e0, e1, I, N, C, K))
+        EVENT_LOG.append((e0, e1, I, N, C, K, "attn"))
     if maps is not None and I == 1:
         maps = maps[0]
     return out, maps
@@ -167,6 +169,79 @@ def xattn_backward(q, packed, mask, coef, dout, scale):
                                dq.data_ptr(), _ptr(dcoef) if K else 0, ws.data_ptr(), I, N, C, packed.heads,
                                packed.M, K, float(scale), _dtype_code(q), _stream(q)), "sta_xattn_bwd")
     return dq, dcoef
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward with the query projection inside (sta_xattn_fwd_proj; inference only)
+# ---------------------------------------------------------------------------------------------------
+PROJ_MIN_WORKGROUPS = 256     # 128-pixel workgroup tiles x heads x images from which the projection-fused kernel is used
+
+
+def proj_supported(C, heads, M, K, N=None, n_img=1):
+    """Shapes sta_xattn_fwd_proj takes (Wq slice + all contexts resident in LDS) and, when N is given, launches
+    large enough that its one-workgroup-per-CU structure fills the chip."""
+    if not _lib.load().sta_xattn_fwd_proj_supported(C, heads, M, K):
+        return False
+    return N is None or ((N + 127) // 128) * heads * n_img >= PROJ_MIN_WORKGROUPS
+
+
+def pack_wq(weight, heads):
+    """to_q.weight [C, C] -> per-head MFMA fragment image (uint8 tensor); once per model."""
+    C = weight.shape[0]
+    if weight.shape != (C, C) or not weight.is_cuda:
+        raise ValueError("to_q.weight must be a square CUDA matrix, got %s" % (tuple(weight.shape),))
+    L = _lib.load()
+    nbytes = L.sta_xattn_packed_wq_bytes(C, heads)
+    if nbytes == 0:
+        raise ValueError("unsupported projection shape C=%d heads=%d" % (C, heads))
+    w = weight.detach().contiguous()
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(L.sta_xattn_pack_wq(w.data_ptr(), buf.data_ptr(), C, heads, _dtype_code(w), _stream(w)), "sta_xattn_pack_wq")
+    return buf
+
+
+def pack_kv_proj(k, v, heads, out=None, n_img=1):
+    """Like pack_kv, for sta_xattn_fwd_proj: forward-only image, K fragments in projected-query order."""
+    if k.shape != v.shape or k.dim() != 3 or not k.is_cuda:
+        raise ValueError("k and v must both be CUDA tensors [n_img * n_ctx, M, C]")
+    total, M, C = k.shape
+    if C % heads or n_img < 1 or total % n_img:
+        raise ValueError("bad shapes: %s, heads=%d, n_img=%d" % (tuple(k.shape), heads, n_img))
+    n_ctx = total // n_img
+    L = _lib.load()
+    k, v = k.contiguous(), v.contiguous()
+    nbytes = L.sta_xattn_packed_kv_proj_bytes(total, heads, C // heads)
+    if nbytes == 0:
+        raise ValueError("unsupported head dim %d" % (C // heads))
+    if out is not None and (out.n_ctx, out.heads, out.M, out.C, out.dtype, out.n_img) == (n_ctx, heads, M, C, k.dtype, n_img) \
+            and out.buf.device == k.device and out.buf.numel() == nbytes:
+        buf = out.buf
+    else:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=k.device)
+    _lib.check(L.sta_xattn_pack_kv_proj(k.data_ptr(), v.data_ptr(), buf.data_ptr(), total, M, C, heads,
+                                        _dtype_code(k), _stream(k)), "sta_xattn_pack_kv_proj")
+    return PackedKV(buf, n_ctx, heads, M, C, k.dtype, n_img)
+
+
+def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale):
+    """y [2I, N, C] = norm2(hidden) -> blended pre-projection output [2I, N, C]; the query projection happens inside
+    the attention kernel (no autograd). `packed` comes from pack_kv_proj, `wq_packed` from pack_wq."""
+    I, N, C, K = _check_inputs(y, packed, mask, coef)
+    L = _lib.load()
+    y = y.contiguous()
+    coef32 = coef.detach().to(torch.float32).contiguous() if K else None
+    maskc = mask.contiguous() if K else None
+    out = torch.empty_like(y)
+    if EVENT_LOG is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.check(L.sta_xattn_fwd_proj(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
+                                    out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y),
+                                    _stream(y)), "sta_xattn_fwd_proj")
+    if EVENT_LOG is not None:
+        e1.record()
+        EVENT_LOG.append((e0, e1, I, N, C, K, "proj"))
+    return out
 
 
 class _XAttnBlend(torch.autograd.Function):
@@ -224,8 +299,8 @@ def self_attention(q, k, vt, heads, scale):
 
 def self_attention_supported(x, heads):
     """Shapes the HIP self-attention kernel takes (the rest goes to PyTorch's SDPA)."""
-    import os
-    if os.environ.get("STA_SELFATTN", "1") == "0":      # tuning/debug knob: fall back to PyTorch SDPA for attn1
+    from . import fused as _fused
+    if not SELFATTN_ENABLED or _fused._hold:
         return False
     B, N, C = x.shape
     d = C // heads

@@ -13,14 +13,23 @@ import torch
 from ldm.models.autoencoder import AutoencoderKL
 from ldm.models.diffusion.ddpm import SD_V1_UNET, LatentDiffusion
 from ldm.modules.diffusionmodules.openaimodel import UNetModel
-from ldm.modules.encoders.modules import SyntheticTextEmbedder
+from ldm.modules.encoders.modules import FrozenCLIPEmbedder, SyntheticTextEmbedder
 from sta import synth
 
 DEFAULT_CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]
 
 
-def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae=True, use_checkpoint=False,
-                init_weights=True, unet_overrides=None, channels_last=False):
+# prefixes of the checkpoint keys the sampling path consumes: a real checkpoint must provide every one of them
+_REQUIRED_PREFIXES = ("model.diffusion_model.", "first_stage_model.", "cond_stage_model.")
+
+
+def build_sd_v1(device="cuda", dtype=torch.float16, ckpt=None, seed=0, with_vae=True, use_checkpoint=False,
+                init_weights=True, unet_overrides=None, channels_last=False, clip_tokenizer=None, real_text_encoder=None):
+    """`ckpt` given: the SD-v1-4 state_dict loads by name INCLUDING the CLIP text encoder
+    (`cond_stage_model.transformer.*` -> FrozenCLIPEmbedder, reference v1-inference.yaml:67-68); a key of the
+    UNet / VAE decoder / text encoder that the checkpoint lacks raises (the tensors are created uninitialised).
+    `ckpt=None`: synthetic weights and the deterministic text stand-in (benchmarks, tests).
+    `real_text_encoder`: ranks that receive the weights by broadcast build the real (empty) encoder too."""
     cfg = dict(SD_V1_UNET, use_checkpoint=use_checkpoint)
     cfg.update(unet_overrides or {})
     # parameters are created on the meta device (no default init of 0.9 G values) and materialised
@@ -31,7 +40,12 @@ def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae
     unet = unet.to(dtype).to_empty(device=device)
     if vae is not None:
         vae = vae.to(dtype).to_empty(device=device)
-    text = SyntheticTextEmbedder().to(device)
+    if real_text_encoder is None:
+        real_text_encoder = ckpt is not None
+    if real_text_encoder:
+        text = FrozenCLIPEmbedder(device=device, from_config=True, tokenizer_path=clip_tokenizer).to(device)
+    else:
+        text = SyntheticTextEmbedder().to(device)
     model = LatentDiffusion(unet_config=unet, first_stage_config=vae, cond_stage_config=text).to(device)
     if channels_last and torch.device(device).type == "cuda":
         # NHWC activations and weights for the UNet trunk: MIOpen's bf16 convolutions are NHWC kernels (the NCHW path
@@ -53,7 +67,11 @@ def build_sd_v1(device="cuda", dtype=torch.bfloat16, ckpt=None, seed=0, with_vae
         sd = torch.load(ckpt, map_location="cpu")
         sd = sd.get("state_dict", sd)
         missing, unexpected = model.load_state_dict(sd, strict=False)
-        print("loaded %s: %d missing, %d unexpected keys" % (ckpt, len(missing), len(unexpected)))
+        # parameters were materialised uninitialised (to_empty): a key the checkpoint lacks would stay HBM garbage
+        bad = [k for k in missing if k.startswith(_REQUIRED_PREFIXES)]
+        if bad:
+            raise RuntimeError("%s lacks %d tensors of the sampling path (first: %s)" % (ckpt, len(bad), ", ".join(bad[:5])))
+        print("loaded %s: %d unexpected keys ignored (encoder / EMA / loss buffers)" % (ckpt, len(unexpected)))
     elif init_weights:
         if torch.device(device).type == "cuda":
             synth.device_fill_(model.model, seed)

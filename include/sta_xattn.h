@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STA_VERSION 0x000100 /* 0.1.0 */
+#define STA_VERSION 0x000200 /* 0.2.0 */
 
 enum { STA_BF16 = 0, STA_F16 = 1 };
 
@@ -51,6 +51,24 @@ int sta_version(void);
 
 /* Text of the last error on the calling thread ("" if none). Never NULL. */
 const char* sta_last_error(void);
+
+/*
+ * Override of the launch heuristics (which forward kernel, workgroup shape, pixel tiles per workgroup, block
+ * map). Nothing in the reference corresponds to it: it exists so that tests reach every kernel variant at
+ * small sizes and tools/ can A/B variants; the product never calls it and the library reads no environment
+ * variables. Process-global, takes effect at the next launch; value 0 restores the automatic choice.
+ */
+enum {
+  STA_OPT_FWD_KERNEL = 0,   /* 1: LDS-resident ("staged") kernel, 2: wave-per-context ("split") kernel */
+  STA_OPT_STAGED_TILES = 1, /* pixel tiles a staged workgroup walks (1..12) */
+  STA_OPT_STAGED_WAVES = 2, /* waves per staged workgroup: 4, 8 or 12 */
+  STA_OPT_STAGED_QT = 3,    /* 2: two 16-pixel sub-tiles per wave */
+  STA_OPT_HEAD_MAJOR = 4,   /* 1: block b -> head b % heads; 2: XCD-contiguous tile ranges */
+  STA_OPT_SPLIT_QT = 5,     /* sub-tiles per wave of the split kernel: 1, 2, 4 */
+  STA_OPT_FUSE_Q = 6,       /* sta_xattn_fwd_proj: 1 = projection inside the attention kernel, 2 = separate pass */
+  STA_OPT_COUNT = 8
+};
+int sta_set_option(int key, int value);
 
 /*
  * Bytes of the packed K/V image for n_ctx contexts, `heads` heads of dim d (0 if unsupported).
@@ -98,6 +116,31 @@ int sta_xattn_pack_kv(const void* k, const void* v, void* packed,
 int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const float* coef,
                   void* out, float* maps,
                   int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+
+/*
+ * Forward with the QUERY PROJECTION inside: sta_xattn_fwd plus the GEMM in front of it,
+ *   q = self.to_q(x)            attention.py:178  (x = norm2(hidden); the reference recomputes it K+1 times)
+ * so the [2][N][C] query tensor is never written to or read from HBM. Inference only (no backward: the tracked
+ * epochs keep q for sta_xattn_bwd). Operands are packed once:
+ *   sta_xattn_pack_wq       to_q.weight [C][C] (bias-free Linear, attention.py:164) -> per-head MFMA fragments;
+ *                           once per model, sta_xattn_packed_wq_bytes(C, heads) bytes
+ *   sta_xattn_pack_kv_proj  like sta_xattn_pack_kv, forward-only image whose K fragments carry the head dim in
+ *                           projected-query order; once per prompt per block,
+ *                           sta_xattn_packed_kv_proj_bytes(n_ctx, heads, d) bytes
+ *   sta_xattn_fwd_proj      y: [n_img][2][N][C] = norm2(hidden); everything else as sta_xattn_fwd (no maps output)
+ * Supported when sta_xattn_fwd_proj_supported(C, heads, M, K) != 0: d <= 96, C % 160 == 0, 64 < M <= 80 and the head's
+ * Wq slice plus all K+2 contexts fit the 160 KiB LDS of a CU (SD-v1 level 0, C = 320: K <= 4). Other shapes take
+ * the GEMM + sta_xattn_fwd.
+ */
+int sta_xattn_fwd_proj_supported(int C, int heads, int M, int K);
+size_t sta_xattn_packed_wq_bytes(int C, int heads);
+int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype, void* stream);
+size_t sta_xattn_packed_kv_proj_bytes(int n_ctx, int heads, int d);
+int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed,
+                           int n_ctx, int M, int C, int heads, int dtype, void* stream);
+int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                       const float* coef, void* out,
+                       int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
 
 /* Bytes of fp32 workspace sta_xattn_bwd needs for the given shape (deterministic dcoef reduce). */
 size_t sta_xattn_bwd_workspace_bytes(int n_img, int N, int heads, int K);

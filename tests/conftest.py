@@ -24,3 +24,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True)
+def _reset_launch_overrides():
+    """Tests may force kernel variants through sta_set_option; never let one leak into the next test."""
+    yield
+    from sta import lib
+    if lib._lib is not None:
+        for key in range(7):
+            lib._lib.sta_set_option(key, 0)

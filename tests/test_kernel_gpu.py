@@ -198,15 +198,16 @@ def test_batched_images_match_oracle_per_image(N, C, heads, K):
     (4096, 384, 8, 6, 4, 3),       # 8 contexts do not fit LDS together: groups are re-staged for every tile
     (256, 1280, 8, 2, 8, None),    # d = 160: two LDS groups per tile
 ])
-def test_multi_tile_workgroups(N, C, heads, K, I, iters, monkeypatch):
+def test_multi_tile_workgroups(N, C, heads, K, I, iters):
     """Throughput-regime launches (several images, workgroups that keep one head's fragments in LDS and walk
     several strided pixel tiles): every image equals (a) the same image launched alone through the
     wave-per-context kernel and (b), for the first and last image, the CPU oracle."""
     from sta import ops
     dtype, dev = torch.bfloat16, "cuda"
+    from sta import lib
     if iters is not None:
-        monkeypatch.setenv("STA_FWD_STAGED_ITERS", str(iters))
-        monkeypatch.setenv("STA_FWD_KERNEL", "staged")
+        lib.set_option(lib.OPT_STAGED_TILES, iters)
+        lib.set_option(lib.OPT_FWD_KERNEL, lib.FWD_STAGED)
     cases = [_case(N, C, heads, K, dtype, seed=40 + i) for i in range(I)]
     q = torch.cat([c[0] for c in cases]).to(dev); k = torch.cat([c[1] for c in cases]).to(dev); v = torch.cat([c[2] for c in cases]).to(dev)
     mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
@@ -214,8 +215,8 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters, monkeypatch):
     scale = (C // heads) ** -0.5
     out, _ = ops.xattn_forward(q, ops.pack_kv(k, v, heads, n_img=I), mb, coef, scale)
     torch.cuda.synchronize()
-    monkeypatch.delenv("STA_FWD_STAGED_ITERS", raising=False)
-    monkeypatch.setenv("STA_FWD_KERNEL", "split")
+    lib.set_option(lib.OPT_STAGED_TILES, 0)
+    lib.set_option(lib.OPT_FWD_KERNEL, lib.FWD_SPLIT)
     eps = 2.0 ** -8
     for i in range(I):
         qi, ki, vi, mi, ci = cases[i]
@@ -226,6 +227,7 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters, monkeypatch):
             ref = orc.fused_xattn(qi.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
             err = (a.cpu().double() - ref).abs()
             assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
+    lib.set_option(lib.OPT_FWD_KERNEL, 0)
 
 
 @pytest.mark.parametrize("B,N,C,heads", [(2, 4096, 320, 8), (4, 1024, 640, 8), (2, 144, 640, 8), (2, 576, 192, 4),
@@ -293,7 +295,7 @@ def test_autograd_function_roundtrip():
 def test_error_convention():
     from sta import lib, ops
     L = lib.load()
-    assert L.sta_version() == 0x000100
+    assert L.sta_version() == 0x000200
     assert L.sta_xattn_packed_kv_bytes(4, 8, 41) == 0          # d % 8 != 0
     x = torch.zeros(2, 16, 8 * 168, device="cuda", dtype=torch.bfloat16)
     rc = L.sta_xattn_fwd(x.data_ptr(), x.data_ptr(), 0, 0, x.data_ptr(), 0, 1, 16, 8 * 168, 8, 77, 0, 1.0, 0, 0)
@@ -301,3 +303,70 @@ def test_error_convention():
     with pytest.raises(ValueError):
         ops.pack_kv(torch.zeros(2, 77, 8 * 168, device="cuda", dtype=torch.bfloat16),
                     torch.zeros(2, 77, 8 * 168, device="cuda", dtype=torch.bfloat16), 8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# forward with the query projection inside (sta_xattn_fwd_proj)
+# ---------------------------------------------------------------------------------------------------
+PROJ_SHAPES = [
+    # N, C, heads, K, images, forced tiles per workgroup (None = heuristic), waves per workgroup (0 = default)
+    (256, 320, 8, 2, 1, None, 0),      # level-0 head dim, two 128-pixel tiles
+    (4096, 320, 8, 2, 4, None, 0),     # BASELINE level 0, 4 prompts: 4 strided tiles per workgroup
+    (4096, 320, 8, 2, 16, None, 0),    # the bench launch: 16 prompts, 16 tiles per workgroup
+    (4096, 320, 8, 4, 2, None, 12),    # 4 objects (6 contexts + Wq = 144 KiB of LDS), 12-wave workgroups
+    (1000, 160, 4, 3, 2, 3, 4),        # ragged N, d = 40 with 4 heads, forced tile count, 4-wave workgroups
+    (1024, 320, 4, 1, 2, None, 0),     # d = 80: 50 KiB of Wq + 3 contexts
+    (576, 480, 8, 0, 1, None, 0),      # d = 60, no objects
+    (9216, 320, 8, 4, 1, None, 0),     # BASELINE configs[4] level 0 (768^2, 4 objects)
+]
+
+
+@pytest.mark.parametrize("N,C,heads,K,I,tiles,waves", PROJ_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, dtype):
+    """y -> to_q -> K+2 attentions -> blend in ONE kernel vs the oracle fed with q = round16(y Wq^T) (what the GEMM
+    in front of sta_xattn_fwd would have produced), and vs the unfused GPU path on the same inputs."""
+    from sta import lib, ops
+    dev = "cuda"
+    assert ops.proj_supported(C, heads, 77, K)
+    g = torch.Generator().manual_seed(N + C + K)
+    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype)
+    cases = [_case(N, C, heads, K, dtype, seed=70 + i) for i in range(I)]          # "q" of a case plays y here
+    y = torch.cat([c[0] for c in cases]).to(dev)
+    k = torch.cat([c[1] for c in cases]).to(dev)
+    v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    scale = (C // heads) ** -0.5
+    if tiles is not None:
+        lib.set_option(lib.OPT_STAGED_TILES, tiles)
+    if waves:
+        lib.set_option(lib.OPT_STAGED_WAVES, waves)
+    out = ops.xattn_forward_proj(y, ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I), mb, coef, scale)
+    torch.cuda.synchronize()
+    lib.set_option(lib.OPT_STAGED_TILES, 0)
+    lib.set_option(lib.OPT_STAGED_WAVES, 0)
+    q_gemm = torch.nn.functional.linear(y, wq.to(dev))
+    unfused, _ = ops.xattn_forward(q_gemm, ops.pack_kv(k, v, heads, n_img=I), mb, coef, scale)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    a, b = out.float(), unfused.float()
+    # same arithmetic up to the summation order of the projection (a q element may round the other way: 1 ulp of q)
+    assert ((a - b).abs() <= 4 * eps * (1.0 + b.abs())).all(), (a - b).abs().max().item()
+    for i in sorted({0, I - 1}):
+        yi, ki, vi, mi, ci = cases[i]
+        q16 = (yi.double() @ wq.double().t()).to(dtype)
+        ref = orc.fused_xattn(q16.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
+        err = (a[2 * i:2 * i + 2].cpu().double() - ref).abs()
+        assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
+
+
+def test_fwd_proj_rejects_what_it_cannot_hold():
+    """Level 1 of SD-v1 (C = 640: 100 KiB of Wq + 4 contexts of 30 KiB) does not fit one CU's LDS: the C-ABI says so
+    instead of launching, and the block then takes the GEMM + sta_xattn_fwd."""
+    from sta import lib, ops
+    assert not ops.proj_supported(640, 8, 77, 2)
+    assert not ops.proj_supported(320, 8, 77, 5)
+    L = lib.load()
+    y = torch.zeros(2, 64, 640, device="cuda", dtype=torch.float16)
+    rc = L.sta_xattn_fwd_proj(y.data_ptr(), y.data_ptr(), y.data_ptr(), 0, 0, y.data_ptr(), 1, 64, 640, 8, 77, 0, 1.0, lib.STA_F16, 0)
+    assert rc == -2 and "LDS" in lib.last_error()

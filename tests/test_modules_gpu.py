@@ -50,31 +50,59 @@ def test_block_vs_reference_golden(name, dtype):
         assert rel.max() < (0.05 if dtype == torch.bfloat16 else 0.01), (coef.grad, g["dcoef"])
 
 
-def test_block_attention_maps_within_1e3():
-    """north_star: per-step attention maps within 1e-3 of the CPU reference. The maps the kernel
-    computes from the block's 16-bit q/K are compared with the reference's fp32 maps at the stored pixels."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_block_projection_fused_path_vs_reference_golden(dtype, monkeypatch):
+    """The inference block with to_q INSIDE the attention kernel (sta_xattn_fwd_proj; normally taken from 256 workgroup
+    tiles per launch, forced here) against the reference's fp32 block output, same tolerance as the unfused block."""
     from ldm.modules.attention import BasicTransformerBlock
-    from sta import ops
-    for name, dtype, tol in (("d40", torch.float16, 1e-3), ("d160", torch.float16, 1e-3), ("d40", torch.bfloat16, 8e-3)):
-        g = _load("block_%s.npz" % name)
-        dim, C, heads, K, seed = (int(g[k]) for k in ("dim", "C", "heads", "K", "seed"))
-        x, context, local_ctx = gi.block_inputs(dim, C, K, seed, gi.load_uncond())
-        blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768, checkpoint=False)
-        seeded_fill_(blk, seed)
-        blk = blk.cuda()
-        with torch.no_grad():
-            xc = x.cuda()
-            x1 = blk.attn1(blk.norm1(xc)) + xc
-            q = blk.attn2.to_q(blk.norm2(x1)).to(dtype)
-            ctxs = torch.cat([context] + local_ctx).cuda()
-            k, v = blk.attn2.to_k(ctxs).to(dtype), blk.attn2.to_v(ctxs).to(dtype)
-            packed = ops.pack_kv(k, v, heads)
-            mask = ops.disc_mask_bits([tuple(c) for c in g["centres"]], dim).cuda()
-            _, maps = ops.xattn_forward(q, packed, mask, torch.from_numpy(g["coef"]).cuda(), blk.attn2.scale, want_maps=True)
-        pix = torch.from_numpy(g["map_pixels"]).cuda()
-        got = maps[:, :, pix, :].cpu().numpy()
-        err = np.abs(got - g["maps"]).max()
-        assert err < tol, (name, dtype, err)
+    from sta import ops, prompt_state
+    monkeypatch.setattr(ops, "PROJ_MIN_WORKGROUPS", 0)
+    g = _load("block_d40.npz")
+    dim, C, heads, K, seed = (int(g[k]) for k in ("dim", "C", "heads", "K", "seed"))
+    x, context, local_ctx = gi.block_inputs(dim, C, K, seed, gi.load_uncond())
+    blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768, checkpoint=False)
+    seeded_fill_(blk, seed)
+    blk = blk.to("cuda", dtype)
+    calls = []
+    real = ops.xattn_forward_proj
+    monkeypatch.setattr(ops, "xattn_forward_proj", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    prompt_state.begin_prompt([c.cuda() for c in local_ctx], first_timestep=981)
+    with torch.no_grad():
+        out = blk(x.cuda().to(dtype), context=context.cuda().to(dtype), time=torch.tensor(981),
+                  coef=torch.from_numpy(g["coef"]).cuda(), bboxs_curr=[list(c) for c in g["centres"]])
+    assert calls, "the projection-fused kernel was not taken"
+    ref = g["out"]
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = np.abs(out.float().cpu().numpy() - ref)
+    assert err.max() <= 8 * eps * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    assert err.mean() <= 4 * eps * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
+
+
+@pytest.mark.parametrize("name", ["d40", "d80", "d160", "d8k4"])
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 1e-3), (torch.bfloat16, 8e-3)])
+def test_block_attention_maps_vs_reference(name, dtype, tol):
+    """north_star: per-step attention maps within 1e-3 of the CPU reference — checked on the PRODUCT block run end to
+    end in 16 bit (input, LayerNorms, attn1, to_q/to_k GEMMs, the kernel's softmax), against the reference's fp32 maps.
+    fp16 — the bench dtype and the reference's own autocast type — meets 1e-3 (measured 3.3e-4 .. 6.7e-4 on the four
+    goldens). bf16 cannot: rounding ONLY the block input to 8 mantissa bits already moves the maps by 1.6e-3 .. 1.9e-3
+    (CPU experiment), the full bf16 block measures 3.7e-3 .. 5.4e-3; its stated bound is 8e-3."""
+    from ldm.modules.attention import BasicTransformerBlock
+    from sta import prompt_state
+    g = _load("block_%s.npz" % name)
+    dim, C, heads, K, seed = (int(g[k]) for k in ("dim", "C", "heads", "K", "seed"))
+    x, context, local_ctx = gi.block_inputs(dim, C, K, seed, gi.load_uncond())
+    blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768, checkpoint=False)
+    seeded_fill_(blk, seed)
+    blk = blk.to("cuda", dtype)
+    blk.keep_maps = True
+    prompt_state.begin_prompt([c.cuda() for c in local_ctx], first_timestep=981)
+    with torch.no_grad():
+        blk(x.cuda().to(dtype), context=context.cuda().to(dtype), time=torch.tensor(981),
+            coef=torch.from_numpy(g["coef"]).cuda(), bboxs_curr=[list(c) for c in g["centres"]])
+    pix = torch.from_numpy(g["map_pixels"]).cuda()
+    got = blk.last_maps[:, :, pix, :].cpu().numpy()
+    err = np.abs(got - g["maps"]).max()
+    assert err < tol, (name, dtype, err)
 
 
 def _golden_unet(dtype):
@@ -112,10 +140,38 @@ def test_unet_eps_vs_reference_golden(dtype, channels_last):
     assert err.mean() <= 12 * e * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
 
 
-def test_plms_trajectory_fp16_vs_reference_golden_and_graph_matches_eager():
-    """Final x0 of the 50-step trajectory on the GPU vs the reference's fp32 CPU x0 (stated fp16
-    tolerance: max-abs <= 5% of max|x0|, mean-abs <= 1% of mean|x0| — 51 chained UNet calls amplify
-    rounding), and hipGraph replay == eager launches bit for bit."""
+def _golden_trajectory(sampler, g, c, local_ctx, x_T):
+    from sta import prompt_state
+    sampler.make_schedule(int(g["S"]), verbose=False)
+    time_range = np.flip(sampler.ddim_timesteps)
+    W = torch.from_numpy(g["W"]).cuda()
+    with torch.no_grad():
+        prompt_state.begin_prompt([l.cuda() for l in local_ctx], first_timestep=int(time_range[0]))
+        return sampler._trajectory(x_T.cuda(), c.cuda(), gi.load_uncond().cuda(), float(g["scale"]), time_range, W,
+                                   [list(cc) for cc in g["centres"]], 0, graph=False)
+
+
+@pytest.mark.parametrize("dtype,tol_max,tol_mean", [(torch.float16, 0.01, 0.005), (torch.bfloat16, 0.03, 0.02)])
+def test_plms_trajectory_vs_reference_golden(dtype, tol_max, tol_mean):
+    """Final x0 of the reference's 50-step trajectory (G5: per-step weight columns, CFG 7.5) on the GPU vs the
+    reference's fp32 CPU x0. Stated tolerance, as fractions of max|x0| / mean|x0| (51 chained UNet calls amplify
+    rounding): fp16 max 1 %, mean 0.5 % (measured 0.24 % / 0.21 %); bf16 max 3 %, mean 2 % (measured 1.0 % / 0.9 %)."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = _load("plms_traj.npz")
+    c, local_ctx, x_T = gi.unet_inputs(2, int(g["input_seed"]))
+    model = LatentDiffusion(unet_config=_golden_unet(dtype)).cuda()
+    sampler = PLMSSampler(model, opt_epochs=0, use_graph=False, save_images=False)
+    img = _golden_trajectory(sampler, g, c, local_ctx, x_T)
+    ref = g["x0"]
+    err = np.abs(img.float().cpu().numpy() - ref)
+    assert err.max() <= tol_max * np.abs(ref).max(), (err.max(), np.abs(ref).max())
+    assert err.mean() <= tol_mean * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
+
+
+def test_plms_graph_replay_matches_eager():
+    """hipGraph replay == eager launches (to the run-to-run noise of the libraries), and a second prompt re-uses the
+    captured graph with refilled K/V buffers."""
     from ldm.models.diffusion.ddpm import LatentDiffusion
     from ldm.models.diffusion.plms import PLMSSampler
     g = _load("plms_traj.npz")
@@ -125,20 +181,6 @@ def test_plms_trajectory_fp16_vs_reference_golden_and_graph_matches_eager():
         unet = _golden_unet(torch.float16)
         model = LatentDiffusion(unet_config=unet).cuda()
         sampler = PLMSSampler(model, opt_epochs=0, use_graph=(mode == "graph"), save_images=False)
-        # fixed weights path uses W = 5/K; the golden used per-step columns, so drive the loop directly for parity
-        sampler.make_schedule(int(g["S"]), verbose=False)
-        if mode == "eager":
-            from sta import prompt_state
-            time_range = np.flip(sampler.ddim_timesteps)
-            W = torch.from_numpy(g["W"]).cuda()
-            with torch.no_grad():
-                prompt_state.begin_prompt([l.cuda() for l in local_ctx], first_timestep=int(time_range[0]))
-                img = sampler._trajectory(x_T.cuda(), c.cuda(), gi.load_uncond().cuda(), float(g["scale"]), time_range, W,
-                                          [list(cc) for cc in g["centres"]], 0, graph=False)
-            ref = g["x0"]
-            err = np.abs(img.float().cpu().numpy() - ref)
-            assert err.max() <= 0.05 * np.abs(ref).max(), (err.max(), np.abs(ref).max())
-            assert err.mean() <= 0.01 * np.abs(ref).mean(), (err.mean(), np.abs(ref).mean())
         for rep in range(2):     # second prompt re-uses the captured graph with refilled K/V buffers
             sampler.sample(S=10, conditioning=c.cuda() * (1 + rep), batch_size=1, shape=[4, 32, 32], verbose=False,
                            unconditional_guidance_scale=7.5, unconditional_conditioning=gi.load_uncond().cuda(), eta=0.0,

@@ -1,0 +1,83 @@
+"""A/B of the projection-fused forward (sta_xattn_fwd_proj) against the GEMM + sta_xattn_fwd it replaces,
+interleaved in one process (HIP events on the launch stream). SURVEY.md section 8f-1 / VERDICT r01 item 2."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd"))
+from sta import lib, ops  # noqa: E402
+
+CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]
+
+
+def timed(fn, iters):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--N", type=int, default=4096)
+    ap.add_argument("--C", type=int, default=320)
+    ap.add_argument("--K", type=int, default=2)
+    ap.add_argument("--imgs", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=100)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--dtype", default="fp16")
+    ap.add_argument("--waves", type=int, nargs="*", default=[8, 12])
+    ap.add_argument("--only", default=None, help="run only this arm (for rocprofv3): proj | gemm | attn")
+    a = ap.parse_args()
+    dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
+    dev, heads, M, I, N, C, K = "cuda", 8, 77, a.imgs, a.N, a.C, a.K
+    g = torch.Generator().manual_seed(0)
+    y = torch.randn(2 * I, N, C, generator=g).to(dt).to(dev)
+    wq = (torch.randn(C, C, generator=g) / C ** 0.5).to(dt).to(dev)
+    k = (torch.randn(I * (K + 2), M, C, generator=g) * 0.78).to(dt).to(dev)
+    v = torch.randn(I * (K + 2), M, C, generator=g).to(dt).to(dev)
+    mask = ops.disc_mask_bits(CENTRES[:K], int(N ** 0.5)).to(dev).repeat(I, 1)
+    coef = torch.full((I, K), 5.0 / max(K, 1), device=dev)
+    scale = (C // heads) ** -0.5
+    packed, packed_p, wqf = ops.pack_kv(k, v, heads, n_img=I), ops.pack_kv_proj(k, v, heads, n_img=I), ops.pack_wq(wq, heads)
+    q = torch.nn.functional.linear(y, wq)
+    arms = {"gemm": lambda: torch.nn.functional.linear(y, wq),
+            "attn": lambda: ops.xattn_forward(q, packed, mask, coef, scale),
+            "gemm+attn": lambda: ops.xattn_forward(torch.nn.functional.linear(y, wq), packed, mask, coef, scale)}
+    for w in a.waves:
+        def proj(w=w):
+            lib.set_option(lib.OPT_STAGED_WAVES, w)
+            r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
+            lib.set_option(lib.OPT_STAGED_WAVES, 0)
+            return r
+        arms["proj%d" % w] = proj
+    if a.only:
+        arms = {k_: f for k_, f in arms.items() if k_.startswith(a.only)}
+    res = {n: [] for n in arms}
+    for _ in range(a.rounds):
+        for n, f in arms.items():
+            res[n].append(round(timed(f, a.iters), 2))
+    f_attn = I * 4.0 * M * C * N * (K + 2)
+    f_proj = I * 2.0 * 2 * N * C * C
+    byts = I * (8.0 * N * C + 4.0 * (K + 2) * M * C + K * N) + 2.0 * C * C
+    out = {"N": N, "C": C, "K": K, "imgs": I, "dtype": a.dtype, "us": res, "attn_gflop": f_attn / 1e9, "proj_gflop": f_proj / 1e9, "mbytes": byts / 1e6}
+    for n, v_ in res.items():
+        if n.startswith("proj"):
+            us = min(v_)
+            out[n + "_tflops"] = round((f_attn + f_proj) / us / 1e6, 1)
+            out[n + "_gbps"] = round(byts / us / 1e3, 1)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
