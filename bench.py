@@ -3,15 +3,16 @@
 One "step" = one image = one pass of the hot path over one prompt: 50 PLMS steps = 51 classifier-
 free-guidance UNet calls (batch 2: uncond | cond) of the SD-v1 UNet with the fused spatial-temporal
 cross-attention in its 16 transformer blocks, then the VAE decode and clamp (the PNG encode on the
-host is not timed). Workload = BASELINE.json configs[1]: fixed blend weights W = 5/K, bf16, synthetic
+host is not timed). Workload = BASELINE.json configs[1]: fixed blend weights W = 5/K, 16-bit (fp16 default, --dtype bf16), synthetic
 weights of the SD-v1-4 architecture and synthetic text embeddings (no checkpoints / network here).
 
 Multi-GPU: one process per GPU (torch.distributed.run), prompts sharded round-robin, the frozen
 weights broadcast once from rank 0 over RCCL before the timed region; no communication inside it.
 
 Prints ONE JSON line on rank 0 (see the task contract) including
-  roofline     — the fused forward kernel: algorithmic bytes / per-launch time measured
-                 here with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
+  roofline     — the dominant cross-attention forward kernel: algorithmic bytes and flops / per-launch
+                 time measured here with HIP events on the launch stream, against the 8 TB/s HBM3E and 2.5 PFLOP/s
+                 dense 16-bit MFMA peaks (the binding one is `bound`);
   cpu_baseline — the same workload through the CPU oracle (fp32 torch), on a bounded sample.
 """
 import argparse
@@ -37,7 +38,7 @@ for _k in ("FWD", "BWD", "WRW"):
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
-MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 / fp16 MFMA peak
 M_KEYS = 77
 
 
@@ -62,10 +63,15 @@ def parse():
                          "<= 2 prompts per step, res for <= 4, all otherwise (sta.pipeline.set_recompute)")
     ap.add_argument("--nchw", action="store_true", help="keep the UNet trunk in NCHW (2.6%% slower at 8 prompts per step)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-side-runs", action="store_true", help="skip the bounded side measurement after the headline run "
+                                                                 "(3-epoch weight optimisation = BASELINE configs[2])")
+    ap.add_argument("--other-dtype", action="store_true", help="also time one step in the other 16-bit type (adds ~2 min of MIOpen "
+                                                                "solver search for its convolutions)")
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16",
                     help="16-bit type of weights and activations. fp16 is the reference's own compute type (CUDA autocast) and the "
                          "one that meets north_star's 1e-3 attention-map tolerance; bf16 runs at the same MFMA rate but rounding "
                          "the block input alone to 8 mantissa bits moves the maps by 2e-3 (DESIGN.md section 2)")
+    ap.add_argument("--fp8", action="store_true", help="e4m3 Linear weights in the transformer blocks (BASELINE configs[4]; sta.fp8)")
     ap.add_argument("--cpu-calls", type=int, default=2, help="timed CPU UNet calls of the baseline sample")
     ap.add_argument("--opt-epochs", type=int, default=0,
                     help="weight-optimisation epochs (0 = fixed weights = BASELINE configs[1], the headline; 3 = configs[2] "
@@ -76,43 +82,53 @@ def parse():
     return a
 
 
-def xattn_units(model, K):  # per image
-    """Algorithmic work of the fused forward kernel per launch, per block of the UNet:
-    F = 4*M*C*N*(K+2) flop;  Bt = 8*N*C (q in, out; bf16) + 4*(K+2)*M*C (K,V) + K*N (mask) bytes."""
-    units = []
-    for blk in model.model.diffusion_model.transformer_blocks():
-        n, c = blk._last_n, blk.attn2.to_q.weight.shape[0]
-        units.append(dict(N=n, C=c, flops=4.0 * M_KEYS * c * n * (K + 2),
-                          bytes=8.0 * n * c + 4.0 * (K + 2) * M_KEYS * c + K * n))
-    return units
+def launch_units(kind, n_img, N, C, K):
+    """Algorithmic work of ONE forward launch (16-bit activations, M = 77 keys):
+      attention       F = 4*M*C*N*(K+2) flop per image;  Bt = 8*N*C (q or y in, out) + 4*(K+2)*M*C (K,V) + K*N (mask) bytes
+      + projection    the to_q GEMM inside the kernel (sta_xattn_fwd_proj): + 2*2*N*C*C flop per image, + 2*C*C bytes (Wq) once."""
+    flops = 4.0 * M_KEYS * C * N * (K + 2) * n_img
+    byts = (8.0 * N * C + 4.0 * (K + 2) * M_KEYS * C + K * N) * n_img
+    if kind == "proj":
+        flops += 4.0 * N * C * C * n_img
+        byts += 2.0 * C * C
+    return flops, byts
 
 
-def measure_xattn(run_eager_calls, n_calls=4):
-    """Per-launch duration of the fused forward kernel IN SITU: `run_eager_calls(n)` issues n real CFG UNet
-    calls eagerly while sta.ops brackets every sta_xattn_fwd launch with its own HIP-event pair on the launch
-    stream (torch's current stream is the stream the launch is given). The cost of an empty event pair
-    (marker -> marker) is measured the same way and subtracted, so the figure is comparable with
-    rocprofv3's kernel durations. Returns {(N, C): mean us} and the subtracted overhead."""
+def measure_xattn(run_eager_call, n_calls=4, reps=20):
+    """Per-launch duration of every cross-attention forward launch of a UNet call, two ways:
+      in situ  — `n_calls` real CFG UNet calls are issued eagerly while sta.ops brackets every launch with its own
+                 HIP-event pair on the launch stream (torch's current stream IS the stream the C-ABI call is given).
+                 RAW event times, nothing subtracted: an empty event pair alone measures ~4.6 us on this stack, so
+                 these sit that much ABOVE rocprofv3's kernel durations (profiles/ holds the trace of the same command);
+      warm     — each recorded launch re-issued `reps` times back to back between ONE event pair (inputs resident in
+                 L2 / Infinity Cache, no neighbours): what the kernel does when its operands are on chip."""
     from sta import ops
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
-    for e0, e1 in evs:
-        e0.record()
-        e1.record()
-    torch.cuda.synchronize()
-    gaps = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in evs)
-    overhead = gaps[len(gaps) // 2]
-    run_eager_calls(1)                                   # warm the eager path (first launches, allocator)
-    ops.EVENT_LOG = []
+    run_eager_call()                                     # warm the eager path (first launches, allocator)
+    ops.LAUNCH_LOG = []
     try:
-        run_eager_calls(n_calls)
+        for _ in range(n_calls):
+            run_eager_call()
         torch.cuda.synchronize()
-        log = ops.EVENT_LOG
+        log = ops.LAUNCH_LOG
     finally:
-        ops.EVENT_LOG = None
-    per = {}
-    for e0, e1, I, N, C, K, _kind in log:
-        per.setdefault((N, C), []).append(max(e0.elapsed_time(e1) * 1e3 - overhead, 0.1))
-    return {k: sum(v) / len(v) for k, v in per.items()}, {k: len(v) for k, v in per.items()}, overhead
+        ops.LAUNCH_LOG = None
+    per_call = len(log) // n_calls
+    rows = []
+    for j in range(per_call):
+        kind, n_img, N, C, K = log[j][:5]
+        us = [log[j + c * per_call][5].elapsed_time(log[j + c * per_call][6]) * 1e3 for c in range(n_calls)]
+        relaunch = log[j][7]
+        for _ in range(3):
+            relaunch()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            relaunch()
+        e1.record()
+        torch.cuda.synchronize()
+        flops, byts = launch_units(kind, n_img, N, C, K)
+        rows.append(dict(kind=kind, N=N, C=C, us=sum(us) / len(us), warm_us=e0.elapsed_time(e1) * 1e3 / reps, flops=flops, bytes=byts))
+    return rows
 
 
 def cpu_baseline(res, ddim_steps, K, n_calls):
@@ -149,6 +165,53 @@ def cpu_baseline(res, ddim_steps, K, n_calls):
                        "extrapolated to %d calls + 1 decode per image" % (n_calls, t_call, t_dec, res, res, n_unet))
 
 
+def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps, K, checkpoint="auto", find=True):
+    """A bounded side measurement on rank 0 after the headline run: the same workload with another 16-bit type, or
+    BASELINE configs[2] (3 weight-optimisation epochs: two tracked trajectories with backward + one fixed-weight one).
+    Builds its own model, reports images/s over `steps` timed steps after `warmup` untimed ones."""
+    from ldm.models.diffusion.plms import DCLIPLoss, PLMSSampler
+    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, set_recompute
+    from sta.synth import SyntheticCLIP
+    dt = torch.float16 if dtype_name == "fp16" else torch.bfloat16
+    model = build_sd_v1(dev, dt, with_vae=True, init_weights=True, seed=0, channels_last=opt_epochs == 0, use_checkpoint=opt_epochs > 1)
+    torch.backends.cudnn.benchmark = bool(find)
+    mode = set_recompute(model, checkpoint, images) if opt_epochs > 1 else None
+    loss_model = DCLIPLoss(SyntheticCLIP().to(dev)) if opt_epochs > 0 else None
+    sampler = PLMSSampler(model, opt_epochs=opt_epochs, loss_model=loss_model, use_graph=True, save_images=False)
+    prompts = load_prompts(64)
+    lat = res // 8
+    centres = [list(c) for c in DEFAULT_CENTRES[:K]]
+    x_T1 = torch.randn([1, 4, lat, lat], generator=torch.Generator(device=dev).manual_seed(1), device=dev)
+
+    def step(j):
+        recs = [prompts[(j * images + i) % len(prompts)] for i in range(images)]
+        names = [(r["objects"] + ["object"] * K)[:K] for r in recs]
+        conds = [conditionings(model, r["prompt"], nm, dt) for r, nm in zip(recs, names)]
+        sampler.sample_batch(S=ddim_steps, shape=[4, lat, lat], conditionings=[c[1] for c in conds],
+                             unconditional_conditionings=[c[0] for c in conds], bboxs=[centres] * images, object_names=names,
+                             local_conditionings=[c[2] for c in conds], curr_texts=[r["prompt"] for r in recs],
+                             x_T=x_T1.expand(images, -1, -1, -1), unconditional_guidance_scale=7.5, seed=1)
+        return sampler.last_result
+
+    for j in range(warmup):
+        step(j)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for j in range(steps):
+        r = step(warmup + j)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    assert torch.isfinite(r["x0"]).all()
+    out = {"value": steps * images / el, "unit": "images/s", "dtype": dtype_name, "images_per_step": images, "steps": steps,
+           "warmup": warmup, "ms_per_step": 1e3 * el / steps}
+    if opt_epochs:
+        out.update(opt_epochs=opt_epochs, recompute=mode, miopen_find=bool(find), loss="CLIP stand-in (sta.synth.SyntheticCLIP): real front-end, VAE decode "
+                   "and backward through 2 x 51 UNet calls; the third epoch runs the fixed-weight path", losses=r.get("losses"))
+    del sampler, model
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     a = parse()
     from sta import parallel
@@ -178,6 +241,9 @@ def main():
     torch.cuda.synchronize()
     t_bcast = time.perf_counter() - t0
 
+    if a.fp8:
+        from sta import fp8
+        fp8.convert_transformer_linears_(model.model.diffusion_model)
     prompts = load_prompts(64)
     mine = parallel.shard_indices(len(prompts), rank, world)
     lat = a.res // 8
@@ -237,12 +303,12 @@ def main():
                                        "%d weight-optimisation epochs, CLIP stand-in loss (BASELINE configs[2])" % a.opt_epochs),
                    "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt, sharded i %% %d" % world,
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
-                   "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
+                   "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,
                    "peak_hbm_gib": round(peak_gb, 1), **({"recompute": ckpt_mode} if a.opt_epochs > 1 else {})},
     }
     if not a.no_roofline:
-        # in-situ per-launch times of the fused forward kernel: a few real CFG UNet calls issued eagerly
+        # per-launch times of the cross-attention forward kernels on the tensors of a real CFG UNet call
         from sta import prompt_state
         rec = prompts[mine[0]]
         names = (rec["objects"] + ["object"] * K)[:K]
@@ -255,31 +321,63 @@ def main():
         boxes = [centres] * I if I > 1 else centres
         prompt_state.begin_prompt([local_c] * I if I > 1 else local_c, first_timestep=981)
 
-        def run_eager_calls(n):
+        def run_eager_call():
             with torch.no_grad():
-                for _ in range(n):
-                    model.apply_model_extra(x_in, 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
+                model.apply_model_extra(x_in, 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
 
-        per_us, counts, overhead = measure_xattn(run_eager_calls)
-        units = xattn_units(model, K)
-        byts = sum(u["bytes"] for u in units) * I                          # algorithmic bytes of one UNet call
-        flops = sum(u["flops"] for u in units) * I
-        us = sum(per_us[(u["N"], u["C"])] for u in units)                  # 16 launches of one UNet call
-        n = len(units)
-        achieved = byts / us / 1e3
+        rows = measure_xattn(run_eager_call)
+        by_shape = {}
+        for r in rows:
+            by_shape.setdefault((r["kind"], r["N"], r["C"]), []).append(r)
+        # the dominant kernel = the launch shape with the largest share of the cross-attention time of a UNet call
+        dom = max(by_shape, key=lambda k_: sum(r["us"] for r in by_shape[k_]))
+        d_us = sum(r["us"] for r in by_shape[dom]) / len(by_shape[dom])
+        d_flops, d_bytes = by_shape[dom][0]["flops"], by_shape[dom][0]["bytes"]
+        t_hbm, t_mfma = d_bytes / (HBM_PEAK_GBS * 1e3), d_flops / (MFMA_PEAK_TFLOPS * 1e6)      # us at either peak
+        all_us, all_bytes, all_flops = (sum(r[k_] for r in rows) for k_ in ("us", "bytes", "flops"))
         traffic = None
         pmc = os.path.join(REPO, "profiles", "xattn_fwd_hbm_traffic.json")
-        if os.path.exists(pmc):      # rocprofv3 --pmc passes of tools/kernel_bench.py, committed per images-per-launch
-            traffic = json.load(open(pmc)).get("by_images_per_launch", {}).get(str(I), {}).get("bytes_per_launch")
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           "kernel": "xattn_fwd{,_staged}_kernel (fused QK^T+softmax+disc mask+blend+PV), 16 launches per UNet call, "
-                                     "%d image(s) per launch" % I,
-                           "bytes_per_launch": byts / n, "flops_per_launch": flops / n, "avg_launch_us": us / n,
-                           "event_pair_overhead_us_subtracted": round(overhead, 2),
-                           "launches_measured": int(sum(counts.values())), "how": "in situ: real eager CFG UNet calls, one HIP-event pair per launch",
-                           "mfma_tflops": flops / us / 1e6, "mfma_frac": flops / us / 1e6 / MFMA_PEAK_TFLOPS,
-                           "per_level_us": {"N%d_C%d" % k: round(v, 2) for k, v in sorted(per_us.items(), reverse=True)}}
+        if os.path.exists(pmc):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed per kernel and images-per-launch
+            traffic = json.load(open(pmc)).get("by_kernel", {}).get("%s_N%d_C%d_I%d" % (dom + (I,)), {}).get("bytes_per_launch")
+        kname = {"proj": "xattn_fwd_proj_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch)",
+                 "attn": "xattn_fwd{,_staged}_kernel (QK^T + softmax + disc mask + blend + PV)"}[dom[0]]
+        bound = "hbm" if t_hbm >= t_mfma else "mfma"
+        out["roofline"] = {
+            "bound": bound,
+            "achieved": d_bytes / d_us / 1e3 if bound == "hbm" else d_flops / d_us / 1e6,
+            "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+            "frac": max(t_hbm, t_mfma) / d_us, "traffic": traffic,
+            "kernel": "%s, N=%d C=%d, %d image(s) per launch, %d of the %d launches of a UNet call (%.0f %% of their time)"
+                      % (kname, dom[1], dom[2], I, len(by_shape[dom]), len(rows), 100.0 * d_us * len(by_shape[dom]) / all_us),
+            "bytes_per_launch": d_bytes, "flops_per_launch": d_flops, "avg_launch_us": d_us,
+            "flop_per_byte": d_flops / d_bytes, "ridge_flop_per_byte": MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS,
+            "hbm_gbps": d_bytes / d_us / 1e3, "hbm_frac": t_hbm / d_us, "mfma_tflops": d_flops / d_us / 1e6, "mfma_frac": t_mfma / d_us,
+            "how": "in situ: 4 real eager CFG UNet calls, one HIP-event pair per launch on the launch stream, RAW event times "
+                   "(an empty pair measures ~4.6 us here; nothing subtracted)",
+            "warm_launch_us": sum(r["warm_us"] for r in by_shape[dom]) / len(by_shape[dom]),
+            "warm_how": "the same launches re-issued 20x back to back between one event pair (operands resident on chip)",
+            "all_launches": {"n": len(rows), "sum_us": all_us, "hbm_gbps": all_bytes / all_us / 1e3, "hbm_frac": all_bytes / all_us / 1e3 / HBM_PEAK_GBS,
+                             "mfma_tflops": all_flops / all_us / 1e6, "mfma_frac": all_flops / all_us / 1e6 / MFMA_PEAK_TFLOPS},
+            "per_shape_us": {"%s_N%d_C%d" % k_: round(sum(r["us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])},
+            "per_shape_warm_us": {"%s_N%d_C%d" % k_: round(sum(r["warm_us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])}}
+        prof = os.path.join(REPO, "profiles", "r02_bench_kernel_stats.csv")
+        if os.path.exists(prof):      # rocprofv3 --kernel-trace summary of this command, committed: the cross-check
+            import csv
+            want = "xattn_fwd_proj_kernel" if dom[0] == "proj" else "xattn_fwd"
+            hit = [r for r in csv.DictReader(open(prof)) if want in r["kernel"]]
+            if hit:
+                best = max(hit, key=lambda r: float(r["total_ns"]))
+                out["roofline"]["rocprof_avg_us_committed"] = float(best["avg_ns"]) / 1e3
+    if world == 1 and not a.no_side_runs and a.opt_epochs == 0:
+        # reported beside the headline, never part of `value`: the other 16-bit type, and BASELINE configs[2]
+        if a.other_dtype:
+            out["other_dtype"] = side_run(dev, "bf16" if a.dtype == "fp16" else "fp16", 0, I, 1, 1, a.res, a.ddim_steps, K)
+        # MIOpen's per-shape solver search is switched off for this leg (immediate mode): searching the backward
+        # convolutions of the UNet and the VAE decoder costs ~10 min on a fresh box for one timed step
+        torch.backends.cudnn.benchmark = False
+        out["weight_optimisation"] = side_run(dev, a.dtype, 3, 2, 1, 1, a.res, a.ddim_steps, K, find=False)
+        out["weight_optimisation"]["config"] = "BASELINE configs[2]: %dx%d, %d PLMS steps, %d objects, 3 epochs of per-step blend-weight optimisation" % (
+            a.res, a.res, a.ddim_steps, K)
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a.res, a.ddim_steps, K, a.cpu_calls)
     print(json.dumps(out))

@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int RING = 5;   // k-steps (32 channels each) of y in flight per batch row; C % (32 * RING) == 0
+constexpr int RING_MIN = 5;   // k-steps (32 channels each) of y per ring refill; C % (32 * RING_MIN) == 0
 
 // to_q.weight [C][C] (row = output channel h*d + dd, col = input channel) -> per head [s][u] fragments:
 // lane (g, c) of fragment (s, u) holds Wq[h*d + 16u + c][32s + 8g .. +7]; rows 16u + c >= d are zero.
@@ -96,12 +96,17 @@ struct PParams {
 // ALL K+2 contexts into LDS once (LDS-DMA; 30 + 19 (K+2) KiB at d = 40), passes one barrier and then walks
 // `iters` strided pixel tiles: per tile and wave
 //   projection  : NDT * nkc * 2 MFMAs (both batch rows share every Wq fragment read), y rows streamed through a
-//                 RING-deep register ring — the loads of k-step s + RING are issued when step s is consumed, and
-//                 the first RING steps of the NEXT tile right after the last one, so they land under the attention
+//                 RING-deep register ring: when k-step s is consumed its slot is refilled with step s + RING — of
+//                 this tile, or, past its end, of the NEXT tile, whose rows therefore land under this tile's
+//                 attention. The y rows are re-read by the 8 head workgroups of a tile group, i.e. 8x the activation
+//                 bytes come through the CU's vector-memory path (from L2): the ring depth is what keeps that path
+//                 busy — 2 x RING loads of 1 KiB in flight per wave at all times. That path, not the MFMA or VALU
+//                 pipes, bounds the kernel: 671 MB of y per 16-image launch at level 0 arrive at 7.6 TB/s
+//                 (profiles/r02_proj_fusion.md)
 //   attention   : contexts 0, 1 and the local contexts whose disc touches the wave's pixels, from LDS
 //                 (attend_staged, shared with sta_xattn.hip) — blend in registers, 16-byte stores.
 // No barrier after the prologue: waves drift apart, one wave's projection MFMAs run beside another's softmax VALU.
-template <typename T, int NDT, int NWV>
+template <typename T, int NDT, int NWV, int RING>
 __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_kernel(const PParams p) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
@@ -140,16 +145,20 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_ke
   const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
   const unsigned row1 = (unsigned)N * row_bytes;
   // pixels >= N (and tiles past the end) are pushed out of the descriptor's range: they read as zeros
+  // every head walks its tiles in the same order: the 8 head workgroups of a tile group then touch the same y rows
+  // at about the same time and 7 of the 8 reads hit L2. (Starting head h a few tiles ahead, to spread the requests
+  // over L2 channels, measured equal to slower: 87.3 / 91.5 / 101 us with heads 4 / 2 / 1 per phase vs 87.2 us.)
+  auto tile_of = [&](int it) -> int { return wt + it * W; };
   auto voff_of = [&](int it) -> unsigned {
-    const int px = (wt + it * W) * TP + wv * 16 + c16;
+    const int px = tile_of(it) * TP + wv * 16 + c16;
     return (it < iters && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
   };
   auto mask_of = [&](int it) -> unsigned {
-    const int px = (wt + it * W) * TP + wv * 16 + c16;
+    const int px = tile_of(it) * TP + wv * 16 + c16;
     return mask[(it < iters && px < N) ? px : 0];
   };
   V8 yr0[RING], yr1[RING];
-  unsigned voff = voff_of(0);
+  unsigned voff = voff_of(0), voffn = voff_of(1);
   unsigned mb = mask_of(0);
 #pragma unroll
   for (int j = 0; j < RING; ++j) {
@@ -160,9 +169,13 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_ke
   const float sl2e = p.sl2e;
   const int sumrow = (d & 15) ? (d & 15) : -1;
   const unsigned kmask = (1u << K) - 1u;
+  STA_T_INIT();
+  STA_T(0);
   wait_dma_and_sync();
+  STA_T(1);
 
   for (int it = 0; it < iters; ++it) {
+    if (it == 1) STA_T(2);
     // ---- projection: Q^T tiles of both batch rows --------------------------------------------------------
     f32x4 qa0[NDT], qa1[NDT];
 #pragma unroll
@@ -183,21 +196,20 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_ke
           qa0[u] = Tr<T>::mfma(a[u], yr0[j], qa0[u]);
           qa1[u] = Tr<T>::mfma(a[u], yr1[j], qa1[u]);
         }
-        if (s + RING < nkc) {                     // scalar condition: refill this ring slot with step s + RING
-          yr0[j] = srd_load16<V8>(y_srd, voff, 64u * (s + RING));
-          yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * (s + RING));
-        }
+        // refill this slot with step s + RING: of this tile, or of the next one (zeros past the last tile)
+        const bool wrap = s + RING >= nkc;        // scalar
+        const unsigned vo = wrap ? voffn : voff;
+        const unsigned so = 64u * (unsigned)(wrap ? s + RING - nkc : s + RING);
+        yr0[j] = srd_load16<V8>(y_srd, vo, so);
+        yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
       }
     }
-    // the first RING steps of the next tile (zeros past the last tile) land while this tile attends
-    const bool valid = (wt + it * W) * TP + wv * 16 + c16 < N;
-    voff = voff_of(it + 1);
+    if (it == 1) STA_T(3);
+    const int px_own = tile_of(it) * TP + wv * 16 + c16;
+    const bool valid = px_own < N;
+    voff = voffn;
+    voffn = voff_of(it + 2);
     const unsigned mbn = mask_of(it + 1);
-#pragma unroll
-    for (int j = 0; j < RING; ++j) {
-      yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
-      yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
-    }
     // accumulators -> B operands of S^T (rounded to T once, as a GEMM epilogue would)
     V8 q0[1][NKS], q1[1][NKS];
 #pragma unroll
@@ -213,7 +225,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_ke
     f32x4 au[1][NDT], ac[1][NDT];
     float w[1] = {0.f};
     attend_staged<T, NDT, 1, 0>((const V8*)lds_ctx + lane, q0, kb4, sl2e, w, au, ac, sumrow);
+    if (it == 1) STA_T(4);
     attend_staged<T, NDT, 1, 1>((const V8*)(lds_ctx + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
+    if (it == 1) STA_T(5);
     const unsigned mbits = valid ? (mb & kmask) : 0u;
     for (int i = 0; i < K; ++i) {
       if (!__ballot((mbits >> i) & 1u)) continue;  // none of this wave's pixels inside disc i
@@ -221,16 +235,20 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_ke
       w[0] = ((mbits >> i) & 1u) ? cw : 0.f;
       attend_staged<T, NDT, 1, 2>((const V8*)(lds_ctx + (size_t)(2 + i) * CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
     }
+    if (it == 1) STA_T(6);
     if (valid) {
-      T* obase = ob + (size_t)((wt + it * W) * TP + wv * 16 + c16) * C + h * d;
+      T* obase = ob + (size_t)px_own * C + h * d;
       store_row16<T, NDT>(obase, au[0], g, d);
       store_row16<T, NDT>(obase + (size_t)N * C, ac[0], g, d);
     }
+    if (it == 1) STA_T(7);
     mb = mbn;
   }
+  STA_T(8);
+  STA_T_END();
 }
 
-template <typename T, int NDT, int NWV>
+template <typename T, int NDT, int NWV, int RING>
 int launch_proj_cfg(PParams p, int n_img, int lds, hipStream_t st) {
   constexpr int TP = 16 * NWV;
   p.tiles = (p.N + TP - 1) / TP;
@@ -243,9 +261,9 @@ int launch_proj_cfg(PParams p, int n_img, int lds, hipStream_t st) {
   if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
   p.W = (p.tiles + p.iters - 1) / p.iters;
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_kernel<T, NDT, NWV>, 160 * 1024))
+  if (!attr.ensure((const void*)xattn_fwd_proj_kernel<T, NDT, NWV, RING>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_kernel<T, NDT, NWV>), dim3(p.W * p.H, n_img), dim3(64 * NWV), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_proj_kernel<T, NDT, NWV, RING>), dim3(p.W * p.H, n_img), dim3(64 * NWV), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj launch: %s", hipGetErrorString(e));
 }
@@ -254,9 +272,13 @@ template <typename T, int NDT>
 int launch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
   int nwv = 8;
   if (const int v = g_sta_opt[STA_OPT_STAGED_WAVES]) nwv = v == 12 ? 12 : (v == 4 ? 4 : 8);
-  if (nwv == 12) return launch_proj_cfg<T, NDT, 12>(p, n_img, lds, st);
-  if (nwv == 4) return launch_proj_cfg<T, NDT, 4>(p, n_img, lds, st);
-  return launch_proj_cfg<T, NDT, 8>(p, n_img, lds, st);
+  // ring depth 5 ships. The 10-deep ring (a whole row of a tile at C = 320, 198 registers) measured SLOWER — 96.8 vs
+  // 89 us: the y stream is throughput bound in the L2 -> L1 path (7.6 TB/s chip-wide for these half-line gathers,
+  // profiles/r02_proj_fusion.md), more loads in flight only lengthen the queue — and stays reachable for A/B runs.
+  const bool deep = p.nkc % 10 == 0 && g_sta_opt[STA_OPT_PROJ_RING] == 10;
+  if (nwv == 12) return launch_proj_cfg<T, NDT, 12, 5>(p, n_img, lds, st);
+  if (nwv == 4) return deep ? launch_proj_cfg<T, NDT, 4, 10>(p, n_img, lds, st) : launch_proj_cfg<T, NDT, 4, 5>(p, n_img, lds, st);
+  return deep ? launch_proj_cfg<T, NDT, 8, 10>(p, n_img, lds, st) : launch_proj_cfg<T, NDT, 8, 5>(p, n_img, lds, st);
 }
 
 template <typename T>
@@ -282,7 +304,7 @@ int check_proj_shape(int N, int C, int heads, int M, int K) {
   if (C % heads) return sta_fail(STA_E_ARG, "C=%d not divisible by heads=%d", C, heads);
   const int d = C / heads;
   if (d % 8 || d > 96) return sta_fail(STA_E_UNSUP, "head dim %d unsupported by the projection-fused forward (d %% 8 == 0, d <= 96)", d);
-  if (C % (32 * RING)) return sta_fail(STA_E_UNSUP, "C=%d unsupported by the projection-fused forward (need C %% %d == 0)", C, 32 * RING);
+  if (C % (32 * RING_MIN)) return sta_fail(STA_E_UNSUP, "C=%d unsupported by the projection-fused forward (need C %% %d == 0)", C, 32 * RING_MIN);
   if (M > STA_MAX_KEYS || M <= 16 * (NKT - 1)) return sta_fail(STA_E_UNSUP, "M=%d keys unsupported (65..%d)", M, STA_MAX_KEYS);
   if (K > STA_MAX_OBJECTS) return sta_fail(STA_E_UNSUP, "K=%d objects unsupported (max %d)", K, STA_MAX_OBJECTS);
   if (proj_lds_bytes(C, heads, K) > 160 * 1024)
@@ -293,6 +315,13 @@ int check_proj_shape(int N, int C, int heads, int M, int K) {
 }  // namespace
 
 extern "C" {
+
+#ifdef STA_TRACE
+// trace build only (tools/trace_proj.py): this translation unit's copy of the trace pointer
+int sta_debug_set_trace_proj(void* buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int sta_xattn_fwd_proj_supported(int C, int heads, int M, int K) {
   const int rc = check_proj_shape(16, C, heads, M, K);

@@ -59,8 +59,9 @@ class DCLIPLoss(torch.nn.Module):
         return self._loss(self.avg_pool(self.upsample(image.unsqueeze(0))), text)
 
     def forward_3(self, image, text):
-        # torchvision Resize on a tensor = bilinear, align_corners=False, antialiased when shrinking
-        img = torch.nn.functional.interpolate(image.unsqueeze(0), size=(224, 224), mode="bilinear", antialias=True)
+        # torchvision 0.12.0 (the reference's pin, environment_replicate.yml:10) resizes TENSORS with plain bilinear
+        # interpolation, align_corners=False, no antialiasing
+        img = torch.nn.functional.interpolate(image.unsqueeze(0), size=(224, 224), mode="bilinear", align_corners=False)
         return self._loss(img, text)
 
 

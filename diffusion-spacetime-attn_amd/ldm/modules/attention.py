@@ -92,6 +92,8 @@ class CrossAttention(nn.Module):
         transposed because the PV product wants keys contiguous per channel: ONE plain GEMM W_v . X^T over the
         flattened batch gives [C, B*N], which the kernel reads through (row, batch) strides. (A batched
         `matmul(W_v, x^T)` with the weight broadcast over the batch faults inside the GEMM library from batch 40 up.)"""
+        if not isinstance(self.to_q, nn.Linear):
+            return self._self_attention_hip_fp8(x)
         wq, wk = self.to_q.weight, self.to_k.weight
         key = (wq.data_ptr(), wq._version, wk.data_ptr(), wk._version)
         if getattr(self, "_wqk_key", None) != key:
@@ -100,6 +102,22 @@ class CrossAttention(nn.Module):
         qk = F.linear(x, self._wqk)                                   # [B, N, 2C]
         b, n, _ = x.shape
         vt = torch.mm(self.to_v.weight, x.reshape(b * n, c).t()).view(c, b, n).permute(1, 0, 2)    # [B, C, N] view of [C, B*N]
+        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
+        return self.to_out(o)
+
+
+    def _self_attention_hip_fp8(self, x):
+        """The same with e4m3 weights (sta.fp8, BASELINE configs[4]): x is quantised ONCE per call (sta_quant_rows_fp8) and
+        feeds both fp8 GEMMs — [Wq; Wk] (row scales concatenated) and the transposed W_v . x^T."""
+        from sta import fp8 as _fp8
+        if getattr(self, "_wqk8", None) is None or self._wqk8_src is not self.to_q.weight_q:
+            self._wqk8 = _fp8.Fp8Linear(torch.cat([self.to_q.weight_q, self.to_k.weight_q]),
+                                        torch.cat([self.to_q.weight_scale, self.to_k.weight_scale], dim=1), None)
+            self._wqk8_src = self.to_q.weight_q
+        b, n, c = x.shape
+        xq, sx = _fp8.quant_rows(x.reshape(b * n, c))
+        qk = torch._scaled_mm(xq, self._wqk8.weight_q.t(), scale_a=sx, scale_b=self._wqk8.weight_scale, out_dtype=x.dtype).view(b, n, 2 * c)
+        vt = self.to_v.forward_transposed(xq, sx, x.dtype).view(c, b, n).permute(1, 0, 2)
         o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
         return self.to_out(o)
 

@@ -59,6 +59,9 @@ def build_parser(default_dataset):
                    help="fidelity-loss model for --opt_epochs > 0: 'module:callable' (called with the device, returns a model with "
                         "encode_image/encode_text or (model, tokenize)), a CLIP .pt path, or 'synthetic' (frozen stand-in, for "
                         "timing the gradient path). Default: clip.load('ViT-B/32') as the reference (plms.py:24)")
+    p.add_argument("--fp8", action="store_true",
+                   help="store the Linear weights of the transformer blocks as OCP e4m3 with per-channel scales and run their GEMMs "
+                        "on the fp8 MFMA path (BASELINE configs[4]); fixed blend weights only (--opt_epochs 0)")
     p.add_argument("--clip_tokenizer", type=str, default=None, help="directory with the CLIP tokenizer files (with --ckpt)")
     p.add_argument("--synthetic", action="store_true", help="synthetic weights/text embeddings when no checkpoint is available")
     p.add_argument("--batch_prompts", type=int, default=1,
@@ -106,6 +109,12 @@ def run(kind, default_dataset):
         from sta.pipeline import set_recompute
         set_recompute(model, "auto", max(opt.batch_prompts, 1))      # sized to 288 GB of HBM at 512x512; larger images keep the reference's policy
     parallel.broadcast_module_(model)                                   # one RCCL broadcast of the frozen weights
+    if opt.fp8:
+        if opt.opt_epochs > 0:
+            raise SystemExit("--fp8 is an inference option: use --opt_epochs 0")
+        from sta import fp8
+        n, before, after = fp8.convert_transformer_linears_(model.model.diffusion_model)
+        print("[rank %d] %d Linear layers -> e4m3: %.2f GB -> %.2f GB" % (rank, n, before / 1e9, after / 1e9))
     sampler = PLMSSampler(model, opt_epochs=opt.opt_epochs, loss_model=loss_model)
     os.makedirs(opt.outdir, exist_ok=True)
 

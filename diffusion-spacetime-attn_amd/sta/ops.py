@@ -127,9 +127,21 @@ def _check_inputs(q, packed, mask, coef):
 
 SELFATTN_ENABLED = True      # A/B switch for tools/ (False: attn1 through PyTorch SDPA); nothing reads the environment
 
-# bench.py's roofline leg: when set to a list, every forward launch is bracketed by its own HIP-event pair
-# on the launch stream and (e0, e1, n_img, N, C, K) is appended — in situ, inside real UNet calls.
-EVENT_LOG = None
+# bench.py's roofline leg: when set to a list, every forward launch is bracketed IN SITU (inside a real UNet call) by its
+# own HIP-event pair on the launch stream and (kind, n_img, N, C, K, e0, e1, relaunch) is appended; `relaunch()` re-issues
+# exactly that C-ABI call on the same tensors (for warm, back-to-back timing beside the in-situ figure).
+LAUNCH_LOG = None
+
+
+def _logged(kind, I, N, C, K, launch):
+    if LAUNCH_LOG is None:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    LAUNCH_LOG.append((kind, I, N, C, K, e0, e1, launch))
 
 
 def xattn_forward(q, packed, mask, coef, scale, want_maps=False):
@@ -141,15 +153,11 @@ def xattn_forward(q, packed, mask, coef, scale, want_maps=False):
     maskc = mask.contiguous() if K else None
     out = torch.empty_like(q)
     maps = torch.empty((I, K + 2, packed.heads, N, packed.M), dtype=torch.float32, device=q.device) if want_maps else None
-    if EVENT_LOG is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(L.sta_xattn_fwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), out.data_ptr(),
-                               _ptr(maps), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(q),
-                               _stream(q)), "sta_xattn_fwd")
-    if EVENT_LOG is not None:
-        e1.record()
-        EVENT_LOG.append((e0, e1, I, N, C, K, "attn"))
+    def launch():
+        _lib.check(L.sta_xattn_fwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), out.data_ptr(),
+                                   _ptr(maps), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(q),
+                                   _stream(q)), "sta_xattn_fwd")
+    _logged("attn", I, N, C, K, launch)
     if maps is not None and I == 1:
         maps = maps[0]
     return out, maps
@@ -232,15 +240,11 @@ def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale):
     coef32 = coef.detach().to(torch.float32).contiguous() if K else None
     maskc = mask.contiguous() if K else None
     out = torch.empty_like(y)
-    if EVENT_LOG is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    _lib.check(L.sta_xattn_fwd_proj(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
-                                    out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y),
-                                    _stream(y)), "sta_xattn_fwd_proj")
-    if EVENT_LOG is not None:
-        e1.record()
-        EVENT_LOG.append((e0, e1, I, N, C, K, "proj"))
+    def launch():
+        _lib.check(L.sta_xattn_fwd_proj(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
+                                        out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y),
+                                        _stream(y)), "sta_xattn_fwd_proj")
+    _logged("proj", I, N, C, K, launch)
     return out
 
 

@@ -86,3 +86,8 @@ class SyntheticCLIP(torch.nn.Module):
     def encode_text(self, text):
         rng = np.random.Generator(np.random.PCG64([7, zlib.crc32(str(text).encode("utf-8"))]))
         return torch.from_numpy(rng.standard_normal((1, self.dim), dtype=np.float32)).to(self.proj.weight.device)
+
+
+def synthetic_clip(device="cuda"):
+    """`--clip sta.synth:synthetic_clip`: the stand-in above as a loss-model factory (ldm...plms.load_clip_model)."""
+    return SyntheticCLIP().to(device)

@@ -13,7 +13,12 @@ failure.
   G4  unet_eps.npz     one UNetModel call (reduced width, same topology)   openaimodel.py:710-743
   G5  plms_traj.npz    50-step PLMS trajectory with CFG and per-step coef  plms.py:227-247, 296-358
   G6  schedule.npz     DDIM timesteps / alpha tables for S = 50 and S = 10  util.py:46-75, plms.py:81-112
+  G5b plms_config1.npz BASELINE configs[0]: 64x64 latent, 10 PLMS steps, 1 object, fixed weights 5/K; the blocks are
+                       primed by one call at time 981 because their per-prompt setup is keyed on that constant
+                       (attention.py:240; for S != 50 the reference itself would raise AttributeError)   plms.py:296-358
   G7  prompts.json     dataset parsing rules on the first records          scripts/txt2img-{gpt,mscoco,vsr}.py:255-261
+  G8  loss_frontend.npz  DCLIPLoss.forward_2 / forward_3 of the reference around the SyntheticCLIP stand-in, on the
+                       crops of plms.py:254-270, and the 224^2 images it feeds to CLIP          plms.py:21-45, 249-273
 """
 import json
 import os
@@ -132,9 +137,9 @@ UNET_CFG = dict(image_size=32, in_channels=4, model_channels=64, out_channels=4,
 UNET_SEED = 21
 
 
-def _unet_inputs(K, seed):
+def _unet_inputs(K, seed, lat=LAT):
     uncond = rh.load_uncond()
-    return (uncond,) + unet_inputs(K, seed)
+    return (uncond,) + unet_inputs(K, seed, lat)
 
 
 def gen_unet():
@@ -198,6 +203,40 @@ def gen_plms():
     print("plms_traj.npz x0 |mean| %.4f max %.3f" % (img.abs().mean().item(), img.abs().max().item()))
 
 
+def gen_config1():
+    """BASELINE configs[0]: one prompt, 64x64 latent, S = 10, K = 1, CFG 7.5, W = 5/K at every step."""
+    K, S, scale, lat = 1, 10, 7.5, 64
+    uncond, c, local_ctx, x_T = _unet_inputs(K, 51, lat)
+    centres = [list(cc) for cc in CENTRES[:K]]
+    W = torch.full((K, S), 5.0 / K)
+    with rh.reference_env(local_ctx) as ref, torch.no_grad():
+        unet = ref.unet.UNetModel(**UNET_CFG).eval()
+        checksum = seeded_fill_(unet, UNET_SEED)
+        model = rh.FakeLatentDiffusion(ref, unet)
+        sampler = rh.make_ref_sampler(ref, model)
+        sampler.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+        time_range = np.flip(sampler.ddim_timesteps)
+        assert int(time_range[0]) == 901
+        # priming call: sets curr_cs / masks / bboxs_curr of every block (attention.py:238-263); its output is discarded
+        unet(torch.cat([x_T, x_T]), 0, torch.tensor([981, 981]), context=torch.cat([uncond, c]), coef=W[:, 0], bboxs_curr=centres)
+        img, old_eps, e0 = x_T.clone(), [], None
+        for i, step in enumerate(time_range):               # loop header of plms.py:227-247
+            ts = torch.full((1,), int(step), dtype=torch.long)
+            ts_next = torch.full((1,), int(time_range[min(i + 1, S - 1)]), dtype=torch.long)
+            img, pred_x0, e_t = sampler.p_sample_plms(img, c, ts, index=S - i - 1, unconditional_guidance_scale=scale,
+                                                      unconditional_conditioning=uncond, old_eps=old_eps, t_next=ts_next,
+                                                      text_index=0, coef=W[:, i], bboxs_curr=centres)
+            old_eps.append(e_t)
+            if len(old_eps) >= 4:
+                old_eps.pop(0)
+            if i == 0:
+                e0 = e_t.clone()
+    np.savez_compressed(os.path.join(OUT, "plms_config1.npz"), checksum=checksum, S=S, K=K, lat=lat, scale=scale, input_seed=51,
+                        centres=np.asarray(centres), x_T_sum=float(x_T.double().abs().sum()), e0=e0.numpy().astype(np.float16),
+                        x0=img.numpy())
+    print("plms_config1.npz x0 |mean| %.4f max %.3f" % (img.abs().mean().item(), img.abs().max().item()))
+
+
 def gen_schedule():
     out = {}
     with rh.reference_env() as ref:
@@ -234,6 +273,47 @@ def gen_prompts():
     print("prompts.json", out["gpt_prompts"][0], out["mscoco64"][0])
 
 
+LOSS_CASES = [   # seed, text, [(object name, (x, y))]
+    (31, "a cat to the left of a dog", [("The cat", (0.30, 0.40)), ("dog", (0.70, 0.60))]),
+    (32, "a bird above the bench", [("the bird", (0.05, 0.95)), ("Bench", (0.5, 0.2)), ("sky", (0.98, 0.02))]),   # crops clipped at the border
+    (33, "nothing in particular", []),
+]
+
+
+def gen_loss():
+    from oracle.golden_inputs import loss_image
+    from sta.synth import SyntheticCLIP
+    model = SyntheticCLIP()
+    out = {"n_cases": len(LOSS_CASES)}
+    with rh.reference_loss_env(model) as plms:
+        lm = plms.DCLIPLoss()
+        seen = []
+        enc = model.encode_image
+        model.encode_image = lambda img: (seen.append(img.detach().clone()), enc(img))[1]       # what CLIP is fed
+        for n, (seed, text, objs) in enumerate(LOSS_CASES):
+            img = loss_image(seed)
+            with torch.no_grad():
+                del seen[:]
+                l2 = lm.forward_2(img, text)                                                        # plms.py:252
+                l3, boxes = [], []
+                for name, (xc, yc) in objs:                                                         # plms.py:254-270, verbatim arithmetic
+                    x1, x2, y1, y2 = max(xc - 0.2, 0), min(xc + 0.2, 1), max(yc - 0.2, 0), min(yc + 0.2, 1)
+                    box = (int(512 * y1), int(512 * y2), int(512 * x1), int(512 * x2))
+                    obj = name.lower().replace("the ", "")
+                    l3.append(float(lm.forward_3(img[:, box[0]:box[1], box[2]:box[3]], "A photo of " + obj)))
+                    boxes.append(box)
+                total = float(l2) + 5 * sum(l3)                                                     # :273
+            out["case%d_loss2" % n] = np.float64(float(l2))
+            out["case%d_loss3" % n] = np.asarray(l3, dtype=np.float64)
+            out["case%d_boxes" % n] = np.asarray(boxes, dtype=np.int64).reshape(-1, 4)
+            out["case%d_total" % n] = np.float64(total)
+            out["case%d_fed" % n] = np.stack([s[0, :, ::7, ::7].numpy() for s in seen])            # [1+K, 3, 32, 32] of the 224^2 inputs
+            out["case%d_fed_sum" % n] = np.asarray([float(s.double().sum()) for s in seen])
+            out["case%d_img_sum" % n] = np.float64(float(img.double().sum()))
+    np.savez_compressed(os.path.join(OUT, "loss_frontend.npz"), **out)
+    print("loss_frontend.npz", [float(out["case%d_total" % n]) for n in range(len(LOSS_CASES))])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -244,7 +324,9 @@ def main():
     gen_schedule()
     gen_unet()
     gen_plms()
+    gen_config1()
     gen_prompts()
+    gen_loss()
 
 
 if __name__ == "__main__":

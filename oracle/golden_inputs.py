@@ -33,8 +33,16 @@ def input_checksum(x, context, local_ctx):
     return float(x.double().abs().sum() + context.double().abs().sum() + sum(c.double().abs().sum() for c in local_ctx))
 
 
-def unet_inputs(K, seed):
+def unet_inputs(K, seed, lat=LAT):
     c = seeded_tensor("c", (1, 77, 768), seed, 0.78)
     local_ctx = [seeded_tensor("c%d" % i, (1, 77, 768), seed, 0.78) for i in range(K)]
-    x = seeded_tensor("x", (1, 4, LAT, LAT), seed)
+    x = seeded_tensor("x", (1, 4, lat, lat), seed)
     return c, local_ctx, x
+
+
+def loss_image(seed, side=512):
+    """A [3, side, side] image in [0, 1] for the loss front-end fixture: smooth blobs + noise (so that resizing and
+    pooling are not no-ops), rebuilt from the seed on both sides."""
+    low = seeded_tensor("img_low", (1, 3, side // 32, side // 32), seed)
+    up = torch.nn.functional.interpolate(low, size=(side, side), mode="bicubic", align_corners=False)[0]
+    return torch.sigmoid(up + 0.5 * seeded_tensor("img_noise", (3, side, side), seed))

@@ -8,8 +8,14 @@ What has to be faked to import the hot-path modules:
   * `torchvision`  — only used by the debug `plot` (attention.py:217-221) and a Resize inside the
                      CLIP loss (plms.py:17,27);
   * `omegaconf.listconfig.ListConfig` — imported inside UNetModel.__init__ (openaimodel.py:476);
-  * `clip`         — plms.py:11, only touched by DCLIPLoss.__init__, which we never construct.
+  * `clip`         — plms.py:11, only touched by DCLIPLoss.__init__ / forward_2 / forward_3.
 These are inert module objects placed in sys.modules; they provide no behaviour of the reference.
+For the loss front-end golden (G8, `reference_loss_env`) two of them carry behaviour of the PINNED third-party
+packages, not of the reference: `clip.load` hands back the frozen stand-in model sta.synth.SyntheticCLIP (the real
+OpenAI CLIP is unpinned and its weights are not available: the golden pins everything AROUND it — x7 upsample +
+16x16 average pool, crop + resize, 1 - cosine), and `torchvision.transforms.Resize` is restated as torchvision
+0.12.0 (environment_replicate.yml:10) implements it for tensors: bilinear, align_corners=False, NO antialiasing.
+`Tensor.cuda()` / `.to("cuda")` are made no-ops there (device placement only; the box has no GPU).
 The reference reads `uncond_fix_radius_0p2_g0.pt` and `c{i}_fix_radius_0p2_g0.pt` relative to the
 cwd (attention.py:234,246), so everything runs inside a scratch directory prepared here.
 """
@@ -52,6 +58,47 @@ def _install_stubs():
         sys.modules["omegaconf.listconfig"] = lc
     if "clip" not in sys.modules:
         sys.modules["clip"] = types.ModuleType("clip")
+
+
+class _Tokens:
+    """What the `clip.tokenize` stand-in returns: remembers the text (SyntheticCLIP.encode_text hashes str(x))."""
+
+    def __init__(self, texts):
+        self.text = texts[0]
+
+    def to(self, *a, **k):
+        return self
+
+    def __str__(self):
+        return self.text
+
+
+@contextlib.contextmanager
+def reference_loss_env(clip_model):
+    """The reference's DCLIPLoss (plms.py:21-61) runnable on CPU around `clip_model`. Yields the reference's plms module."""
+    import torch.nn.functional as F
+
+    class Resize(torch.nn.Module):            # torchvision 0.12.0, tensor input: F.interpolate(bilinear, align_corners=False)
+        def __init__(self, size):
+            super().__init__()
+            self.size = tuple(size)
+
+        def forward(self, img):
+            return F.interpolate(img.unsqueeze(0).float(), size=self.size, mode="bilinear", align_corners=False).squeeze(0)
+
+    with reference_env() as ref:
+        tvt = sys.modules["torchvision.transforms"]
+        clip = sys.modules["clip"]
+        saved = (tvt.Resize, getattr(clip, "load", None), getattr(clip, "tokenize", None), torch.Tensor.cuda)
+        tvt.Resize = Resize
+        ref.plms.transforms.Resize = Resize
+        clip.load = lambda name, device=None, **k: (clip_model, None)
+        clip.tokenize = lambda texts: _Tokens(texts)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            yield ref.plms
+        finally:
+            tvt.Resize, clip.load, clip.tokenize, torch.Tensor.cuda = saved
 
 
 def load_uncond():

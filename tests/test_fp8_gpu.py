@@ -1,0 +1,116 @@
+"""fp8 (OCP e4m3) weights for the transformer-block Linears — BASELINE configs[4] — on the GPU: the row quantiser
+(csrc/sta_fp8.hip) against a plain-torch fp32 restatement, the fp8 GEMM layer against the 16-bit layer, and the UNet /
+a 768x768-shaped 4-object trajectory with fp8 weights against the same model in 16 bit. The reference has no fp8
+path (it runs fp16 autocast): the tolerance is therefore stated against OUR 16-bit path, which is pinned to the
+reference's goldens elsewhere."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import golden_inputs as gi  # noqa: E402
+from sta.synth import seeded_fill_  # noqa: E402
+
+G = gi.GOLDEN
+
+
+@pytest.mark.parametrize("rows,C", [(131072, 320), (1000, 640), (77, 5120), (5, 8), (4096, 2560)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_quant_rows_fp8(rows, C, dtype):
+    """scale = rowmax|x| / 448, xq = e4m3(x / scale): the HIP kernel vs the same arithmetic in torch (fp32 math, torch's
+    round-to-nearest-even cast). The kernel multiplies by 1/scale instead of dividing, so a value may land on the other
+    side of a rounding tie: at most one e4m3 step apart, for a vanishing fraction of the elements."""
+    from sta import fp8
+    g = torch.Generator().manual_seed(rows + C)
+    x = (torch.randn(rows, C, generator=g) * torch.rand(rows, 1, generator=g) * 3).to(dtype)
+    x[0] = 0                                         # an all-zero row: scale 1, codes 0
+    xq, scale = fp8.quant_rows(x.cuda())
+    torch.cuda.synchronize()
+    amax = x.float().abs().amax(dim=1, keepdim=True)
+    ref_scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.equal(scale.cpu(), ref_scale)
+    ref = (x.float() / ref_scale).to(torch.float8_e4m3fn)
+    got, want = xq.cpu().float(), ref.float()
+    diff = (got - want).abs()
+    assert (diff <= 0.126 * want.abs() + 2 ** -9).all()            # one e4m3 step = 2^-3 relative (2^-9 absolute for subnormals)
+    assert (diff > 0).float().mean() < 2e-3
+    assert got[0].abs().max() == 0 and got.abs().max() <= 448.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_fp8_linear_vs_16bit(dtype):
+    from sta import fp8
+    g = torch.Generator().manual_seed(3)
+    lin = torch.nn.Linear(640, 1280).to("cuda", dtype)
+    x = torch.randn(2, 1024, 640, generator=g).to("cuda", dtype)
+    with torch.no_grad():
+        ref = lin(x).float()
+        got = fp8.Fp8Linear.from_linear(lin)(x).float()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    assert got.shape == ref.shape and rel < 0.04, rel            # two e4m3 operands: ~2^-4 per product, averaged over K = 640 terms
+
+
+def _golden_unet(dtype):
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    meta = json.load(open(os.path.join(G, "unet_state_dict_keys.json")))
+    unet = UNetModel(**meta["cfg"]).eval()
+    seeded_fill_(unet, 21)
+    for p in unet.parameters():
+        p.requires_grad_(False)
+    return unet.to("cuda", dtype)
+
+
+def test_unet_eps_fp8_weights_vs_16bit_and_reference():
+    """One CFG UNet call with e4m3 Linear weights in all 16 transformer blocks vs the same UNet in fp16 and vs the
+    REFERENCE's fp32 epsilon (G4). Stated tolerance vs the reference: max-abs <= 6 % of max|eps|, mean-abs <= 3 % of mean|eps|."""
+    from sta import fp8, prompt_state
+    g = np.load(os.path.join(G, "unet_eps.npz"))
+    c, local_ctx, _ = gi.unet_inputs(2, int(g["input_seed"]))
+    outs = {}
+    for tag in ("fp16", "fp8"):
+        unet = _golden_unet(torch.float16)
+        if tag == "fp8":
+            n, before, after = fp8.convert_transformer_linears_(unet)
+            assert n == 16 * 7 and after < 0.52 * before
+        prompt_state.begin_prompt([l.cuda() for l in local_ctx], first_timestep=981)
+        with torch.no_grad():
+            outs[tag] = unet(torch.from_numpy(g["x_in"]).cuda(), 0, torch.from_numpy(g["t"]).cuda(),
+                             context=torch.cat([gi.load_uncond(), c]).cuda().half(), coef=torch.from_numpy(g["coef"]).cuda(),
+                             bboxs_curr=[list(cc) for cc in g["centres"]]).float().cpu().numpy()
+    ref = g["eps"]
+    for tag, tol_max, tol_mean in (("fp16", 24 * 2.0 ** -11, 12 * 2.0 ** -11), ("fp8", 0.06, 0.03)):
+        err = np.abs(outs[tag] - ref)
+        print("%s vs reference: max %.4f mean %.4f (relative)" % (tag, err.max() / np.abs(ref).max(), err.mean() / np.abs(ref).mean()))
+        assert err.max() <= tol_max * np.abs(ref).max() and err.mean() <= tol_mean * np.abs(ref).mean(), tag
+    assert np.abs(outs["fp8"] - outs["fp16"]).max() > 0             # the fp8 path really ran
+
+
+def test_config5_fp8_weights_trajectory():
+    """BASELINE configs[4] in miniature: 96x96 latent (768x768), 4 objects, fp8 Linear weights, hipGraph replay, 4 PLMS
+    steps vs the same sampler with 16-bit weights. Stated tolerance on x0: max-abs <= 8 %, mean-abs <= 4 % of the 16-bit
+    result's max / mean magnitude."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    from sta import fp8
+    from sta.pipeline import DEFAULT_CENTRES
+    K, S, lat = 4, 4, 96
+    c, local_ctx, x_T = gi.unet_inputs(K, 77, lat)
+    x0 = {}
+    for tag in ("fp16", "fp8"):
+        unet = _golden_unet(torch.float16)
+        if tag == "fp8":
+            fp8.convert_transformer_linears_(unet)
+        sampler = PLMSSampler(LatentDiffusion(unet_config=unet).cuda(), opt_epochs=0, use_graph=True, save_images=False)
+        sampler.sample(S=S, conditioning=c.cuda(), batch_size=1, shape=[4, lat, lat], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=gi.load_uncond().cuda(), eta=0.0, x_T=x_T.cuda(), text_index=0, curr_text="p",
+                       bboxs_curr=[list(cc) for cc in DEFAULT_CENTRES[:K]], seed=1, prompt_idx=0, object_names=list("abcd"),
+                       local_conditionings=[l.cuda() for l in local_ctx])
+        x0[tag] = sampler.last_result["x0"].float().cpu()
+    err = (x0["fp8"] - x0["fp16"]).abs()
+    print("config5 fp8 vs fp16: max %.4f mean %.4f" % (err.max() / x0["fp16"].abs().max(), err.mean() / x0["fp16"].abs().mean()))
+    assert torch.isfinite(x0["fp8"]).all()
+    assert err.max() <= 0.08 * x0["fp16"].abs().max() and err.mean() <= 0.04 * x0["fp16"].abs().mean()

@@ -305,3 +305,93 @@ def test_weight_optimisation_epochs_move_W():
     assert len(r["losses"]) == 1 and r["image"].shape == (1, 3, 16, 16)
     step = (r["W"] - 2.5).abs()
     assert torch.allclose(step, torch.full_like(step, 0.005), atol=1e-4)   # first Adam step has size lr everywhere
+
+
+def test_loss_front_end_matches_reference():
+    """G8: the product's DCLIPLoss front-ends and `_fidelity_loss` (crop rule, object-name normalisation, weight 5) vs
+    the REFERENCE's DCLIPLoss.forward_2 / forward_3 (plms.py:21-45) run around the same frozen stand-in CLIP, on the
+    crops of plms.py:254-270: the 224^2 images handed to CLIP, each loss term and the total."""
+    from ldm.models.diffusion.plms import DCLIPLoss, PLMSSampler, object_crop_box
+    from oracle.gen_golden import LOSS_CASES
+    from sta.synth import SyntheticCLIP
+    g = _load("loss_frontend.npz")
+    model = SyntheticCLIP()
+    fed = []
+    enc = model.encode_image
+    model.encode_image = lambda img: (fed.append(img.detach().clone()), enc(img))[1]
+    lm = DCLIPLoss(model)
+    sampler = object.__new__(PLMSSampler)
+    sampler.clip_loss_model, sampler.local_loss_weight = lm, 5.0
+    assert int(g["n_cases"]) == len(LOSS_CASES)
+    for n, (seed, text, objs) in enumerate(LOSS_CASES):
+        img = gi.loss_image(seed)
+        assert abs(float(img.double().sum()) - float(g["case%d_img_sum" % n])) < 1e-3        # same seeded image
+        del fed[:]
+        with torch.no_grad():
+            total = sampler._fidelity_loss(img, text, [c for _, c in objs], [nm for nm, _ in objs])
+        boxes = [object_crop_box(c, 512, 512) for _, c in objs]
+        assert np.array_equal(np.asarray(boxes, dtype=np.int64).reshape(-1, 4), g["case%d_boxes" % n])
+        assert len(fed) == 1 + len(objs)
+        got = np.stack([f[0, :, ::7, ::7].numpy() for f in fed])
+        assert np.abs(got - g["case%d_fed" % n]).max() < 1e-6
+        assert np.allclose([float(f.double().sum()) for f in fed], g["case%d_fed_sum" % n], rtol=1e-6)
+        assert abs(float(total) - float(g["case%d_total" % n])) < 1e-5, (float(total), float(g["case%d_total" % n]))
+        with torch.no_grad():
+            assert abs(float(lm.forward_2(img, text)) - float(g["case%d_loss2" % n])) < 1e-6
+            for (nm, c), b, ref in zip(objs, boxes, g["case%d_loss3" % n]):
+                l3 = lm.forward_3(img[:, b[0]:b[1], b[2]:b[3]], "A photo of " + nm.lower().replace("the ", ""))
+                assert abs(float(l3) - float(ref)) < 1e-6
+
+
+def test_loss_model_is_checked_before_sampling():
+    """opt_epochs > 0 without a loss model fails BEFORE the first trajectory; DCLIPLoss tokenises through
+    the callable it is given (the reference's clip.tokenize, plms.py:31,38)."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import DCLIPLoss, PLMSSampler, load_clip_model
+    from sta.synth import SyntheticCLIP
+    unet, _ = _golden_unet()
+    model = LatentDiffusion(unet_config=unet)
+    calls = []
+    model.apply_model_extra = lambda *a, **k: calls.append(1)
+    c, local_ctx, x_T = gi.unet_inputs(2, 6)
+    sampler = PLMSSampler(model, opt_epochs=3, use_graph=False, save_images=False)
+    with pytest.raises(RuntimeError, match="loss_model"):
+        sampler.sample(S=5, conditioning=c, batch_size=1, shape=[4, 8, 8], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=gi.load_uncond(), x_T=x_T[:, :, :8, :8], text_index=0, curr_text="x",
+                       bboxs_curr=[[0.3, 0.4], [0.7, 0.6]], seed=1, prompt_idx=0, object_names=["a", "b"],
+                       local_conditionings=local_ctx)
+    assert not calls
+    seen = []
+    clip = SyntheticCLIP()
+    lm = DCLIPLoss(clip, tokenize=lambda texts: (seen.append(list(texts)), torch.zeros(1, 77, dtype=torch.long))[1])
+    clip.encode_text = lambda tok: (seen.append(tuple(tok.shape)), torch.ones(1, 512))[1]
+    lm.forward_2(torch.rand(3, 512, 512), "a cat")
+    assert seen == [["a cat"], (1, 77)]
+    with pytest.raises(RuntimeError, match="CLIP"):
+        load_clip_model(None, "cpu")                      # the OpenAI package is absent here: a clear error, not a late crash
+    m, tok = load_clip_model("sta.synth:synthetic_clip", "cpu")      # module:callable form
+    assert hasattr(m, "encode_image")
+
+
+def test_config1_trajectory_matches_reference():
+    """BASELINE configs[0] (G5b): one prompt, 64x64 latent, 10 PLMS steps, 1 object, through the PUBLIC sample() entry
+    (fixed weights W = 5/K, first timestep 901 announced to the blocks instead of the reference's `time == 981` test)
+    vs the reference's fp32 CPU trajectory."""
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import PLMSSampler
+    g = _load("plms_config1.npz")
+    unet, _ = _golden_unet()
+    seeded_fill_(unet, 21)
+    model = LatentDiffusion(unet_config=unet)
+    K, S, lat = int(g["K"]), int(g["S"]), int(g["lat"])
+    c, local_ctx, x_T = gi.unet_inputs(K, int(g["input_seed"]), lat)
+    assert abs(float(x_T.double().abs().sum()) - float(g["x_T_sum"])) < 1e-6 * float(g["x_T_sum"])
+    sampler = PLMSSampler(model, opt_epochs=0, use_graph=False, save_images=False)
+    with oracle_ops():
+        sampler.sample(S=S, conditioning=c, batch_size=1, shape=[4, lat, lat], verbose=False, unconditional_guidance_scale=float(g["scale"]),
+                       unconditional_conditioning=gi.load_uncond(), eta=0.0, x_T=x_T, text_index=0, curr_text="a prompt",
+                       bboxs_curr=[list(cc) for cc in g["centres"]], seed=1, prompt_idx=0, object_names=["thing"],
+                       local_conditionings=local_ctx)
+    x0 = sampler.last_result["x0"].numpy()
+    err = np.abs(x0 - g["x0"]).max() / np.abs(g["x0"]).max()
+    assert err < 2e-3, err

@@ -258,6 +258,29 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_self_attention_768_level0(dtype):
+    """BASELINE configs[4] (768x768): attn1 of level 0 has N = 9216 queries and keys (d = 40). The full fp64 score tensor
+    would be 11 GB, so 512 seeded query rows per (batch, head) are checked against softmax(q k^T scale) v in fp64 over
+    ALL 9216 keys, plus the rows of the last (partial-free) tile."""
+    from sta import ops
+    B, N, C, heads = 2, 9216, 320, 8
+    g = torch.Generator().manual_seed(9216)
+    qk = torch.randn(B, N, 2 * C, generator=g).to(dtype)
+    v = torch.randn(B, N, C, generator=g).to(dtype)
+    d, scale = C // heads, (C // heads) ** -0.5
+    out = ops.self_attention(qk[..., :C].cuda(), qk[..., C:].cuda(), v.transpose(1, 2).contiguous().cuda(), heads, scale)
+    torch.cuda.synchronize()
+    rows = torch.cat([torch.randperm(N, generator=g)[:512], torch.arange(N - 128, N)]).unique()
+    q64 = qk[:, rows, :C].double().view(B, len(rows), heads, d).transpose(1, 2)
+    k64 = qk[..., C:].double().view(B, N, heads, d).transpose(1, 2)
+    v64 = v.double().view(B, N, heads, d).transpose(1, 2)
+    ref = (torch.softmax(q64 @ k64.transpose(-1, -2) * scale, -1) @ v64).transpose(1, 2).reshape(B, len(rows), C)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (out[:, rows.cuda()].float().cpu().double() - ref).abs()
+    assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
+
+
 def test_self_attention_module_large_batch():
     """CrossAttention's inference path at CFG batch 40 (20 prompts per UNet call): q/k from one fused GEMM, V^T from ONE
     plain GEMM over the flattened batch. (A weight-broadcast batched matmul for V^T faulted inside the GEMM library from
@@ -316,7 +339,7 @@ PROJ_SHAPES = [
     (4096, 320, 8, 4, 2, None, 12),    # 4 objects (6 contexts + Wq = 144 KiB of LDS), 12-wave workgroups
     (1000, 160, 4, 3, 2, 3, 4),        # ragged N, d = 40 with 4 heads, forced tile count, 4-wave workgroups
     (1024, 320, 4, 1, 2, None, 0),     # d = 80: 50 KiB of Wq + 3 contexts
-    (576, 480, 8, 0, 1, None, 0),      # d = 60, no objects
+    (576, 480, 10, 0, 1, None, 0),     # d = 48 with 10 heads (15 k-steps: the short ring), no objects
     (9216, 320, 8, 4, 1, None, 0),     # BASELINE configs[4] level 0 (768^2, 4 objects)
 ]
 
@@ -368,5 +391,6 @@ def test_fwd_proj_rejects_what_it_cannot_hold():
     assert not ops.proj_supported(320, 8, 77, 5)
     L = lib.load()
     y = torch.zeros(2, 64, 640, device="cuda", dtype=torch.float16)
-    rc = L.sta_xattn_fwd_proj(y.data_ptr(), y.data_ptr(), y.data_ptr(), 0, 0, y.data_ptr(), 1, 64, 640, 8, 77, 0, 1.0, lib.STA_F16, 0)
+    rc = L.sta_xattn_fwd_proj(y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), 1, 64, 640, 8, 77, 2,
+                              1.0, lib.STA_F16, 0)
     assert rc == -2 and "LDS" in lib.last_error()

@@ -29,13 +29,15 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(100 + rank)                              # different garbage on every rank before the broadcast
     def make():    # Linear + norm + a channels_last (NHWC-strided) conv weight, as in the NHWC UNet trunk + a buffer
         m = torch.nn.Sequential(torch.nn.Linear(64, 96), torch.nn.LayerNorm(96), torch.nn.Linear(96, 8),
-                                torch.nn.Conv2d(16, 24, 3)).to(torch.bfloat16).to(memory_format=torch.channels_last)
+                                torch.nn.Conv2d(16, 24, 3), torch.nn.Linear(129, 131)).to(torch.bfloat16).to(memory_format=torch.channels_last)
         m.register_buffer("table", torch.randn(33))
         return m
     net = make()
     if rank == 0:
         synth.seeded_fill_(net, 7)
-    nbytes = parallel.broadcast_module_(net, src=0, bucket_bytes=4096)      # small buckets: several messages per dtype
+    # small buckets: several messages per dtype; the 129 x 131 Linear is one bucket of odd length that goes as
+    # scatter + all-gather with padding, the small ones as plain broadcasts
+    nbytes = parallel.broadcast_module_(net, src=0, bucket_bytes=4096)
     ref = make()
     synth.seeded_fill_(ref, 7)
     same = all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), ref.state_dict().values()))

@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--waves", type=int, nargs="*", default=[8, 12])
+    ap.add_argument("--rings", type=int, nargs="*", default=[5])
     ap.add_argument("--only", default=None, help="run only this arm (for rocprofv3): proj | gemm | attn")
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
@@ -55,12 +56,15 @@ def main():
             "attn": lambda: ops.xattn_forward(q, packed, mask, coef, scale),
             "gemm+attn": lambda: ops.xattn_forward(torch.nn.functional.linear(y, wq), packed, mask, coef, scale)}
     for w in a.waves:
-        def proj(w=w):
-            lib.set_option(lib.OPT_STAGED_WAVES, w)
-            r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
-            lib.set_option(lib.OPT_STAGED_WAVES, 0)
-            return r
-        arms["proj%d" % w] = proj
+        for ring in (a.rings if w != 12 else [5]):
+            def proj(w=w, ring=ring):
+                lib.set_option(lib.OPT_STAGED_WAVES, w)
+                lib.set_option(lib.OPT_PROJ_RING, ring)
+                r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
+                lib.set_option(lib.OPT_STAGED_WAVES, 0)
+                lib.set_option(lib.OPT_PROJ_RING, 0)
+                return r
+            arms["proj_w%d_r%d" % (w, ring)] = proj
     if a.only:
         arms = {k_: f for k_, f in arms.items() if k_.startswith(a.only)}
     res = {n: [] for n in arms}

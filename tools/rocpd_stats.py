@@ -52,7 +52,7 @@ if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "--break
 def category(n):
     if "naive_conv" in n:
         return "miopen-find (naive conv, warm-up only)"
-    if "xattn" in n or "pack_kv" in n or "dcoef_reduce" in n:
+    if "xattn" in n or "pack_kv" in n or "pack_wq" in n or "dcoef_reduce" in n:
         return "sta xattn (ours)"
     if "selfattn_fwd" in n:
         return "sta self-attention (ours)"
