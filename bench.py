@@ -212,6 +212,14 @@ def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps
     return out
 
 
+_T0 = time.perf_counter()
+
+
+def _phase(name):
+    """Wall-clock log of the bench's phases on stderr (the JSON line on stdout stays alone)."""
+    print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, name), file=sys.stderr, flush=True)
+
+
 def main():
     a = parse()
     from sta import parallel
@@ -277,8 +285,10 @@ def main():
                                  x_T=x_T1.expand(I, -1, -1, -1), unconditional_guidance_scale=7.5, seed=1)
         return sampler.last_result
 
+    _phase("model built")
     for j in range(a.warmup):
         one_step(j)
+    _phase("warm-up done (MIOpen solver search, graph capture)")
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -290,6 +300,7 @@ def main():
     elapsed = parallel.max_over_ranks(elapsed, dev)
     assert torch.isfinite(r["x0"]).all() and r["image"] is not None and r["x0"].shape[0] == I
 
+    _phase("timed region done")
     peak_gb = torch.cuda.max_memory_allocated() / 2 ** 30
     if rank != 0:
         return
@@ -368,6 +379,7 @@ def main():
             if hit:
                 best = max(hit, key=lambda r: float(r["total_ns"]))
                 out["roofline"]["rocprof_avg_us_committed"] = float(best["avg_ns"]) / 1e3
+    _phase("roofline leg done")
     if world == 1 and not a.no_side_runs and a.opt_epochs == 0:
         # reported beside the headline, never part of `value`: the other 16-bit type, and BASELINE configs[2]
         if a.other_dtype:
@@ -378,8 +390,10 @@ def main():
         out["weight_optimisation"] = side_run(dev, a.dtype, 3, 2, 1, 1, a.res, a.ddim_steps, K, find=False)
         out["weight_optimisation"]["config"] = "BASELINE configs[2]: %dx%d, %d PLMS steps, %d objects, 3 epochs of per-step blend-weight optimisation" % (
             a.res, a.res, a.ddim_steps, K)
+    _phase("side runs done")
     if not a.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(a.res, a.ddim_steps, K, a.cpu_calls)
+    _phase("cpu baseline done")
     print(json.dumps(out))
 
 

@@ -116,7 +116,7 @@ class CrossAttention(nn.Module):
             self._wqk8_src = self.to_q.weight_q
         b, n, c = x.shape
         xq, sx = _fp8.quant_rows(x.reshape(b * n, c))
-        qk = torch._scaled_mm(xq, self._wqk8.weight_q.t(), scale_a=sx, scale_b=self._wqk8.weight_scale, out_dtype=x.dtype).view(b, n, 2 * c)
+        qk = _fp8.scaled_mm(xq, self._wqk8.weight_q.t(), sx, self._wqk8.weight_scale, None, x.dtype).view(b, n, 2 * c)
         vt = self.to_v.forward_transposed(xq, sx, x.dtype).view(c, b, n).permute(1, 0, 2)
         o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
         return self.to_out(o)

@@ -35,6 +35,15 @@ def quant_rows(x2d):
     return xq, scale
 
 
+def scaled_mm(a_q, b_q, scale_a, scale_b, bias, out_dtype):
+    """e4m3 x e4m3 -> fp32 accumulators x (row scale x column scale) -> 16 bit. hipBLASLt's row-wise-scaled fp8 GEMM
+    writes bf16 only (ROCm 7.2 / torch 2.10: "rowwise _scaled_mm only supports BFloat16 output"), so an fp16 model takes
+    the bf16 result through one cast pass; values are GEMM outputs of O(1..100), far inside both ranges."""
+    out = torch._scaled_mm(a_q, b_q, scale_a=scale_a, scale_b=scale_b, bias=None if bias is None else bias.to(torch.bfloat16),
+                           out_dtype=torch.bfloat16)
+    return out if out_dtype == torch.bfloat16 else out.to(out_dtype)
+
+
 def quant_weight(w):
     """w [out, in] -> (wq [out, in] e4m3, scale [1, out] fp32): one scale per output channel."""
     amax = w.detach().float().abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
@@ -60,13 +69,12 @@ class Fp8Linear(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             raise RuntimeError("Fp8Linear is an inference layer (BASELINE configs[4] has fixed blend weights)")
         xq, sx = quant_rows(x.reshape(-1, self.in_features))
-        out = torch._scaled_mm(xq, self.weight_q.t(), scale_a=sx, scale_b=self.weight_scale, bias=self.bias, out_dtype=x.dtype)
+        out = scaled_mm(xq, self.weight_q.t(), sx, self.weight_scale, self.bias, x.dtype)
         return out.view(*x.shape[:-1], self.out_features)
 
     def forward_transposed(self, xq, sx, out_dtype):
         """W . x^T for an already quantised x: [out, R] (the self-attention kernel wants V transposed)."""
-        return torch._scaled_mm(self.weight_q, xq.t(), scale_a=self.weight_scale.t().contiguous(), scale_b=sx.t().contiguous(),
-                                out_dtype=out_dtype)
+        return scaled_mm(self.weight_q, xq.t(), self.weight_scale.t().contiguous(), sx.t().contiguous(), None, out_dtype)
 
 
 def convert_transformer_linears_(unet):

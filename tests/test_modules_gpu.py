@@ -365,9 +365,56 @@ def test_weight_optimisation_on_gpu(recompute):
     if len(_LOSSES) == 3:      # same forward maths whichever activations are kept (fused vs eager trunk: 16-bit noise)
         vals = list(_LOSSES.values())
         assert max(vals) - min(vals) <= 0.02 * abs(vals[0]) + 1e-3, _LOSSES
+    # not only consistent but RIGHT: the same epoch in fp32 on the host with the oracle's fused op (the combination the
+    # CPU suite pins to the reference) gives the loss and the direction of every first Adam step
+    ref = _weight_optimisation_reference()
+    assert abs(r["losses"][0] - ref["loss"]) <= 0.01 * abs(ref["loss"]), (r["losses"][0], ref["loss"])
+    got_sign, ref_sign = torch.sign(r["W"].cpu() - 2.5), torch.sign(ref["W"] - 2.5)
+    strong = ref["grad"].abs() > 0.05 * ref["grad"].abs().max()          # entries whose gradient is not lost in 16-bit noise
+    assert strong.float().mean() > 0.3 and (got_sign[strong] == ref_sign[strong]).float().mean() >= 0.95, \
+        (got_sign[strong] == ref_sign[strong]).float().mean()
 
 
 _LOSSES = {}
+_WOPT_REF = {}
+
+
+def _weight_optimisation_reference():
+    """First epoch of test_weight_optimisation_on_gpu in fp32 on the CPU with the oracle's differentiable fused op:
+    loss, dLoss/dW and W after one Adam step."""
+    if _WOPT_REF:
+        return _WOPT_REF
+    from ldm.models.autoencoder import AutoencoderKL
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import DCLIPLoss, PLMSSampler
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from sta.synth import SyntheticCLIP
+    from tests.cpu_backend import oracle_ops
+    meta = json.load(open(os.path.join(G, "unet_state_dict_keys.json")))
+    unet = UNetModel(**dict(meta["cfg"], use_checkpoint=False)).eval()
+    seeded_fill_(unet, 21)
+    vae = AutoencoderKL(ddconfig=dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32,
+                                      ch_mult=[1, 2, 4, 4], num_res_blocks=1, attn_resolutions=[], dropout=0.0))
+    seeded_fill_(vae, 3)
+    model = LatentDiffusion(unet_config=unet, first_stage_config=vae)
+    for p in model.parameters():
+        p.requires_grad_(False)
+    c, local_ctx, x_T = gi.unet_inputs(2, 6)
+    sampler = PLMSSampler(model, loss_model=DCLIPLoss(SyntheticCLIP()), opt_epochs=2, use_graph=False, save_images=False)
+    grads = []
+    orig_step = torch.optim.Adam.step
+    torch.optim.Adam.step = lambda self, *a, **k: (grads.append(self.param_groups[0]["params"][0].grad.clone()), orig_step(self, *a, **k))[1]
+    try:
+        with oracle_ops():
+            sampler.sample(S=6, conditioning=c, batch_size=1, shape=[4, 32, 32], verbose=False, unconditional_guidance_scale=7.5,
+                           unconditional_conditioning=gi.load_uncond(), x_T=x_T, text_index=0, curr_text="two things",
+                           bboxs_curr=[[0.3, 0.4], [0.7, 0.6]], seed=1, prompt_idx=0, object_names=["The cat", "dog"],
+                           local_conditionings=local_ctx)
+    finally:
+        torch.optim.Adam.step = orig_step
+    r = sampler.last_result
+    _WOPT_REF.update(loss=r["losses"][0], W=r["W"].clone(), grad=grads[0][0])
+    return _WOPT_REF
 
 
 def test_entry_point_script_end_to_end(tmp_path):
@@ -392,6 +439,28 @@ def test_entry_point_script_end_to_end(tmp_path):
         assert pngs == ["final0_s1_index_%d.png" % i for i in range(4)], pngs
         for f in pngs:
             os.remove(tmp_path / "result_outputs" / f)
+
+
+def test_entry_point_default_epochs(tmp_path):
+    """The reference's mode (3 optimisation epochs): without a CLIP model the script stops BEFORE building the model, with
+    `--clip synthetic` it runs the tracked epochs and names the image like the reference (final2_..., plms.py:286-288)."""
+    import subprocess
+    import sys
+    prompts = json.load(open(os.path.join(G, "prompts.json")))["mscoco64"][:1]
+    ds = tmp_path / "mscoco.txt"
+    ds.write_text(prompts[0]["prompt"])
+    (tmp_path / "layout.json").write_text(json.dumps({prompts[0]["prompt"]: {o: [0.3 + 0.4 * j, 0.5] for j, o in enumerate(prompts[0]["objects"])}}))
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(repo, "diffusion-spacetime-attn_amd", "scripts", "txt2img-mscoco.py")
+    base = [sys.executable, script, "--plms", "--ddim_steps", "3", "--synthetic", "--dataset", str(ds), "--layout", str(tmp_path / "layout.json"),
+            "--limit", "1", "--outdir", str(tmp_path / "o"), "--H", "256", "--W", "256"]
+    env = dict(os.environ, STA_CONV_FIND="0")
+    out = subprocess.run(base, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode != 0 and "--opt_epochs 3" in (out.stdout + out.stderr) and "CLIP" in (out.stdout + out.stderr)
+    assert not (tmp_path / "result_outputs").exists()
+    out = subprocess.run(base + ["--clip", "synthetic"], cwd=tmp_path, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert sorted(os.listdir(tmp_path / "result_outputs")) == ["final2_s1_index_0.png"]
 
 
 def test_smoke_entry():
