@@ -16,6 +16,15 @@ from ldm.modules.diffusionmodules.openaimodel import UNetModel
 from ldm.modules.encoders.modules import FrozenCLIPEmbedder, SyntheticTextEmbedder
 from sta import synth
 
+# MIOpen measures its solvers per convolution shape the first time it sees one (find mode, below): 6.5 minutes for the
+# fp16 UNet + VAE at 16 prompts per step on a fresh box, 7 s when its USER find-db already holds the answers. The db is
+# 30 KB of text keyed by (gfx950, MIOpen build): the one measured on an MI355X of the pool ships in sta/data/miopen_userdb
+# and is used unless the caller points MIOPEN_USER_DB_PATH elsewhere. A different MIOpen build ignores the file (its
+# name carries the build id) and searches as before; new shapes are searched and appended.
+USER_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "miopen_userdb")
+if os.path.isdir(USER_DB) and os.access(USER_DB, os.W_OK):
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", USER_DB)
+
 DEFAULT_CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]
 
 
