@@ -24,6 +24,7 @@
 #include "sta_xattn.h"
 #include "sta_internal.h"
 #include "sta_xattn_dev.h"
+#include "sta_xattn_proj2.h"
 
 namespace {
 
@@ -333,7 +334,8 @@ size_t sta_xattn_packed_wq_bytes(int C, int heads) {
   if (C <= 0 || heads <= 0 || C % heads || C % 32) return 0;
   const int d = C / heads;
   if (d % 8 || d > STA_MAX_HEAD_DIM) return 0;
-  return (size_t)heads * ((d + 15) / 16) * (C / 32) * FRAG;
+  // + the head-PAIR fragments (sta_xattn_proj2.hip) where that kernel applies
+  return (size_t)heads * ((d + 15) / 16) * (C / 32) * FRAG + (sta_pair::shape_ok(C, heads) ? sta_pair::wq_bytes(C, heads) : 0);
 }
 
 int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype, void* stream) {
@@ -348,13 +350,22 @@ int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype,
     hipLaunchKernelGGL(pack_wq_kernel<__bf16>, grid, dim3(64), 0, st, (const __bf16*)wq, (__bf16*)packed, C, d, ndt);
   else
     hipLaunchKernelGGL(pack_wq_kernel<_Float16>, grid, dim3(64), 0, st, (const _Float16*)wq, (_Float16*)packed, C, d, ndt);
+  if (sta_pair::shape_ok(C, heads)) {      // the same weights per head PAIR: 2d = 80 output columns = 5 tiles, no padding
+    char* pair = (char*)packed + (size_t)heads * ndt * (C / 32) * FRAG;
+    const dim3 g2(sta_pair::NT * (C / 32), heads / 2);
+    if (dtype == STA_BF16)
+      hipLaunchKernelGGL(pack_wq_kernel<__bf16>, g2, dim3(64), 0, st, (const __bf16*)wq, (__bf16*)pair, C, 2 * d, sta_pair::NT);
+    else
+      hipLaunchKernelGGL(pack_wq_kernel<_Float16>, g2, dim3(64), 0, st, (const _Float16*)wq, (_Float16*)pair, C, 2 * d, sta_pair::NT);
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_wq launch: %s", hipGetErrorString(e));
 }
 
 size_t sta_xattn_packed_kv_proj_bytes(int n_ctx, int heads, int d) {
   if (n_ctx <= 0 || heads <= 0 || d <= 0 || d % 8 || d > STA_MAX_HEAD_DIM) return 0;
-  return (size_t)n_ctx * heads * fwd_frags((d + 15) / 16) * FRAG;
+  // + the compact per-(ctx, head) blocks of the head-pair kernel where it applies (d = 40, even head count)
+  return (size_t)n_ctx * heads * fwd_frags((d + 15) / 16) * FRAG + ((d == sta_pair::D && heads % 2 == 0) ? sta_pair::kv_bytes(n_ctx, heads) : 0);
 }
 
 int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype,
@@ -375,6 +386,9 @@ int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx
   else
     hipLaunchKernelGGL(pack_kv_proj_kernel<_Float16>, grid, dim3(64), 0, st, (const _Float16*)k, (const _Float16*)v,
                        (_Float16*)packed, M, C, heads, d, ndt);
+  if (d == sta_pair::D && heads % 2 == 0 && M <= sta_pair::KROWS) {
+    if (int rc = sta_pair::pack_kv(k, v, (char*)packed + (size_t)n_ctx * heads * fwd_frags(ndt) * FRAG, n_ctx, M, C, heads, dtype, st)) return rc;
+  }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_kv_proj launch: %s", hipGetErrorString(e));
 }
@@ -399,6 +413,13 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
   p.sl2e = scale * 1.4426950408889634f;
   const int lds = proj_lds_bytes(C, heads, K);
   hipStream_t st = (hipStream_t)stream;
+  // head pairs share one read of y where both heads' operands fit a CU in compact form (d = 40, K <= 2)
+  if (sta_pair::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2) {
+    const int ndt = (p.d + 15) / 16;
+    const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
+    const char* kv_pair = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
+    return sta_pair::forward(y, wq_pair, kv_pair, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st);
+  }
   return dtype == STA_BF16 ? dispatch_proj<__bf16>(p, n_img, lds, st) : dispatch_proj<_Float16>(p, n_img, lds, st);
 }
 

@@ -1,0 +1,333 @@
+// sta_xattn_proj2.hip — the projection-fused forward for HEAD PAIRS (d = 40: SD-v1 level 0, K <= 2).
+//
+// Why a second kernel: sta_xattn_proj.hip is bound by the L2 -> L1 path — the y rows of a pixel tile are read once per
+// HEAD (8x the activation bytes, 671 MB per 16-image launch, arriving at 7.6 TB/s: profiles/r02_proj_fusion.md). One
+// workgroup can only serve two heads from one y read if BOTH heads' operands fit the CU's 160 KiB of LDS, and in MFMA
+// fragment order (keys padded 77 -> 80/96, head dim 40 -> 48/64) they do not: 2 x (30 + 4 x 19) = 212 KiB. Stored
+// COMPACTLY they do:
+//   Wq of the pair   80 output columns = 5 column tiles exactly (no padding)         5 x nkc KiB  = 50 KiB at C = 320
+//   K  per (ctx, head)   [80 keys][40 dims] row-major, keys 77..79 zero                 6400 B
+//   V^T per (ctx, head)  [41 rows = 40 dims + a row of ones][84 key slots], zero padded    6888 B
+//   -> 13 KiB per (ctx, head), 104 KiB for 4 contexts x 2 heads; 154 KiB + slack in total.
+// The K / V^T operand fragments are then assembled from two 8-byte LDS reads each (k-slots 8g .. 8g+3 and 8g+4 .. 8g+7
+// of a 16x16x32 MFMA are two runs of 4 consecutive dims / keys) instead of one 16-byte read of a pre-permuted
+// fragment. Slots that belong to no dim of the head read whatever finite bytes lie there; the OTHER operand (q, built
+// in registers) carries the zeros.
+//
+// The 80 projected columns of a pixel tile split as: head A = pair dims 0..39 = tiles 0, 1 and rows 0..7 of tile 2;
+// head B = pair dims 40..79 = rows 8..15 of tile 2 and tiles 3, 4. S^T k-slots (step s, half hf) take pair tile
+// tX0 + 2s + hf (tA0 = 0, tB0 = 2), i.e. head dims 16 (2s + hf) + 4g + r for A and 16 (2s + hf) + 4g + r - 8 for B.
+//
+// Reference replaced: ldm/modules/attention.py:178 (to_q), :175-197 (the K+2 attentions), :278-294 (masked blend) —
+// identical arithmetic to sta_xattn_fwd_proj; reached through the same C-ABI call (sta_xattn_proj.hip dispatches here).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "sta_xattn.h"
+#include "sta_internal.h"
+#include "sta_xattn_dev.h"
+#include "sta_xattn_proj2.h"
+
+namespace {
+
+using namespace sta_pair;
+
+// K, V [n_ctx][M][C] -> compact image [ctx][pair][head in pair][K block | V^T block], BLK bytes each.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kv_pair_kernel(const T* __restrict__ k, const T* __restrict__ v,
+                                                           T* __restrict__ packed, int M, int C, int H) {
+  const int ch = blockIdx.x;                  // ctx * H + h
+  const int ctx = ch / H, h = ch % H;
+  T* blk = (T*)((char*)packed + ((size_t)ctx * H + h) * BLK);       // [ctx][pair][hp] with h = 2 pair + hp
+  for (int i = threadIdx.x; i < BLK / 2; i += blockDim.x) {
+    T x = (T)0.0f;
+    if (i < KROWS * D) {
+      const int key = i / D, dd = i % D;
+      if (key < M) x = k[((size_t)ctx * M + key) * C + h * D + dd];
+    } else if (i < KROWS * D + VROWS * VSLOTS) {
+      const int j = i - KROWS * D;
+      const int row = j / VSLOTS, key = j % VSLOTS;
+      if (key < M) x = row < D ? v[((size_t)ctx * M + key) * C + h * D + row] : (T)1.0f;     // row D: ones (softmax denominator)
+    }
+    blk[i] = x;
+  }
+}
+
+struct P2 {
+  const void* y;
+  const char* wq;        // pair fragments: [pair][nkc][NT]
+  const char* kv;        // compact image: [I][K+2][pairs][2][BLK]
+  const uint8_t* mask;
+  const float* coef;
+  void* out;
+  int N, C, H, M, K, nkc, W, tiles, iters;
+  float sl2e;
+};
+
+typedef __attribute__((ext_vector_type(4))) unsigned short us4;      // 8 bytes of LDS: four 16-bit values
+
+// two 8-byte LDS reads -> one A operand (k-slots 0..3 | 4..7 of the lane)
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::V8 ld_pair(const char* lo, const char* hi) {
+  const us4 a = *(const us4*)lo, b = *(const us4*)hi;
+  typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+  const us8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(typename Tr<T>::V8, r);
+}
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::V8 ld_half(const char* lo) {     // k-slots 4..7 are zeros
+  const us4 a = *(const us4*)lo;
+  typedef __attribute__((ext_vector_type(8))) unsigned short us8;
+  const us8 r = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+  return __builtin_bit_cast(typename Tr<T>::V8, r);
+}
+
+// One context of one head from the compact image. kb: this lane's K base (block + c*2D + 8g, minus 16 for head B);
+// vb: its V^T base (block + K bytes + c*VS + 8g). KIND as in attend_staged.
+template <typename T, int KIND, int HB>
+__device__ __forceinline__ void attend_compact(const char* kb, const char* vb, const typename Tr<T>::V8 (&q)[2], const f32x4 kb4,
+                                               const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3]) {
+  using V8 = typename Tr<T>::V8;
+  // S^T = K Q^T: 5 key tiles x (step 0: both halves, step 1: first half only)
+  f32x4 st[1][NKT];
+  {
+    V8 k0[NKT], k1[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const char* row = kb + t * 16 * 2 * D;
+      k0[t] = ld_pair<T>(row, row + 32);                       // dims 4g.. | 16+4g..   (head B: base already shifted by -8 dims)
+      k1[t] = ld_half<T>(row + 64);                            // dims 32+4g.. | none
+    }
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      acc = Tr<T>::mfma(k0[t], q[0], acc);
+      acc = Tr<T>::mfma(k1[t], q[1], acc);
+      st[0][t] = acc;
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // V^T fragments: 3 key steps x 3 head-dim tiles; the last step has keys 64..79 only
+  V8 va[NPS][3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    const char* row = vb + u * 16 * VS;
+    va[0][u] = ld_pair<T>(row, row + 32);
+    va[1][u] = ld_pair<T>(row + 64, row + 96);
+    va[2][u] = ld_half<T>(row + 128);
+  }
+  softmax_biased(st[0], sl2e, false);                          // denominator comes out of the ones row of V^T
+  V8 pb[NPS];
+  tiles_to_b<T>(st[0], pb);
+  f32x4 o[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s][u], pb[s], acc);
+    o[u] = acc;
+  }
+  // row D = 40 of O^T = tile 2, row 8 = lane row g = 2, register 0
+  const float inv = __builtin_amdgcn_rcpf(__shfl(o[2][0], 32 + (int)(threadIdx.x & 15)));
+  const float wi = w * inv;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    if (KIND == 0) au[u] = o[u] * inv;
+    else if (KIND == 1) ac[u] = o[u] * inv;
+    else ac[u] = o[u] * wi + (ac[u] - au[u] * w);
+  }
+}
+
+// Workgroup = NWV waves x 16 pixels, one HEAD PAIR, one image; walks `iters` strided pixel tiles.
+template <typename T, int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_pair_kernel(const P2 p) {
+  using V8 = typename Tr<T>::V8;
+  constexpr int RING = 5;
+  constexpr int TP = 16 * NWV;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int PAIRS = p.H >> 1;
+  // block -> (image, tile group, pair): XCD-contiguous over the grid; the PAIRS workgroups of a tile group share y rows
+  const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int Lg = xcd_remap(lin, (int)(gridDim.x * gridDim.y));
+  const int img = Lg / (int)gridDim.x;
+  const int L = Lg - img * (int)gridDim.x;
+  const int wt = L / PAIRS, pr = L - wt * PAIRS;
+  const int N = p.N, C = p.C, K = p.K, nkc = p.nkc, W = p.W;
+  const unsigned row_bytes = (unsigned)C * (unsigned)sizeof(T);
+  const size_t act = (size_t)2 * N * row_bytes;
+  const char* yb = (const char*)p.y + img * act;
+  T* ob = (T*)((char*)p.out + img * act);
+  const uint8_t* mask = p.mask + (size_t)img * N;
+  const float coef_lane = p.coef[(size_t)img * K + min(lane, K > 0 ? K - 1 : 0)];
+  const int nwq = NT * nkc;                       // Wq fragments of the pair (1 KiB each)
+  char* lds_kv = smem + (size_t)nwq * FRAG;       // [ctx][hp][BLK]
+
+  // ---- prologue: LDS-DMA of the pair's Wq and of every context (both heads: 2 BLK contiguous per context) -----
+  stage_frags(p.wq + (size_t)pr * nwq * FRAG, smem, nwq, wv, NWV, lane);
+  {
+    const size_t ctx_stride = (size_t)PAIRS * 2 * BLK;
+    const char* src = p.kv + (size_t)img * (K + 2) * ctx_stride + (size_t)pr * 2 * BLK;
+    for (int c = 0; c < K + 2; ++c) stage_frags(src + c * ctx_stride, lds_kv + (size_t)c * 2 * BLK, 2 * BLK / FRAG, wv, NWV, lane);
+    // the V^T fragment reads of the last head-dim tile run 1.2 KiB past the last block (rows 41..47, never used):
+    // keep those bytes finite
+    char* tail = lds_kv + (size_t)(K + 2) * 2 * BLK;
+    if ((int)threadIdx.x * 16 < SLACK) *(u32x4*)(tail + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  const int mine = (p.tiles - wt + W - 1) / W;
+  const int iters = mine < p.iters ? mine : p.iters;
+  const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
+  const unsigned row1 = (unsigned)N * row_bytes;
+  auto tile_of = [&](int it) -> int { return wt + it * W; };
+  auto voff_of = [&](int it) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + c16;
+    return (it < iters && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
+  };
+  auto mask_of = [&](int it) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + c16;
+    return mask[(it < iters && px < N) ? px : 0];
+  };
+  V8 yr0[RING], yr1[RING];
+  unsigned voff = voff_of(0), voffn = voff_of(1);
+  unsigned mb = mask_of(0);
+#pragma unroll
+  for (int j = 0; j < RING; ++j) {
+    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
+    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
+  }
+  const f32x4 kb4 = last_tile_bias(g, p.M);
+  const float sl2e = p.sl2e;
+  const unsigned kmask = (1u << K) - 1u;
+  // per-lane offsets into a (ctx, head) block: K row of key c (+ 8g bytes = dims 4g..), V^T row of dim c (+ keys 4g..)
+  const int koff = c16 * 2 * D + 8 * g;
+  const int vofs = KBYTES + c16 * VS + 8 * g;
+  wait_dma_and_sync();
+
+  for (int it = 0; it < iters; ++it) {
+    // ---- projection: 5 column tiles x both batch rows ---------------------------------------------------------
+    f32x4 qa0[NT], qa1[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      qa0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      qa1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const V8* wf = (const V8*)smem + lane;
+    for (int s0 = 0; s0 < nkc; s0 += RING) {
+#pragma unroll
+      for (int j = 0; j < RING; ++j) {
+        const int s = s0 + j;
+        V8 a[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) a[u] = wf[(s * NT + u) * 64];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          qa0[u] = Tr<T>::mfma(a[u], yr0[j], qa0[u]);
+          qa1[u] = Tr<T>::mfma(a[u], yr1[j], qa1[u]);
+        }
+        const bool wrap = s + RING >= nkc;
+        const unsigned vo = wrap ? voffn : voff;
+        const unsigned so = 64u * (unsigned)(wrap ? s + RING - nkc : s + RING);
+        yr0[j] = srd_load16<V8>(y_srd, vo, so);
+        yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+      }
+    }
+    const int px_own = tile_of(it) * TP + wv * 16 + c16;
+    const bool valid = px_own < N;
+    voff = voffn;
+    voffn = voff_of(it + 2);
+    const unsigned mbn = mask_of(it + 1);
+    const unsigned mbits = valid ? (mb & kmask) : 0u;
+
+    // accumulators -> S^T B operands of both heads (rounded to T once). Tile 2 is shared: lane rows g < 2 hold
+    // head A's dims 32..39, lane rows g >= 2 head B's dims 0..7; the other head's slots are zeroed HERE.
+    const bool lowg = g < 2;
+    V8 qA0[2], qA1[2], qB0[2], qB1[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = j & 3;
+      // head A: step 0 = tiles 0 | 1, step 1 = tile 2 (g < 2) | zero
+      qA0[0][j] = (T)(j < 4 ? qa0[0][r] : qa0[1][r]);
+      qA1[0][j] = (T)(j < 4 ? qa1[0][r] : qa1[1][r]);
+      qA0[1][j] = j < 4 ? (lowg ? (T)qa0[2][r] : (T)0.0f) : (T)0.0f;
+      qA1[1][j] = j < 4 ? (lowg ? (T)qa1[2][r] : (T)0.0f) : (T)0.0f;
+      // head B: step 0 = tile 2 (g >= 2) | tile 3, step 1 = tile 4 | zero
+      qB0[0][j] = j < 4 ? (lowg ? (T)0.0f : (T)qa0[2][r]) : (T)qa0[3][r];
+      qB1[0][j] = j < 4 ? (lowg ? (T)0.0f : (T)qa1[2][r]) : (T)qa1[3][r];
+      qB0[1][j] = j < 4 ? (T)qa0[4][r] : (T)0.0f;
+      qB1[1][j] = j < 4 ? (T)qa1[4][r] : (T)0.0f;
+    }
+
+    // ---- attention + blend, head A then head B --------------------------------------------------------------
+    auto head = [&](auto hb_tag, const V8 (&q0)[2], const V8 (&q1)[2]) {
+      constexpr int HB = decltype(hb_tag)::value;
+      f32x4 au[3], ac[3];
+      // head B's K reads start 8 dims (16 bytes) before the row: its slot (step 0, first half) is dims 4g - 8
+      const char* blk = lds_kv + HB * BLK;
+      const char* kb = blk + koff - (HB ? 16 : 0);
+      const char* vb = blk + vofs;
+      attend_compact<T, 0, HB>(kb, vb, q0, kb4, sl2e, 0.f, au, ac);
+      attend_compact<T, 1, HB>(kb + 2 * BLK, vb + 2 * BLK, q1, kb4, sl2e, 0.f, au, ac);
+      for (int i = 0; i < K; ++i) {
+        if (!__ballot((mbits >> i) & 1u)) continue;
+        const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+        const float w = ((mbits >> i) & 1u) ? cw : 0.f;
+        attend_compact<T, 2, HB>(kb + (size_t)(2 + i) * 2 * BLK, vb + (size_t)(2 + i) * 2 * BLK, q1, kb4, sl2e, w, au, ac);
+      }
+      if (valid) {
+        T* obase = ob + (size_t)px_own * C + (2 * pr + HB) * D;
+        store_row16<T, 3>(obase, au, g, D);
+        store_row16<T, 3>(obase + (size_t)N * C, ac, g, D);
+      }
+    };
+    head(std::integral_constant<int, 0>{}, qA0, qA1);
+    head(std::integral_constant<int, 1>{}, qB0, qB1);
+    mb = mbn;
+  }
+}
+
+template <typename T, int NWV>
+int launch_pair(P2 p, int n_img, hipStream_t st) {
+  constexpr int TP = 16 * NWV;
+  const int pairs = p.H / 2;
+  p.tiles = (p.N + TP - 1) / TP;
+  long wg = 256L / ((long)pairs * n_img);          // workgroups per (pair, image): one round of one workgroup per CU
+  if (wg < 1) wg = 1;
+  if (wg > p.tiles) wg = p.tiles;
+  p.iters = (int)((p.tiles + wg - 1) / wg);
+  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
+  p.W = (p.tiles + p.iters - 1) / p.iters;
+  const int lds = lds_bytes(p.C, p.K);
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)xattn_fwd_proj_pair_kernel<T, NWV>, 160 * 1024))
+    return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj pair) failed");
+  hipLaunchKernelGGL((xattn_fwd_proj_pair_kernel<T, NWV>), dim3(p.W * pairs, n_img), dim3(64 * NWV), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj pair launch: %s", hipGetErrorString(e));
+}
+
+}  // namespace
+
+namespace sta_pair {
+
+int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype, hipStream_t st) {
+  const dim3 grid(n_ctx * heads);
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(pack_kv_pair_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)k, (const __bf16*)v, (__bf16*)packed, M, C, heads);
+  else
+    hipLaunchKernelGGL(pack_kv_pair_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)k, (const _Float16*)v, (_Float16*)packed, M, C, heads);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_kv_pair launch: %s", hipGetErrorString(e));
+}
+
+int forward(const void* y, const void* wq_pair, const void* kv_pair, const uint8_t* mask, const float* coef, void* out, int n_img,
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st) {
+  P2 p{};
+  p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv_pair; p.mask = mask; p.coef = coef; p.out = out;
+  p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.nkc = C / 32; p.sl2e = sl2e;
+  const int nwv = g_sta_opt[STA_OPT_STAGED_WAVES] == 4 ? 4 : 8;
+  if (dtype == STA_BF16) return nwv == 4 ? launch_pair<__bf16, 4>(p, n_img, st) : launch_pair<__bf16, 8>(p, n_img, st);
+  return nwv == 4 ? launch_pair<_Float16, 4>(p, n_img, st) : launch_pair<_Float16, 8>(p, n_img, st);
+}
+
+}  // namespace sta_pair

@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_selfattn.hip", "sta_unet.hip", "sta_fp8.hip")]
+SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj2.hip", "sta_selfattn.hip", "sta_unet.hip", "sta_fp8.hip")]
 
 # Self-attention keeps its MFMA accumulators in VGPRs: hipcc otherwise parks them in AGPRs and brackets the
 # online-softmax rescale with v_accvgpr_read/write pairs (120 extra VALU instructions per key block in a kernel
@@ -26,10 +26,11 @@ SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip"
 # it, masks are finite sentinels): fmaxf on MFMA outputs then compiles to bare v_max3 without quieting moves.
 # (Self-attention likewise: 1387 -> 1325 us at B=32, N=4096, d=40.)
 PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
-                    "sta_xattn.hip": ["-ffinite-math-only"], "sta_xattn_proj.hip": ["-ffinite-math-only"]}
+                    "sta_xattn.hip": ["-ffinite-math-only"], "sta_xattn_proj.hip": ["-ffinite-math-only"],
+                    "sta_xattn_proj2.hip": ["-ffinite-math-only"]}
 
 STA_BF16, STA_F16 = 0, 1
-OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_PROJ_RING = range(7)
+OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_PROJ_RING, OPT_PROJ_PAIR = range(8)
 FWD_STAGED, FWD_SPLIT = 1, 2
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
 
@@ -70,7 +71,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h")]
+    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h"), os.path.join(CSRC, "sta_xattn_proj2.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

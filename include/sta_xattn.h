@@ -66,6 +66,7 @@ enum {
   STA_OPT_HEAD_MAJOR = 4,   /* 1: block b -> head b % heads; 2: XCD-contiguous tile ranges */
   STA_OPT_SPLIT_QT = 5,     /* sub-tiles per wave of the split kernel: 1, 2, 4 */
   STA_OPT_PROJ_RING = 6,    /* sta_xattn_fwd_proj: k-steps of y in flight per row, 5 or 10 */
+  STA_OPT_PROJ_PAIR = 7,    /* sta_xattn_fwd_proj: 2 = one head per workgroup even where the head-pair kernel applies */
   STA_OPT_COUNT = 8
 };
 int sta_set_option(int key, int value);

@@ -332,21 +332,28 @@ def test_error_convention():
 # forward with the query projection inside (sta_xattn_fwd_proj)
 # ---------------------------------------------------------------------------------------------------
 PROJ_SHAPES = [
-    # N, C, heads, K, images, forced tiles per workgroup (None = heuristic), waves per workgroup (0 = default)
-    (256, 320, 8, 2, 1, None, 0),      # level-0 head dim, two 128-pixel tiles
-    (4096, 320, 8, 2, 4, None, 0),     # BASELINE level 0, 4 prompts: 4 strided tiles per workgroup
-    (4096, 320, 8, 2, 16, None, 0),    # the bench launch: 16 prompts, 16 tiles per workgroup
-    (4096, 320, 8, 4, 2, None, 12),    # 4 objects (6 contexts + Wq = 144 KiB of LDS), 12-wave workgroups
-    (1000, 160, 4, 3, 2, 3, 4),        # ragged N, d = 40 with 4 heads, forced tile count, 4-wave workgroups
-    (1024, 320, 4, 1, 2, None, 0),     # d = 80: 50 KiB of Wq + 3 contexts
-    (576, 480, 10, 0, 1, None, 0),     # d = 48 with 10 heads (15 k-steps: the short ring), no objects
-    (9216, 320, 8, 4, 1, None, 0),     # BASELINE configs[4] level 0 (768^2, 4 objects)
+    # N, C, heads, K, images, forced tiles per workgroup (None = heuristic), waves per workgroup (0 = default),
+    # pair (True: d = 40 and K <= 2 take the head-PAIR kernel, sta_xattn_proj2.hip; False: one head per workgroup forced)
+    (256, 320, 8, 2, 1, None, 0, True),      # level-0 head dim, two 128-pixel tiles
+    (256, 320, 8, 2, 1, None, 0, False),
+    (4096, 320, 8, 2, 4, None, 0, True),     # BASELINE level 0, 4 prompts
+    (4096, 320, 8, 2, 16, None, 0, True),    # the bench launch: 16 prompts, 4 head pairs x 4 workgroups per image, 8 tiles each
+    (4096, 320, 8, 2, 16, None, 0, False),   # 16 tiles per workgroup, one head each
+    (4096, 320, 8, 1, 3, None, 4, True),     # one object, 4-wave workgroups
+    (4096, 320, 8, 0, 2, None, 0, True),     # no objects
+    (1000, 160, 4, 2, 2, 3, 4, True),        # ragged N, 2 head pairs, forced tile count
+    (4096, 320, 8, 4, 2, None, 12, True),    # 4 objects do not fit as pairs -> per-head kernel (6 contexts + Wq = 144 KiB), 12 waves
+    (1000, 160, 4, 3, 2, 3, 4, True),        # K = 3: per-head kernel, ragged N, forced tile count, 4-wave workgroups
+    (1024, 320, 4, 1, 2, None, 0, True),     # d = 80: 50 KiB of Wq + 3 contexts (per head)
+    (576, 480, 10, 0, 1, None, 0, True),     # d = 48 with 10 heads (15 k-steps), no objects (per head)
+    (9216, 320, 8, 4, 1, None, 0, True),     # BASELINE configs[4] level 0 (768^2, 4 objects; per head)
+    (9216, 320, 8, 2, 2, None, 0, True),     # 768^2 with 2 objects: head pairs
 ]
 
 
-@pytest.mark.parametrize("N,C,heads,K,I,tiles,waves", PROJ_SHAPES)
+@pytest.mark.parametrize("N,C,heads,K,I,tiles,waves,pair", PROJ_SHAPES)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, dtype):
+def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, pair, dtype):
     """y -> to_q -> K+2 attentions -> blend in ONE kernel vs the oracle fed with q = round16(y Wq^T) (what the GEMM
     in front of sta_xattn_fwd would have produced), and vs the unfused GPU path on the same inputs."""
     from sta import lib, ops
@@ -365,10 +372,13 @@ def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, dtype):
         lib.set_option(lib.OPT_STAGED_TILES, tiles)
     if waves:
         lib.set_option(lib.OPT_STAGED_WAVES, waves)
+    if not pair:
+        lib.set_option(lib.OPT_PROJ_PAIR, 2)
     out = ops.xattn_forward_proj(y, ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I), mb, coef, scale)
     torch.cuda.synchronize()
     lib.set_option(lib.OPT_STAGED_TILES, 0)
     lib.set_option(lib.OPT_STAGED_WAVES, 0)
+    lib.set_option(lib.OPT_PROJ_PAIR, 0)
     q_gemm = torch.nn.functional.linear(y, wq.to(dev))
     unfused, _ = ops.xattn_forward(q_gemm, ops.pack_kv(k, v, heads, n_img=I), mb, coef, scale)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11

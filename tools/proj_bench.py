@@ -58,15 +58,24 @@ def main():
     for w in a.waves:
         for ring in (a.rings if w != 12 else [5]):
             def proj(w=w, ring=ring):
+                lib.set_option(lib.OPT_PROJ_PAIR, 2)
                 lib.set_option(lib.OPT_STAGED_WAVES, w)
                 lib.set_option(lib.OPT_PROJ_RING, ring)
                 r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
                 lib.set_option(lib.OPT_STAGED_WAVES, 0)
                 lib.set_option(lib.OPT_PROJ_RING, 0)
+                lib.set_option(lib.OPT_PROJ_PAIR, 0)
                 return r
             arms["proj_w%d_r%d" % (w, ring)] = proj
+    for w in (8, 4):
+        def pair(w=w):
+            lib.set_option(lib.OPT_STAGED_WAVES, w)
+            r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
+            lib.set_option(lib.OPT_STAGED_WAVES, 0)
+            return r
+        arms["pair_w%d" % w] = pair
     if a.only:
-        arms = {k_: f for k_, f in arms.items() if k_.startswith(a.only)}
+        arms = {k_: f for k_, f in arms.items() if k_.startswith(a.only) or (a.only == "proj" and k_.startswith("pair"))}
     res = {n: [] for n in arms}
     for _ in range(a.rounds):
         for n, f in arms.items():
@@ -76,7 +85,7 @@ def main():
     byts = I * (8.0 * N * C + 4.0 * (K + 2) * M * C + K * N) + 2.0 * C * C
     out = {"N": N, "C": C, "K": K, "imgs": I, "dtype": a.dtype, "us": res, "attn_gflop": f_attn / 1e9, "proj_gflop": f_proj / 1e9, "mbytes": byts / 1e6}
     for n, v_ in res.items():
-        if n.startswith("proj"):
+        if n.startswith("proj") or n.startswith("pair"):
             us = min(v_)
             out[n + "_tflops"] = round((f_attn + f_proj) / us / 1e6, 1)
             out[n + "_gbps"] = round(byts / us / 1e3, 1)
