@@ -413,8 +413,11 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
   p.sl2e = scale * 1.4426950408889634f;
   const int lds = proj_lds_bytes(C, heads, K);
   hipStream_t st = (hipStream_t)stream;
-  // head pairs share one read of y where both heads' operands fit a CU in compact form (d = 40, K <= 2)
-  if (sta_pair::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2) {
+  // Head pairs share one read of y where both heads' operands fit a CU in compact form (d = 40, K <= 2) and the
+  // launch still fills the chip with one pair workgroup per CU (level 0, 16 / 8 / 4 / 2 images: 73 / 42 / 25 / 16 us
+  // against 92 / 51 / 29 / 17 us one head per workgroup; one image: 128 pair workgroups, 14.8 vs 12.1 us).
+  const long pair_wgs = (long)((N + 127) / 128) * (heads / 2) * n_img;
+  if (sta_pair::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2 && (pair_wgs >= 256 || g_sta_opt[STA_OPT_PROJ_PAIR] == 1)) {
     const int ndt = (p.d + 15) / 16;
     const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
     const char* kv_pair = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;

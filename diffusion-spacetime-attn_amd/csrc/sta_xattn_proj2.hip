@@ -139,10 +139,9 @@ __device__ __forceinline__ void attend_compact(const char* kb, const char* vb, c
 }
 
 // Workgroup = NWV waves x 16 pixels, one HEAD PAIR, one image; walks `iters` strided pixel tiles.
-template <typename T, int NWV>
-__global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_pair_kernel(const P2 p) {
+template <typename T, int NWV, int RING>
+__global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_pair_kernel(const P2 p) {
   using V8 = typename Tr<T>::V8;
-  constexpr int RING = 5;
   constexpr int TP = 16 * NWV;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -202,9 +201,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_pair_kernel(const 
   // per-lane offsets into a (ctx, head) block: K row of key c (+ 8g bytes = dims 4g..), V^T row of dim c (+ keys 4g..)
   const int koff = c16 * 2 * D + 8 * g;
   const int vofs = KBYTES + c16 * VS + 8 * g;
+  STA_T_INIT();
+  STA_T(0);
   wait_dma_and_sync();
+  STA_T(1);
 
   for (int it = 0; it < iters; ++it) {
+    if (it == 1) STA_T(2);
     // ---- projection: 5 column tiles x both batch rows ---------------------------------------------------------
     f32x4 qa0[NT], qa1[NT];
 #pragma unroll
@@ -232,6 +235,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_pair_kernel(const 
         yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
       }
     }
+    if (it == 1) STA_T(3);
     const int px_own = tile_of(it) * TP + wv * 16 + c16;
     const bool valid = px_own < N;
     voff = voffn;
@@ -281,13 +285,17 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_pair_kernel(const 
       }
     };
     head(std::integral_constant<int, 0>{}, qA0, qA1);
+    if (it == 1) STA_T(4);
     head(std::integral_constant<int, 1>{}, qB0, qB1);
+    if (it == 1) STA_T(5);
     mb = mbn;
   }
+  STA_T(8);
+  STA_T_END();
 }
 
-template <typename T, int NWV>
-int launch_pair(P2 p, int n_img, hipStream_t st) {
+template <typename T, int NWV, int RING>
+int launch_pair_cfg(P2 p, int n_img, hipStream_t st) {
   constexpr int TP = 16 * NWV;
   const int pairs = p.H / 2;
   p.tiles = (p.N + TP - 1) / TP;
@@ -299,14 +307,30 @@ int launch_pair(P2 p, int n_img, hipStream_t st) {
   p.W = (p.tiles + p.iters - 1) / p.iters;
   const int lds = lds_bytes(p.C, p.K);
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_pair_kernel<T, NWV>, 160 * 1024))
+  if (!attr.ensure((const void*)xattn_fwd_proj_pair_kernel<T, NWV, RING>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj pair) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_pair_kernel<T, NWV>), dim3(p.W * pairs, n_img), dim3(64 * NWV), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_proj_pair_kernel<T, NWV, RING>), dim3(p.W * pairs, n_img), dim3(64 * NWV), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj pair launch: %s", hipGetErrorString(e));
 }
 
+template <typename T, int NWV>
+int launch_pair(const P2& p, int n_img, hipStream_t st) {
+  // ring depth 5 ships; 10 (the whole y row of the next tile in flight, 202 registers) measured slower here too
+  // (77.6 - 81.3 vs 73.0 - 76.3 us): the projection phase is not waiting for y any more (profiles/r02_proj_fusion.md)
+  if constexpr (NWV != 12) {
+    if (p.nkc % 10 == 0 && g_sta_opt[STA_OPT_PROJ_RING] == 10) return launch_pair_cfg<T, NWV, 10>(p, n_img, st);
+  }
+  return launch_pair_cfg<T, NWV, 5>(p, n_img, st);
+}
+
 }  // namespace
+
+#ifdef STA_TRACE
+extern "C" int sta_debug_set_trace_pair(void* buf) {      // trace build only (tools/trace_proj.py)
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 namespace sta_pair {
 
@@ -325,9 +349,10 @@ int forward(const void* y, const void* wq_pair, const void* kv_pair, const uint8
   P2 p{};
   p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv_pair; p.mask = mask; p.coef = coef; p.out = out;
   p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.nkc = C / 32; p.sl2e = sl2e;
-  const int nwv = g_sta_opt[STA_OPT_STAGED_WAVES] == 4 ? 4 : 8;
-  if (dtype == STA_BF16) return nwv == 4 ? launch_pair<__bf16, 4>(p, n_img, st) : launch_pair<__bf16, 8>(p, n_img, st);
-  return nwv == 4 ? launch_pair<_Float16, 4>(p, n_img, st) : launch_pair<_Float16, 8>(p, n_img, st);
+  const int nwv = g_sta_opt[STA_OPT_STAGED_WAVES] == 4 ? 4 : (g_sta_opt[STA_OPT_STAGED_WAVES] == 12 ? 12 : 8);
+  if (dtype == STA_BF16)
+    return nwv == 4 ? launch_pair<__bf16, 4>(p, n_img, st) : (nwv == 12 ? launch_pair<__bf16, 12>(p, n_img, st) : launch_pair<__bf16, 8>(p, n_img, st));
+  return nwv == 4 ? launch_pair<_Float16, 4>(p, n_img, st) : (nwv == 12 ? launch_pair<_Float16, 12>(p, n_img, st) : launch_pair<_Float16, 8>(p, n_img, st));
 }
 
 }  // namespace sta_pair

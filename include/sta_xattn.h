@@ -66,7 +66,7 @@ enum {
   STA_OPT_HEAD_MAJOR = 4,   /* 1: block b -> head b % heads; 2: XCD-contiguous tile ranges */
   STA_OPT_SPLIT_QT = 5,     /* sub-tiles per wave of the split kernel: 1, 2, 4 */
   STA_OPT_PROJ_RING = 6,    /* sta_xattn_fwd_proj: k-steps of y in flight per row, 5 or 10 */
-  STA_OPT_PROJ_PAIR = 7,    /* sta_xattn_fwd_proj: 2 = one head per workgroup even where the head-pair kernel applies */
+  STA_OPT_PROJ_PAIR = 7,    /* sta_xattn_fwd_proj: 1 = head-pair kernel whenever the shape allows, 2 = one head per workgroup */
   STA_OPT_COUNT = 8
 };
 int sta_set_option(int key, int value);
@@ -131,7 +131,8 @@ int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const 
  *   sta_xattn_fwd_proj      y: [n_img][2][N][C] = norm2(hidden); everything else as sta_xattn_fwd (no maps output)
  * Supported when sta_xattn_fwd_proj_supported(C, heads, M, K) != 0: d <= 96, C % 160 == 0, 64 < M <= 80 and the head's
  * Wq slice plus all K+2 contexts fit the 160 KiB LDS of a CU (SD-v1 level 0, C = 320: K <= 4). Other shapes take
- * the GEMM + sta_xattn_fwd.
+ * the GEMM + sta_xattn_fwd. At d = 40 with K <= 2 and an even head count a workgroup serves a head PAIR from one read
+ * of the y rows (compact per-(ctx, head) images, packed alongside by the same two pack calls).
  */
 int sta_xattn_fwd_proj_supported(int C, int heads, int M, int K);
 size_t sta_xattn_packed_wq_bytes(int C, int heads);

@@ -372,8 +372,7 @@ def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, pair, dtype):
         lib.set_option(lib.OPT_STAGED_TILES, tiles)
     if waves:
         lib.set_option(lib.OPT_STAGED_WAVES, waves)
-    if not pair:
-        lib.set_option(lib.OPT_PROJ_PAIR, 2)
+    lib.set_option(lib.OPT_PROJ_PAIR, 1 if pair else 2)      # pair: taken wherever the shape allows, whatever the launch size
     out = ops.xattn_forward_proj(y, ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I), mb, coef, scale)
     torch.cuda.synchronize()
     lib.set_option(lib.OPT_STAGED_TILES, 0)

@@ -67,13 +67,17 @@ def main():
                 lib.set_option(lib.OPT_PROJ_PAIR, 0)
                 return r
             arms["proj_w%d_r%d" % (w, ring)] = proj
-    for w in (8, 4):
-        def pair(w=w):
+    for w, ring in ((8, 5), (12, 5), (8, 10)):
+        def pair(w=w, ring=ring):
             lib.set_option(lib.OPT_STAGED_WAVES, w)
+            lib.set_option(lib.OPT_PROJ_PAIR, 1)
+            lib.set_option(lib.OPT_PROJ_RING, ring)
             r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
             lib.set_option(lib.OPT_STAGED_WAVES, 0)
+            lib.set_option(lib.OPT_PROJ_PAIR, 0)
+            lib.set_option(lib.OPT_PROJ_RING, 0)
             return r
-        arms["pair_w%d" % w] = pair
+        arms["pair_w%d_r%d" % (w, ring)] = pair
     if a.only:
         arms = {k_: f for k_, f in arms.items() if k_.startswith(a.only) or (a.only == "proj" and k_.startswith("pair"))}
     res = {n: [] for n in arms}

@@ -2,7 +2,8 @@
 per wave of one workgroup, shader-cycle deltas from kernel start to
  1 LDS image landed + barrier | 2 tile 1 begins | 3 tile-1 projection MFMAs issued | 4 ctx0 done | 5 ctx1 done |
  6 local contexts done | 7 stores issued | 8 all tiles done
-usage: trace_proj.py [images_per_launch] [wg,wg,...] [waves]"""
+(head-pair kernel, `pair` as 4th argument: 1 image landed | 2 tile 1 begins | 3 projection issued | 4 head A done | 5 head B done | 8 end)
+usage: trace_proj.py [images_per_launch] [wg,wg,...] [waves] [pair]"""
 import ctypes
 import os
 import subprocess
@@ -20,7 +21,9 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
                        "-I", lib.INCLUDE, "-I", lib.CSRC, *lib.SOURCES, "-o", out])
 lib.LIB_PATH = out
 L = lib.load()
-L.sta_debug_set_trace_proj.restype, L.sta_debug_set_trace_proj.argtypes = ctypes.c_int, [ctypes.c_void_p]
+PAIR = len(sys.argv) > 4 and sys.argv[4] == "pair"
+set_trace = L.sta_debug_set_trace_pair if PAIR else L.sta_debug_set_trace_proj
+set_trace.restype, set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
 
 dev = "cuda"
 I = int(sys.argv[1]) if len(sys.argv) > 1 else 16
@@ -36,17 +39,18 @@ mask = ops.disc_mask_bits([(0.3, 0.4), (0.7, 0.6)], 64).to(dev).repeat(I, 1)
 coef = torch.full((I, K), 2.5, device=dev)
 packed, wqf = ops.pack_kv_proj(k, v, H, n_img=I), ops.pack_wq(wq, H)
 lib.set_option(lib.OPT_STAGED_WAVES, NW)
+lib.set_option(lib.OPT_PROJ_PAIR, 1 if PAIR else 2)
 for wg in WGS:
     tr = torch.zeros(8 + 16 * 16, dtype=torch.int64, device=dev)
     tr[0] = wg
-    assert L.sta_debug_set_trace_proj(tr.data_ptr()) == 0
+    assert set_trace(tr.data_ptr()) == 0
     for _ in range(3):
         ops.xattn_forward_proj(y, wqf, packed, mask, coef, (C // H) ** -0.5)
     torch.cuda.synchronize()
     full = tr[8:].cpu().view(16, 16)[:NW]
     wall = (full[:, 14] - full[:, 15]).tolist()
     t = full[:, :14]
-    print("proj N=%d C=%d I=%d waves=%d wg=%d" % (N, C, I, NW, wg))
+    print("%s N=%d C=%d I=%d waves=%d wg=%d" % ("pair" if PAIR else "proj", N, C, I, NW, wg))
     base = min(t[w, 0].item() for w in range(NW))
     for w in range(NW):
         row = t[w].tolist()
