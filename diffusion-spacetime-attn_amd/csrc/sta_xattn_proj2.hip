@@ -84,9 +84,14 @@ __device__ __forceinline__ typename Tr<T>::V8 ld_half(const char* lo) {     // k
 
 // One context of one head from the compact image. kb: this lane's K base (block + c*2D + 8g, minus 16 for head B);
 // vb: its V^T base (block + K bytes + c*VS + 8g). KIND as in attend_staged.
-template <typename T, int KIND, int HB>
+struct NoFiller { __device__ __forceinline__ void operator()() const {} };
+
+// `filler` is issued between the S^T MFMAs and the softmax, in the same scheduling region as the V^T fragment reads and
+// the softmax VALU chain: the software-pipelined kernel passes a few k-steps of the NEXT tile's projection there, whose
+// MFMAs the scheduler can then place under this context's vector work.
+template <typename T, int KIND, int HB, typename F = NoFiller>
 __device__ __forceinline__ void attend_compact(const char* kb, const char* vb, const typename Tr<T>::V8 (&q)[2], const f32x4 kb4,
-                                               const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3]) {
+                                               const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3], F filler = F()) {
   using V8 = typename Tr<T>::V8;
   // S^T = K Q^T: 5 key tiles x (step 0: both halves, step 1: first half only)
   f32x4 st[1][NKT];
@@ -116,6 +121,7 @@ __device__ __forceinline__ void attend_compact(const char* kb, const char* vb, c
     va[1][u] = ld_pair<T>(row + 64, row + 96);
     va[2][u] = ld_half<T>(row + 128);
   }
+  filler();
   softmax_biased(st[0], sl2e, false);                          // denominator comes out of the ones row of V^T
   V8 pb[NPS];
   tiles_to_b<T>(st[0], pb);
@@ -294,6 +300,163 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_pa
   STA_T_END();
 }
 
+// Software-pipelined variant: the projection of tile it+1 runs INSIDE the attention of tile it — its 10 k-steps are
+// handed, 2-3 at a time, to the four mandatory attention sections of a tile (head A / B x contexts 0 / 1) as `filler`
+// (see attend_compact), so their MFMAs sit in the same scheduling region as a softmax. Straight-line code: the k-step
+// count is a template parameter (NKC = 10 at C = 320, 5 at C = 160), the y ring is RING = 5 deep as before. The
+// projection of the tile after the last is computed on zero rows and discarded.
+template <typename T, int NWV, int NKC>
+__global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_pair_sp_kernel(const P2 p) {
+  using V8 = typename Tr<T>::V8;
+  constexpr int RING = 5;
+  constexpr int TP = 16 * NWV;
+  static_assert(NKC % RING == 0, "k-steps per tile must be a multiple of the ring depth");
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int PAIRS = p.H >> 1;
+  const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int Lg = xcd_remap(lin, (int)(gridDim.x * gridDim.y));
+  const int img = Lg / (int)gridDim.x;
+  const int L = Lg - img * (int)gridDim.x;
+  const int wt = L / PAIRS, pr = L - wt * PAIRS;
+  const int N = p.N, C = p.C, K = p.K, W = p.W;
+  const unsigned row_bytes = (unsigned)C * (unsigned)sizeof(T);
+  const size_t act = (size_t)2 * N * row_bytes;
+  const char* yb = (const char*)p.y + img * act;
+  T* ob = (T*)((char*)p.out + img * act);
+  const uint8_t* mask = p.mask + (size_t)img * N;
+  const float coef_lane = p.coef[(size_t)img * K + min(lane, K > 0 ? K - 1 : 0)];
+  constexpr int nwq = NT * NKC;
+  char* lds_kv = smem + (size_t)nwq * FRAG;
+
+  stage_frags(p.wq + (size_t)pr * nwq * FRAG, smem, nwq, wv, NWV, lane);
+  {
+    const size_t ctx_stride = (size_t)PAIRS * 2 * BLK;
+    const char* src = p.kv + (size_t)img * (K + 2) * ctx_stride + (size_t)pr * 2 * BLK;
+    for (int c = 0; c < K + 2; ++c) stage_frags(src + c * ctx_stride, lds_kv + (size_t)c * 2 * BLK, 2 * BLK / FRAG, wv, NWV, lane);
+    char* tail = lds_kv + (size_t)(K + 2) * 2 * BLK;
+    if ((int)threadIdx.x * 16 < SLACK) *(u32x4*)(tail + threadIdx.x * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  const int mine = (p.tiles - wt + W - 1) / W;
+  const int iters = mine < p.iters ? mine : p.iters;
+  const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
+  const unsigned row1 = (unsigned)N * row_bytes;
+  auto tile_of = [&](int it) -> int { return wt + it * W; };
+  auto voff_of = [&](int it) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + c16;
+    return (it < iters && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
+  };
+  auto mask_of = [&](int it) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + c16;
+    return mask[(it < iters && px < N) ? px : 0];
+  };
+  // ring state: `voff` = rows of the tile being projected, `voffn` = rows of the tile after it
+  V8 yr0[RING], yr1[RING];
+  unsigned voff = voff_of(0), voffn = voff_of(1);
+  unsigned mb = mask_of(0);
+#pragma unroll
+  for (int j = 0; j < RING; ++j) {
+    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
+    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
+  }
+  const f32x4 kb4 = last_tile_bias(g, p.M);
+  const float sl2e = p.sl2e;
+  const unsigned kmask = (1u << K) - 1u;
+  const int koff = c16 * 2 * D + 8 * g;
+  const int vofs = KBYTES + c16 * VS + 8 * g;
+  const V8* wf = (const V8*)smem + lane;
+  f32x4 qn0[NT], qn1[NT];                          // projection accumulators of the tile being projected
+  // k-steps [S0, S1) of that projection (compile-time range): A fragments from LDS, 10 MFMAs and the ring refill each
+  auto ksteps = [&](auto s0_tag, auto s1_tag) {
+    constexpr int S0 = decltype(s0_tag)::value, S1 = decltype(s1_tag)::value;
+#pragma unroll
+    for (int s = S0; s < S1; ++s) {
+      const int j = s % RING;
+      V8 a[NT];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) a[u] = wf[(s * NT + u) * 64];
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        qn0[u] = Tr<T>::mfma(a[u], yr0[j], qn0[u]);
+        qn1[u] = Tr<T>::mfma(a[u], yr1[j], qn1[u]);
+      }
+      const bool wrap = s + RING >= NKC;           // compile time
+      const unsigned vo = wrap ? voffn : voff;
+      const unsigned so = 64u * (unsigned)(wrap ? s + RING - NKC : s + RING);
+      yr0[j] = srd_load16<V8>(y_srd, vo, so);
+      yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  // split of the NKC k-steps over the four mandatory attention sections
+  using I1 = std::integral_constant<int, (NKC * 1) / 4>;
+  using I2 = std::integral_constant<int, (NKC * 2) / 4>;
+  using I3 = std::integral_constant<int, (NKC * 3) / 4>;
+  using I4 = std::integral_constant<int, NKC>;
+  auto zero_q = [&]() {
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      qn0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      qn1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  wait_dma_and_sync();
+  zero_q();
+  ksteps(I0{}, I4{});                              // tile 0, not overlapped with anything
+  voff = voffn;
+  voffn = voff_of(2);
+
+  for (int it = 0; it < iters; ++it) {
+    const int px_own = tile_of(it) * TP + wv * 16 + c16;
+    const bool valid = px_own < N;
+    const unsigned mbn = mask_of(it + 1);
+    const unsigned mbits = valid ? (mb & kmask) : 0u;
+    // this tile's q operands from the finished accumulators; the accumulators then start the next tile
+    const bool lowg = g < 2;
+    V8 qA0[2], qA1[2], qB0[2], qB1[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = j & 3;
+      qA0[0][j] = (T)(j < 4 ? qn0[0][r] : qn0[1][r]);
+      qA1[0][j] = (T)(j < 4 ? qn1[0][r] : qn1[1][r]);
+      qA0[1][j] = j < 4 ? (lowg ? (T)qn0[2][r] : (T)0.0f) : (T)0.0f;
+      qA1[1][j] = j < 4 ? (lowg ? (T)qn1[2][r] : (T)0.0f) : (T)0.0f;
+      qB0[0][j] = j < 4 ? (lowg ? (T)0.0f : (T)qn0[2][r]) : (T)qn0[3][r];
+      qB1[0][j] = j < 4 ? (lowg ? (T)0.0f : (T)qn1[2][r]) : (T)qn1[3][r];
+      qB0[1][j] = j < 4 ? (T)qn0[4][r] : (T)0.0f;
+      qB1[1][j] = j < 4 ? (T)qn1[4][r] : (T)0.0f;
+    }
+    zero_q();
+
+    auto head = [&](auto hb_tag, const V8 (&q0)[2], const V8 (&q1)[2], auto f0, auto f1) {
+      constexpr int HB = decltype(hb_tag)::value;
+      f32x4 au[3], ac[3];
+      const char* blk = lds_kv + HB * BLK;
+      const char* kb = blk + koff - (HB ? 16 : 0);
+      const char* vb = blk + vofs;
+      attend_compact<T, 0, HB>(kb, vb, q0, kb4, sl2e, 0.f, au, ac, f0);
+      attend_compact<T, 1, HB>(kb + 2 * BLK, vb + 2 * BLK, q1, kb4, sl2e, 0.f, au, ac, f1);
+      for (int i = 0; i < K; ++i) {
+        if (!__ballot((mbits >> i) & 1u)) continue;
+        const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+        const float w = ((mbits >> i) & 1u) ? cw : 0.f;
+        attend_compact<T, 2, HB>(kb + (size_t)(2 + i) * 2 * BLK, vb + (size_t)(2 + i) * 2 * BLK, q1, kb4, sl2e, w, au, ac);
+      }
+      if (valid) {
+        T* obase = ob + (size_t)px_own * C + (2 * pr + HB) * D;
+        store_row16<T, 3>(obase, au, g, D);
+        store_row16<T, 3>(obase + (size_t)N * C, ac, g, D);
+      }
+    };
+    head(std::integral_constant<int, 0>{}, qA0, qA1, [&]() { ksteps(I0{}, I1{}); }, [&]() { ksteps(I1{}, I2{}); });
+    head(std::integral_constant<int, 1>{}, qB0, qB1, [&]() { ksteps(I2{}, I3{}); }, [&]() { ksteps(I3{}, I4{}); });
+    voff = voffn;
+    voffn = voff_of(it + 3);
+    mb = mbn;
+  }
+}
+
 template <typename T, int NWV, int RING>
 int launch_pair_cfg(P2 p, int n_img, hipStream_t st) {
   constexpr int TP = 16 * NWV;
@@ -314,8 +477,34 @@ int launch_pair_cfg(P2 p, int n_img, hipStream_t st) {
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj pair launch: %s", hipGetErrorString(e));
 }
 
+template <typename T, int NWV, int NKC>
+int launch_pair_sp(P2 p, int n_img, hipStream_t st) {
+  constexpr int TP = 16 * NWV;
+  const int pairs = p.H / 2;
+  p.tiles = (p.N + TP - 1) / TP;
+  long wg = 256L / ((long)pairs * n_img);
+  if (wg < 1) wg = 1;
+  if (wg > p.tiles) wg = p.tiles;
+  p.iters = (int)((p.tiles + wg - 1) / wg);
+  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
+  p.W = (p.tiles + p.iters - 1) / p.iters;
+  const int lds = lds_bytes(p.C, p.K);
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)xattn_fwd_proj_pair_sp_kernel<T, NWV, NKC>, 160 * 1024))
+    return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj pair sp) failed");
+  hipLaunchKernelGGL((xattn_fwd_proj_pair_sp_kernel<T, NWV, NKC>), dim3(p.W * pairs, n_img), dim3(64 * NWV), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj pair sp launch: %s", hipGetErrorString(e));
+}
+
 template <typename T, int NWV>
 int launch_pair(const P2& p, int n_img, hipStream_t st) {
+  if constexpr (NWV == 8) {      // software-pipelined build (projection of the next tile inside this tile's attention)
+    if (g_sta_opt[STA_OPT_PROJ_RING] == 2) {
+      if (p.nkc == 10) return launch_pair_sp<T, 8, 10>(p, n_img, st);
+      if (p.nkc == 5) return launch_pair_sp<T, 8, 5>(p, n_img, st);
+    }
+  }
   // ring depth 5 ships; 10 (the whole y row of the next tile in flight, 202 registers) measured slower here too
   // (77.6 - 81.3 vs 73.0 - 76.3 us): the projection phase is not waiting for y any more (profiles/r02_proj_fusion.md)
   if constexpr (NWV != 12) {

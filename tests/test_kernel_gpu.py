@@ -392,6 +392,32 @@ def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, pair, dtype):
         assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
 
 
+@pytest.mark.parametrize("N,C,heads,K,I", [(4096, 320, 8, 2, 16), (4096, 320, 8, 2, 3), (1000, 160, 4, 2, 2), (9216, 320, 8, 1, 2)])
+def test_fwd_proj_pair_software_pipelined(N, C, heads, K, I):
+    """The software-pipelined head-pair kernel (projection of tile t+1 issued inside the attention of tile t) computes
+    every accumulator in the same order as the plain pair kernel: outputs must be IDENTICAL, tile order, ragged tails
+    and the discarded projection past the last tile included."""
+    from sta import lib, ops
+    dtype, dev = torch.float16, "cuda"
+    g = torch.Generator().manual_seed(N + I)
+    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype).to(dev)
+    cases = [_case(N, C, heads, K, dtype, seed=90 + i) for i in range(I)]
+    y = torch.cat([c[0] for c in cases]).to(dev)
+    k = torch.cat([c[1] for c in cases]).to(dev)
+    v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    scale = (C // heads) ** -0.5
+    wqf, kvp = ops.pack_wq(wq, heads), ops.pack_kv_proj(k, v, heads, n_img=I)
+    lib.set_option(lib.OPT_PROJ_PAIR, 1)
+    plain = ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale)
+    lib.set_option(lib.OPT_PROJ_RING, 2)
+    piped = ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(plain, piped)
+    assert piped.float().abs().max() > 0
+
+
 def test_fwd_proj_rejects_what_it_cannot_hold():
     """Level 1 of SD-v1 (C = 640: 100 KiB of Wq + 4 contexts of 30 KiB) does not fit one CU's LDS: the C-ABI says so
     instead of launching, and the block then takes the GEMM + sta_xattn_fwd."""
