@@ -350,7 +350,7 @@ def main():
         pmc = os.path.join(REPO, "profiles", "xattn_fwd_hbm_traffic.json")
         if os.path.exists(pmc):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed per kernel and images-per-launch
             traffic = json.load(open(pmc)).get("by_kernel", {}).get("%s_N%d_C%d_I%d" % (dom + (I,)), {}).get("bytes_per_launch")
-        kname = {"proj": "xattn_fwd_proj_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch)",
+        kname = {"proj": "xattn_fwd_proj_pair_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, a head pair per workgroup)",
                  "attn": "xattn_fwd{,_staged}_kernel (QK^T + softmax + disc mask + blend + PV)"}[dom[0]]
         bound = "hbm" if t_hbm >= t_mfma else "mfma"
         out["roofline"] = {
@@ -374,7 +374,7 @@ def main():
         prof = os.path.join(REPO, "profiles", "r02_bench_kernel_stats.csv")
         if os.path.exists(prof):      # rocprofv3 --kernel-trace summary of this command, committed: the cross-check
             import csv
-            want = "xattn_fwd_proj_kernel" if dom[0] == "proj" else "xattn_fwd"
+            want = "xattn_fwd_proj" if dom[0] == "proj" else "xattn_fwd_staged"
             hit = [r for r in csv.DictReader(open(prof)) if want in r["kernel"]]
             if hit:
                 best = max(hit, key=lambda r: float(r["total_ns"]))
