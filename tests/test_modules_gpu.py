@@ -452,7 +452,7 @@ def test_entry_point_default_epochs(tmp_path):
     (tmp_path / "layout.json").write_text(json.dumps({prompts[0]["prompt"]: {o: [0.3 + 0.4 * j, 0.5] for j, o in enumerate(prompts[0]["objects"])}}))
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = os.path.join(repo, "diffusion-spacetime-attn_amd", "scripts", "txt2img-mscoco.py")
-    base = [sys.executable, script, "--plms", "--ddim_steps", "3", "--synthetic", "--dataset", str(ds), "--layout", str(tmp_path / "layout.json"),
+    base = [sys.executable, script, "--plms", "--ddim_steps", "4", "--synthetic", "--dataset", str(ds), "--layout", str(tmp_path / "layout.json"),
             "--limit", "1", "--outdir", str(tmp_path / "o"), "--H", "256", "--W", "256"]
     env = dict(os.environ, STA_CONV_FIND="0")
     out = subprocess.run(base, cwd=tmp_path, capture_output=True, text=True, timeout=300, env=env)
