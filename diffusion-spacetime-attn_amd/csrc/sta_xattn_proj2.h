@@ -12,12 +12,12 @@ constexpr int NT = 5;                       // 16-wide column tiles of a head pa
 constexpr int KROWS = 80;                   // key rows of a K block (77 real, the rest zero)
 constexpr int KBYTES = KROWS * D * 2;       // 6400
 constexpr int VROWS = D + 1;                // 40 head dims + the row of ones
-constexpr int VSLOTS = 84;                  // key slots per V^T row (>= 80, row stride 168 B: conflict-light LDS reads)
-constexpr int VS = VSLOTS * 2;              // 168
-constexpr int VBYTES = VROWS * VS;          // 6888
-constexpr int BLK = 13312;                  // one (ctx, head) block, K then V^T, padded to a multiple of 1 KiB
+constexpr int VSLOTS = 88;                  // key slots per V^T row (>= 80): row stride 176 B = 44 dwords = 4 x odd, so the
+constexpr int VS = VSLOTS * 2;              //   16 rows a ds_read_b64 touches start in 16 different 4-bank groups (no
+constexpr int VBYTES = VROWS * VS;          //   conflicts; 168 B measured 26 % conflict cycles). 7216 bytes
+constexpr int BLK = 13824;                  // one (ctx, head) block, K then V^T; a context's two blocks are 27 KiB
 constexpr int SLACK = 2048;                 // zeroed LDS behind the last block (over-reads of the unused V^T rows 41..47)
-static_assert(KBYTES + VBYTES <= BLK && BLK % 1024 == 0, "block layout");
+static_assert(KBYTES + VBYTES <= BLK && (2 * BLK) % 1024 == 0, "block layout");
 
 inline bool shape_ok(int C, int heads) { return heads > 0 && heads % 2 == 0 && C == heads * D && C % 160 == 0; }
 inline int lds_bytes(int C, int K) { return NT * (C / 32) * 1024 + (K + 2) * 2 * BLK + SLACK; }

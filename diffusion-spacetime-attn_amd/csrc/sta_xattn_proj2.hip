@@ -7,8 +7,8 @@
 // COMPACTLY they do:
 //   Wq of the pair   80 output columns = 5 column tiles exactly (no padding)         5 x nkc KiB  = 50 KiB at C = 320
 //   K  per (ctx, head)   [80 keys][40 dims] row-major, keys 77..79 zero                 6400 B
-//   V^T per (ctx, head)  [41 rows = 40 dims + a row of ones][84 key slots], zero padded    6888 B
-//   -> 13 KiB per (ctx, head), 104 KiB for 4 contexts x 2 heads; 154 KiB + slack in total.
+//   V^T per (ctx, head)  [41 rows = 40 dims + a row of ones][88 key slots], zero padded    7216 B
+//   -> 13.5 KiB per (ctx, head), 108 KiB for 4 contexts x 2 heads; with the slack exactly the 160 KiB of a CU.
 // The K / V^T operand fragments are then assembled from two 8-byte LDS reads each (k-slots 8g .. 8g+3 and 8g+4 .. 8g+7
 // of a 16x16x32 MFMA are two runs of 4 consecutive dims / keys) instead of one 16-byte read of a pre-permuted
 // fragment. Slots that belong to no dim of the head read whatever finite bytes lie there; the OTHER operand (q, built
