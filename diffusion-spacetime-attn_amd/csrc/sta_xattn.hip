@@ -784,6 +784,141 @@ __global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params pin) {
   }
 }
 
+// Backward on the LDS-RESIDENT structure of the staged forward: when the forward AND backward fragment images of all
+// K+2 contexts fit one CU's LDS together (d <= 48 with K <= 2: 4 x 38 KiB), a workgroup copies them once, passes ONE
+// barrier and walks `p.iters` strided pixel tiles with them — no barrier and no re-staging per context or per tile
+// (the kernel above stages one context at a time: 4 barriers and 152 KiB of LDS-DMA per 64 pixels). dcoef partials
+// accumulate in registers over the tiles; one fixed workspace slot per wave keeps the reduction deterministic.
+template <typename T, int NDT, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void xattn_bwd_staged_kernel(const Params pin) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)pin.K * gridDim.x * NWV);
+  constexpr int NKS = nks_of(NDT);
+  constexpr int CB = all_frags(NDT) * FRAG;
+  constexpr int TP = 16 * NWV;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  int wt, h;
+  if (p.H == 8) { wt = L >> 3; h = L & 7; } else { wt = L / p.H; h = L % p.H; }
+  const int N = p.N, C = p.C, d = p.d, K = p.K, W = p.ntiles;
+  const int mine = (p.tiles - wt + W - 1) / W;
+  const int iters = mine < p.iters ? mine : p.iters;
+
+  const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
+  const size_t ctx_stride = (size_t)p.H * CB;
+  const char* img_h = p.packed + (size_t)h * CB;
+  for (int c = 0; c < K + 2; ++c) stage_frags(img_h + c * ctx_stride, smem + (size_t)c * CB, all_frags(NDT), wv, NWV, lane);
+  float dc[MAXK];
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) dc[i] = 0.f;
+  const size_t row1 = (size_t)N * C;
+  wait_dma_and_sync();
+
+  for (int it = 0; it < iters; ++it) {
+    const int px = (wt + it * W) * TP + wv * 16 + c16;
+    const bool valid = px < N;
+    const unsigned ownbits = valid ? ((unsigned)p.mask[px] & ((1u << K) - 1u)) : 0u;
+    float w[MAXK];
+    float wsum = 0.f;
+    unsigned mybits = 0;
+#pragma unroll
+    for (int i = 0; i < MAXK; ++i) {
+      w[i] = 0.f;
+      if (i < K) {
+        const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+        if (__ballot((ownbits >> i) & 1u)) mybits |= 1u << i;
+        w[i] = ((ownbits >> i) & 1u) ? ci : 0.f;
+        wsum += w[i];
+      }
+    }
+    const T* qbase = (const T*)p.q + (size_t)(valid ? px : 0) * C + h * d;
+    const T* gbase = (const T*)p.dout + (size_t)(valid ? px : 0) * C + h * d;
+    V8 qf[NKS], gf[NKS], g1[NKS];
+    load_b_frags<T, NKS>(qbase, valid, g, d, qf);
+    load_b_frags<T, NKS>(gbase, valid, g, d, gf);
+    load_b_frags<T, NKS>(gbase + row1, valid, g, d, g1);
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gf[s][j] = (T)((float)gf[s][j] - wsum * (float)g1[s][j]);
+    f32x4 g1t[NDT];
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      const int dd = 16 * u + 4 * g;
+      g1t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (valid && dd < d) {
+        const V4 t4 = *(const V4*)(gbase + row1 + dd);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g1t[u][r] = (float)t4[r];
+      }
+    }
+    T* dqbase = (T*)p.out + (size_t)px * C + h * d;
+    f32x4 au[NDT], o[NDT], dq[NDT];
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // row 0: context 0 against dO0 - (sum_i coef_i mask_i) dO1; A_u is needed only where a disc touches the wave
+    if (mybits)
+      attend_bwd<T, NDT, true>(smem, qf, gf, p.scale, au, dq, lane, g, p.M, p.sl2e);
+    else
+      attend_bwd<T, NDT, false>(smem, qf, gf, p.scale, au, dq, lane, g, p.M, p.sl2e);
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) {
+        const int dd = 16 * u + 4 * g;
+        if (dd < d) {
+          V4 r0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) r0[r] = (T)dq[u][r];
+          *(V4*)(dqbase + dd) = r0;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    load_b_frags<T, NKS>(qbase + row1, valid, g, d, qf);
+    attend_bwd<T, NDT, false>(smem + CB, qf, g1, p.scale, o, dq, lane, g, p.M, p.sl2e);
+    for (int i = 0; i < K; ++i) {
+      if (!((mybits >> i) & 1u)) continue;
+      float wc = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXK; ++j) wc = (j == i) ? w[j] : wc;
+      attend_bwd<T, NDT, true>(smem + (size_t)(2 + i) * CB, qf, g1, p.scale * wc, o, dq, lane, g, p.M, p.sl2e);
+      float part = 0.f;
+#pragma unroll
+      for (int u = 0; u < NDT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part += g1t[u][r] * (o[u][r] - au[u][r]);
+      part = ((ownbits >> i) & 1u) ? part : 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXK; ++j) dc[j] += (j == i) ? part : 0.f;
+    }
+    if (valid) {
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) {
+        const int dd = 16 * u + 4 * g;
+        if (dd < d) {
+          V4 r1;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) r1[r] = (T)dq[u][r];
+          *(V4*)(dqbase + row1 + dd) = r1;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXK; ++i) {
+    if (i < K) {
+      float v = dc[i];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) p.aux[(size_t)i * gridDim.x * NWV + (size_t)blockIdx.x * NWV + wv] = v;
+    }
+  }
+}
+
 // Sum the per-wave partials in a fixed order: one block of 256 threads per object.
 __global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restrict__ part, float* dcoef,
                                                            int n) {
@@ -958,8 +1093,42 @@ int launch_fwd_qt(const Params& p, int qt, hipStream_t st) {
   return launch_fwd<T, NDT, 1>(p, st);
 }
 
+// LDS-resident backward: shapes whose K+2 full (forward + backward) images fit 160 KiB together.
+template <typename T, int NDT>
+int launch_bwd_staged(const Params& p0, float* dcoef, hipStream_t st) {
+  constexpr int NWV = 4;                                    // one wave per SIMD: the backward keeps > 256 registers live
+  constexpr int TP = 16 * NWV;
+  Params p = p0;
+  const int lds = (p.K + 2) * all_frags(NDT) * FRAG;
+  p.tiles = (p.N + TP - 1) / TP;
+  long wg_per_head = 256L / ((long)p.H * p.n_img);          // one workgroup per CU (its image takes the whole LDS)
+  if (wg_per_head < 1) wg_per_head = 1;
+  if (wg_per_head > p.tiles) wg_per_head = p.tiles;
+  p.iters = (int)((p.tiles + wg_per_head - 1) / wg_per_head);
+  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
+  p.ntiles = (p.tiles + p.iters - 1) / p.iters;            // workgroups per head
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)xattn_bwd_staged_kernel<T, NDT, NWV>, 160 * 1024)) return fail(STA_E_LAUNCH, "hipFuncSetAttribute(bwd staged) failed");
+  const int nwg = p.ntiles * p.H;
+  hipLaunchKernelGGL((xattn_bwd_staged_kernel<T, NDT, NWV>), dim3(nwg, p.n_img), dim3(64 * NWV), lds, st, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(STA_E_LAUNCH, "bwd staged launch: %s", hipGetErrorString(e));
+  if (p.K > 0) {
+    hipLaunchKernelGGL(dcoef_reduce_kernel, dim3(p.K, p.n_img), dim3(256), 0, st, p.aux, dcoef, nwg * NWV);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(STA_E_LAUNCH, "dcoef reduce launch: %s", hipGetErrorString(e));
+  }
+  return STA_OK;
+}
+
 template <typename T, int NDT>
 int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
+  if constexpr (NDT <= 3) {
+    const bool fits = (p.K + 2) * all_frags(NDT) * FRAG <= 160 * 1024;
+    const long tiles64 = (long)((p.N + 63) / 64) * p.H * p.n_img;
+    if (fits && g_sta_opt[STA_OPT_FWD_KERNEL] != 2 && (tiles64 >= 512 || g_sta_opt[STA_OPT_FWD_KERNEL] == 1))
+      return launch_bwd_staged<T, NDT>(p, dcoef, st);
+  }
   constexpr int lds = (bwd_double_buffered(NDT) ? 2 : 1) * all_frags(NDT) * FRAG + 16;
   static StaLdsAttr attr;
   if (!attr.ensure((const void*)xattn_bwd_kernel<T, NDT>, lds)) return fail(STA_E_LAUNCH, "hipFuncSetAttribute(bwd) failed");

@@ -59,7 +59,8 @@ const char* sta_last_error(void);
  * variables. Process-global, takes effect at the next launch; value 0 restores the automatic choice.
  */
 enum {
-  STA_OPT_FWD_KERNEL = 0,   /* 1: LDS-resident ("staged") kernel, 2: wave-per-context ("split") kernel */
+  STA_OPT_FWD_KERNEL = 0,   /* 1: LDS-resident ("staged") kernel, 2: wave-per-context ("split") kernel; the backward reads it
+                               the same way: 1 = LDS-resident multi-tile backward where it fits, 2 = one context at a time */
   STA_OPT_STAGED_TILES = 1, /* pixel tiles a staged workgroup walks (1..12) */
   STA_OPT_STAGED_WAVES = 2, /* waves per staged workgroup: 4, 8 or 12 */
   STA_OPT_STAGED_QT = 3,    /* 2: two 16-pixel sub-tiles per wave */

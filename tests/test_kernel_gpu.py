@@ -102,6 +102,54 @@ def test_bwd_matches_oracle(N, C, heads, K, dtype):
         assert ((dcoef - g).abs() <= tol).all(), (dcoef, g)
 
 
+@pytest.mark.parametrize("N,C,heads,K,I,tiles", [
+    (4096, 320, 8, 2, 1, None),    # level 0, one image: 256 workgroups x 2 tiles
+    (4096, 320, 8, 2, 3, None),    # 3 images: ragged tile count per workgroup
+    (256, 320, 8, 2, 2, 2),        # small launch, forced
+    (1000, 160, 4, 1, 3, 3),       # ragged N, 4 heads, forced tile count
+    (1024, 384, 8, 2, 2, None),    # d = 48
+    (1024, 320, 8, 0, 2, None),    # no objects
+])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_bwd_lds_resident_matches_oracle(N, C, heads, K, I, tiles, dtype):
+    """The LDS-resident multi-tile backward (all K+2 forward+backward images in LDS, no barrier per context) against the
+    fp64 oracle per image, and against the one-context-at-a-time kernel on the same launch (same arithmetic per pixel:
+    dq identical, dcoef equal up to the order of the per-wave partial sums)."""
+    from sta import lib, ops
+    dev = "cuda"
+    cases = [_case(N, C, heads, K, dtype, seed=50 + i) for i in range(I)]
+    q = torch.cat([c[0] for c in cases]).to(dev); k = torch.cat([c[1] for c in cases]).to(dev); v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    g = torch.Generator().manual_seed(17)
+    dout = torch.randn(2 * I, N, C, generator=g).to(dtype).to(dev)
+    scale = (C // heads) ** -0.5
+    packed = ops.pack_kv(k, v, heads, n_img=I)
+    lib.set_option(lib.OPT_FWD_KERNEL, lib.FWD_STAGED)
+    if tiles:
+        lib.set_option(lib.OPT_STAGED_TILES, tiles)
+    dq, dcoef = ops.xattn_backward(q, packed, mb, coef, dout, scale)
+    lib.set_option(lib.OPT_STAGED_TILES, 0)
+    lib.set_option(lib.OPT_FWD_KERNEL, lib.FWD_SPLIT)
+    dq1, dcoef1 = ops.xattn_backward(q, packed, mb, coef, dout, scale)
+    lib.set_option(lib.OPT_FWD_KERNEL, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(dq, dq1)
+    if K:
+        assert torch.allclose(dcoef, dcoef1, rtol=1e-4, atol=1e-3 * dcoef1.abs().max().item())
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for i in sorted({0, I - 1}):
+        qi, ki, vi, mi, ci = cases[i]
+        qd, cd = qi.double().requires_grad_(True), ci.double().requires_grad_(True)
+        orc.fused_xattn(qd, ki.double(), vi.double(), mi, cd, heads, scale).backward(dout[2 * i:2 * i + 2].cpu().double())
+        gs = qd.grad.abs().max().item()
+        assert (dq[2 * i:2 * i + 2].float().cpu().double() - qd.grad).abs().max() <= 6 * eps * gs + 1e-6
+        if K:
+            gc = cd.grad
+            tol = 0.02 * gc.abs() + 0.005 * gc.abs().max() + 1e-4 * math.sqrt(N * C)
+            assert ((dcoef.view(I, K)[i].cpu().double() - gc).abs() <= tol).all()
+
+
 @pytest.mark.parametrize("N,C,heads,K,M", [(64, 320, 8, 2, 80), (256, 320, 8, 2, 33), (16, 64, 8, 1, 77), (1024, 640, 8, 3, 1), (48, 1280, 8, 2, 16)])
 def test_key_count_and_tiny_latents(N, C, heads, K, M):
     """Edge cases of the key axis (M = 1 .. 80 = STA_MAX_KEYS; CLIP uses 77) and of the pixel axis (a single

@@ -57,6 +57,10 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--imgs", type=int, default=1)
     ap.add_argument("--level", type=int, default=-1, help="only this level (0..3) of the resolution")
+    ap.add_argument("--kernel", type=int, default=0, help="sta_set_option(STA_OPT_FWD_KERNEL): 0 auto, 1 LDS-resident, 2 split / one context at a time")
     a = ap.parse_args()
+    if a.kernel:
+        from sta import lib
+        lib.set_option(lib.OPT_FWD_KERNEL, a.kernel)
     for N, C in (LEVELS[a.res] if a.level < 0 else [LEVELS[a.res][a.level]]):
         print(json.dumps(bench_level(N, C, a.K, iters=a.iters, bwd=a.bwd, imgs=a.imgs)))
