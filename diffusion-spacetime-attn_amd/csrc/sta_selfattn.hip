@@ -42,6 +42,7 @@ template <> struct Tr<_Float16> {
 };
 
 constexpr int KB = 64;        // keys per block
+constexpr float RESCALE_LOG2 = 8.0f;   // see the deferred rescale in the kernel
 constexpr int FRAG = 1024;    // bytes per fragment
 
 struct SParams {
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #pragma unroll
     for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
     f32x4 st[QT][4];
+    __builtin_amdgcn_s_setprio(1);      // MFMA clusters at raised priority: +2 % (1405 -> 1377 us at B = 32, N = 4096, d = 40)
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #pragma unroll
         for (int s = 0; s < NKS; ++s) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
       }
+    __builtin_amdgcn_s_setprio(0);
     V8 va[NVF];
 #pragma unroll
     for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
@@ -238,12 +241,21 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(st[qt][2][0], st[qt][2][1]), fmaxf(st[qt][2][2], st[qt][2][3])),
                            fmaxf(fmaxf(st[qt][3][0], st[qt][3][1]), fmaxf(st[qt][3][2], st[qt][3][3]))));
       bm = bfly_max(bm);
-      const float mnew = fmaxf(mrun[qt], bm);
-      const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * p.sl2e);
-      mrun[qt] = mnew;
-      if constexpr (!SUMROW) lrun[qt] *= alpha;
+      // Deferred rescale: the running maximum (and with it the O^T accumulators, 12 multiplies + an exp per tile and
+      // block) is only moved when some pixel of the wave saw its maximum grow by more than 2^RESCALE_LOG2 since the last
+      // move; until then P = exp2(s - stale max) may reach 2^RESCALE_LOG2 = 256, well inside fp16 / bf16, and the
+      // ones row of V^T (or lrun) sums the same P, so the ratio O / l is unchanged. Wave-uniform branch. Measured
+      // 1385 -> 1344 us at B = 32, N = 4096, d = 40 (neutral at d = 80); both sides of the branch are forced in
+      // tests/test_kernel_gpu.py::test_self_attention_deferred_rescale_branches.
+      if (__any((bm - mrun[qt]) * p.sl2e > RESCALE_LOG2)) {
+        const float mnew = fmaxf(mrun[qt], bm);
+        const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * p.sl2e);
+        mrun[qt] = mnew;
+        if constexpr (!SUMROW) lrun[qt] *= alpha;
 #pragma unroll
-      for (int u = 0; u < NDT; ++u) o[qt][u] *= alpha;
+        for (int u = 0; u < NDT; ++u) o[qt][u] *= alpha;
+      }
+      const float mnew = mrun[qt];
       const float off = mnew * p.sl2e;
       float rs = 0.f;
 #pragma unroll
@@ -261,12 +273,14 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
         for (int j = 0; j < 8; ++j) pb[qt][s2][j] = (T)st[qt][2 * s2 + (j >> 2)][j & 3];
     }
     // O^T += V^T P^T
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int u = 0; u < NDT; ++u)
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][u] = Tr<T>::mfma(va[s2 * NDT + u], pb[qt][s2], o[qt][u]);
+    __builtin_amdgcn_s_setprio(0);
   }
 
 #pragma unroll

@@ -329,6 +329,38 @@ def test_self_attention_768_level0(dtype):
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_self_attention_deferred_rescale_branches(dtype):
+    """The running maximum of the online softmax is moved only when a pixel's maximum grew by more than 2^8 since the
+    last move (sta_selfattn.hip). Inputs that force both sides of that branch at chosen key blocks: (a) keys whose norm
+    ramps up along the sequence, so the maximum creeps up by less than the threshold per block but far more than it in
+    total (the stale maximum must be refreshed several times); (b) spiked keys late in the sequence that lift the maximum
+    of SOME queries of a wave by >> 2^8 in one block (all 16 pixels of the wave rescale, the others by a factor ~1);
+    (c) a spike in the very last, partial block. Reference: fp64 softmax over all keys."""
+    from sta import ops
+    B, N, C, heads = 2, 1000, 320, 8            # N % 64 != 0: the last block is partial
+    d, scale = C // heads, (C // heads) ** -0.5
+    g = torch.Generator().manual_seed(123)
+    q = torch.randn(B, N, C, generator=g)
+    k = torch.randn(B, N, C, generator=g) * (0.3 + 2.7 * torch.arange(N).view(1, N, 1) / N)        # (a)
+    for key, px in ((700, 5), (701, 260), (990, 17)):                                                 # (b), (c)
+        k[:, key] = 4.0 * q[:, px]
+    v = torch.randn(B, N, C, generator=g)
+    q, k, v = (t.to(dtype) for t in (q, k, v))
+    out = ops.self_attention(q.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda(), heads, scale)
+    torch.cuda.synchronize()
+    q64 = q.double().view(B, N, heads, d).transpose(1, 2)
+    k64 = k.double().view(B, N, heads, d).transpose(1, 2)
+    v64 = v.double().view(B, N, heads, d).transpose(1, 2)
+    logits = q64 @ k64.transpose(-1, -2) * scale
+    assert (logits.max(-1).values - logits[..., :64].max(-1).values).max() * 1.4427 > 40      # the maximum really moves late
+    ref = (torch.softmax(logits, -1) @ v64).transpose(1, 2).reshape(B, N, C)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (out.float().cpu().double() - ref).abs()
+    assert torch.isfinite(out).all()
+    assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
+
+
 def test_self_attention_module_large_batch():
     """CrossAttention's inference path at CFG batch 40 (20 prompts per UNet call): q/k from one fused GEMM, V^T from ONE
     plain GEMM over the flattened batch. (A weight-broadcast batched matmul for V^T faulted inside the GEMM library from

@@ -1,0 +1,43 @@
+"""A/B harness for kernel experiments: builds the library once per flag set into gpurun_out/libsta_<tag>.so and runs a
+tool script against each build in its own process, `rounds` times interleaved.
+usage: lib_ab.py <tool.py> [tool args ...] -- tag1=-DFLAG1,-DFLAG2 tag2= ...   (an empty flag list = the product build)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd"))
+from sta import lib  # noqa: E402
+
+sep = sys.argv.index("--")
+tool, variants = sys.argv[1:sep], sys.argv[sep + 1:]
+rounds = int(os.environ.get("AB_ROUNDS", "2"))
+libs = {}
+for v in variants:
+    tag, flags = v.split("=", 1)
+    out = os.path.join(ROOT, "build", "ab", "libsta_%s.so" % tag)      # build/ is git-ignored but travels to the GPU box
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    libs[tag] = out
+    if os.path.exists(out) and os.environ.get("AB_REBUILD") != "1":
+        continue
+    objs = []
+    for src in lib.SOURCES:
+        obj = out + "." + os.path.basename(src) + ".o"
+        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", lib.INCLUDE, "-I", lib.CSRC,
+               *lib.PER_SOURCE_FLAGS.get(os.path.basename(src), []), *[f for f in flags.split(",") if f], "-c", src, "-o", obj]
+        objs.append((subprocess.Popen(cmd), obj))
+    for pr, _ in objs:
+        assert pr.wait() == 0
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *[o for _, o in objs], "-o", out])
+    for _, o in objs:
+        os.remove(o)
+    libs[tag] = out
+for r in range(rounds):
+    for tag, path in libs.items():
+        code = "import sys; sys.argv=%r; sys.path.insert(0, %r); from sta import lib; lib.LIB_PATH=%r; __file__=%r; exec(open(__file__).read())" % (
+            tool, os.path.join(ROOT, "diffusion-spacetime-attn_amd"), path, os.path.abspath(tool[0]))
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+        for line in out.stdout.strip().splitlines():
+            print("[%s r%d] %s" % (tag, r, line))
+        if out.returncode:
+            print(out.stderr[-500:])
