@@ -16,34 +16,9 @@
 // Online softmax over 64-key blocks; K/V^T fragments of a block are copied to LDS once per workgroup by
 // LDS-DMA with per-lane source addresses (global_load_lds_dwordx4) and double-buffered.
 
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include "sta_xattn.h"
-#include "sta_internal.h"
+#include "sta_selfattn_dev.h"
 
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
-template <typename T> struct Tr;
-template <> struct Tr<__bf16> {
-  using V8 = bf16x8;
-  using V4 = bf16x4;
-  static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-};
-template <> struct Tr<_Float16> {
-  using V8 = f16x8;
-  using V4 = f16x4;
-  static __device__ __forceinline__ f32x4 mfma(V8 a, V8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
-};
-
-constexpr int KB = 64;        // keys per block
-constexpr float RESCALE_LOG2 = 8.0f;   // see the deferred rescale in the kernel
-constexpr int FRAG = 1024;    // bytes per fragment
 
 struct SParams {
   const void* q;    // [B][N][ldq]
@@ -53,6 +28,7 @@ struct SParams {
   int B, N, C, H, d, ldq, ldk;
   long vt_rs, vt_bs;   // row (channel) and batch strides of vt in elements: [B][C][N] -> (N, C*N); [C][B*N] -> (B*N, N)
   float sl2e;       // scale * log2(e)
+  float* lse;       // optional [B][H][N]: log2-domain log-sum-exp of the scaled scores (what the backward kernels re-derive P from)
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem_sa[];
@@ -73,9 +49,6 @@ __device__ __forceinline__ float bfly_sum(float x) {
   auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
-
-// key (within a 64-key block) held by row i of S^T tile T
-__device__ __forceinline__ int tile_key(int T, int i) { return 32 * (T >> 1) + 8 * (i >> 2) + 4 * (T & 1) + (i & 3); }
 
 // SUMROW (head dims that are not a multiple of 16, e.g. 40): the first PADDED row of V^T is set to ones in
 // registers, so the PV MFMAs accumulate the softmax denominator as row d of O^T — 16 v_add per 64 keys per query
@@ -286,17 +259,20 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int px = px0 + 16 * qt + c16;
-    float inv;
+    float l;
     if constexpr (SUMROW) {   // denominator = row d of O^T: tile NDT-1, row d % 16 = 4*g_s + r_s, held by the lanes of lane row g_s
       const int rs_ = d & 15, g_s = rs_ >> 2, r_s = rs_ & 3;
-      float l = 0.f;
+      float lr = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) l = (r == r_s) ? o[qt][NDT - 1][r] : l;
-      inv = 1.0f / __shfl(l, 16 * g_s + c16);
+      for (int r = 0; r < 4; ++r) lr = (r == r_s) ? o[qt][NDT - 1][r] : lr;
+      l = __shfl(lr, 16 * g_s + c16);
     } else {
-      inv = 1.0f / bfly_sum(lrun[qt]);
+      l = bfly_sum(lrun[qt]);
     }
+    const float inv = 1.0f / l;
     if (px >= N) continue;
+    if (p.lse && g == 0)                   // P = exp2(s * sl2e - lse): exact whether or not the running maximum is stale
+      p.lse[((size_t)b * p.H + h) * N + px] = mrun[qt] * p.sl2e + __builtin_amdgcn_logf(l);
     T* ob = (T*)p.out + ((size_t)b * N + px) * C + h * d;
 #pragma unroll
     for (int u = 0; u < NDT; ++u) {
@@ -343,9 +319,9 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, int B, int N, int C,
-                                int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
-                                void* stream) {
+static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int N, int C,
+                            int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
+                            void* stream) {
   g_sta_err[0] = 0;
   if (!q || !k || !vt || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (B < 1 || B > 65535 || N < 8 || N % 8 || C <= 0 || heads <= 0 || C % heads)
@@ -356,7 +332,20 @@ extern "C" int sta_selfattn_fwd(const void* q, const void* k, const void* vt, vo
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   if (vt_row_stride < N || vt_row_stride % 8 || vt_batch_stride % 8)
     return sta_fail(STA_E_ARG, "selfattn: vt strides (%ld, %ld) must be multiples of 8 with row stride >= N", vt_row_stride, vt_batch_stride);
-  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, scale * 1.4426950408889634f};
+  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, scale * 1.4426950408889634f, lse};
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_sa<__bf16>(p, st) : dispatch_sa<_Float16>(p, st);
+}
+
+extern "C" int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, int B, int N, int C,
+                                int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
+                                void* stream) {
+  return selfattn_fwd_any(q, k, vt, out, nullptr, B, N, C, heads, ldq, ldk, vt_row_stride, vt_batch_stride, scale, dtype, stream);
+}
+
+extern "C" int sta_selfattn_fwd_lse(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int N, int C,
+                                    int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
+                                    void* stream) {
+  if (!lse) return sta_fail(STA_E_ARG, "null pointer");
+  return selfattn_fwd_any(q, k, vt, out, lse, B, N, C, heads, ldq, ldk, vt_row_stride, vt_batch_stride, scale, dtype, stream);
 }

@@ -78,6 +78,9 @@ class CrossAttention(nn.Module):
         h = self.heads
         if context is None and not torch.is_grad_enabled() and _ops.self_attention_supported(x, h):
             return self._self_attention_hip(x)
+        if context is None and isinstance(self.to_q, nn.Linear) and _ops.self_attention_train_supported(x, h) \
+                and not (self.to_q.weight.requires_grad or self.to_k.weight.requires_grad or self.to_v.weight.requires_grad):
+            return self._self_attention_tracked(x)
         context = x if context is None else context
         b, n, _ = x.shape
         q = self.to_q(x).view(b, n, h, -1).transpose(1, 2)
@@ -85,6 +88,17 @@ class CrossAttention(nn.Module):
         v = self.to_v(context).view(b, context.shape[1], h, -1).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
         return self.to_out(o.transpose(1, 2).reshape(b, n, -1))
+
+    def _self_attention_tracked(self, x):
+        """attn1 with autograd (the tracked weight-optimisation epochs, frozen weights): ONE GEMM against [Wq; Wk; Wv], the HIP
+        forward that keeps the log-sum-exp, and the HIP backward kernels (sta.ops.SelfAttentionQKV) instead of PyTorch's SDPA —
+        whose backward was the largest kernel of the tracked epochs (profiles/r02_config3_breakdown.txt)."""
+        ws = (self.to_q.weight, self.to_k.weight, self.to_v.weight)
+        key = tuple((w.data_ptr(), w._version) for w in ws)
+        if getattr(self, "_wqkv_key", None) != key:
+            self._wqkv, self._wqkv_key = torch.cat([w.detach() for w in ws]), key
+        o = _ops.SelfAttentionQKV.apply(F.linear(x, self._wqkv), self.heads, self.scale)
+        return self.to_out(o)
 
     def _self_attention_hip(self, x):
         """attn1 without autograd: the flash-style HIP kernel (csrc/sta_selfattn.hip). q and k come out of ONE

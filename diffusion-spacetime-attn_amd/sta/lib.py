@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj2.hip", "sta_selfattn.hip", "sta_unet.hip", "sta_fp8.hip")]
+SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj2.hip", "sta_selfattn.hip", "sta_selfattn_bwd.hip", "sta_unet.hip", "sta_fp8.hip")]
 
 # Self-attention keeps its MFMA accumulators in VGPRs: hipcc otherwise parks them in AGPRs and brackets the
 # online-softmax rescale with v_accvgpr_read/write pairs (120 extra VALU instructions per key block in a kernel
@@ -26,6 +26,7 @@ SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip"
 # it, masks are finite sentinels): fmaxf on MFMA outputs then compiles to bare v_max3 without quieting moves.
 # (Self-attention likewise: 1387 -> 1325 us at B=32, N=4096, d=40.)
 PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
+                    "sta_selfattn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
                     "sta_xattn.hip": ["-ffinite-math-only"], "sta_xattn_proj.hip": ["-ffinite-math-only"],
                     "sta_xattn_proj2.hip": ["-ffinite-math-only"]}
 
@@ -52,6 +53,8 @@ SYMBOLS = {
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
+    "sta_selfattn_fwd_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
+    "sta_selfattn_bwd": (_i, [_vp] * 13 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_groupnorm_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "sta_geglu": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "sta_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
@@ -71,7 +74,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h"), os.path.join(CSRC, "sta_xattn_proj2.h")]
+    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h"), os.path.join(CSRC, "sta_xattn_proj2.h"), os.path.join(CSRC, "sta_selfattn_dev.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

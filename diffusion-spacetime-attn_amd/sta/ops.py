@@ -301,6 +301,66 @@ def self_attention(q, k, vt, heads, scale):
     return out
 
 
+def self_attention_lse(q, k, vt, heads, scale):
+    """`self_attention` for the differentiable path: also returns lse [B, heads, N] float32 (log2 domain), the only
+    thing the backward kernels need of the N x N scores (sta_selfattn_fwd_lse)."""
+    B, N, C = q.shape
+    out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=q.device)
+    L = _lib.load()
+    _lib.check(L.sta_selfattn_fwd_lse(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), lse.data_ptr(), B, N, C, heads,
+                                      q.stride(1), k.stride(1), vt.stride(1), vt.stride(0), float(scale), _dtype_code(q), _stream(q)),
+               "sta_selfattn_fwd_lse")
+    return out, lse
+
+
+class SelfAttentionQKV(torch.autograd.Function):
+    """Differentiable self-attention over ONE fused projection buffer qkv [B, N, 3C] (columns [q | k | v]): the HIP
+    forward keeps out and lse, the HIP backward (sta_selfattn_bwd: delta, dk/dv and dq kernels) writes the three column
+    blocks of ONE [B, N, 3C] gradient, so the projection's backward is a single GEMM. Replaces the autograd of
+    CrossAttention.forward with context = x (attention.py:175-197) in the tracked epochs (plms.py:275-277)."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
+        vt = qkv[..., 2 * C:].transpose(1, 2).contiguous()
+        out, lse = self_attention_lse(qkv[..., :C], qkv[..., C:2 * C], vt, heads, scale)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads, ctx.scale = heads, scale
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        dout = dout.contiguous()
+        qt = qkv[..., :C].transpose(1, 2).contiguous()                 # [B, C, N] copies: the A operands whose MFMA k axis is pixels
+        kt = qkv[..., C:2 * C].transpose(1, 2).contiguous()
+        dot = dout.transpose(1, 2).contiguous()
+        dqkv = torch.empty_like(qkv)
+        delta = torch.empty_like(lse)
+        es = qkv.element_size()
+        L = _lib.load()
+        _lib.check(L.sta_selfattn_bwd(qkv.data_ptr(), qkv.data_ptr() + C * es, qkv.data_ptr() + 2 * C * es, qt.data_ptr(), kt.data_ptr(),
+                                      dout.data_ptr(), dot.data_ptr(), out.data_ptr(), lse.data_ptr(), delta.data_ptr(),
+                                      dqkv.data_ptr(), dqkv.data_ptr() + C * es, dqkv.data_ptr() + 2 * C * es,
+                                      B, N, C, ctx.heads, 3 * C, 3 * C, float(ctx.scale), _dtype_code(qkv), _stream(qkv)),
+                   "sta_selfattn_bwd")
+        return dqkv, None, None
+
+
+def self_attention_train_supported(x, heads):
+    """Shapes the differentiable HIP self-attention takes (forward with lse + backward kernels; the rest stays on SDPA)."""
+    if not SELFATTN_ENABLED:
+        return False
+    B, N, C = x.shape
+    d = C // heads
+    return x.is_cuda and x.dtype in _DTYPES and N % 64 == 0 and d % 8 == 0 and d <= 96 and C % heads == 0
+
+
 def self_attention_supported(x, heads):
     """Shapes the HIP self-attention kernel takes (the rest goes to PyTorch's SDPA)."""
     from . import fused as _fused

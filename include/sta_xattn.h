@@ -163,7 +163,7 @@ int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const 
 
 /*
  * Flash-style self-attention of the same transformer block (attn1; CrossAttention.forward with
- * context = x, attention.py:175-197 called at :274), inference only: out = softmax(scale q k^T) v per head
+ * context = x, attention.py:175-197 called at :274): out = softmax(scale q k^T) v per head
  * without materialising the [heads, N, N] scores. SURVEY.md §8f rank 2.
  *   q   : [B][N][ldq]  dtype, head h in columns h*d .. h*d+d-1 (ldq >= C lets q live in a fused QKV buffer)
  *   k   : [B][N][ldk]  dtype
@@ -175,6 +175,31 @@ int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const 
  */
 int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, int B, int N, int C, int heads,
                      int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype, void* stream);
+
+/*
+ * The same forward for the differentiable path (the weight-optimisation epochs: plms.py:275-277 back-propagates
+ * through attn1 of every checkpointed block, diffusionmodules/util.py:123-145): additionally writes
+ *   lse : [B][heads][N] float32 = log2 of the row sums of exp(scale q k^T), i.e. P = exp2(scale*log2(e)*s - lse),
+ * which is all the backward needs of the N x N scores.
+ */
+int sta_selfattn_fwd_lse(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int N, int C, int heads,
+                         int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype, void* stream);
+
+/*
+ * Backward of the self-attention above (replaces the autograd of attention.py:175-197 with context = x; the
+ * reference materialises and differentiates the [heads, N, N] softmax): given dout, the forward's out and lse,
+ *   dv = P^T dout,  dS = P o (dout v^T - delta),  delta = rowsum(dout o out),  dq = scale dS k,  dk = scale dS^T q
+ * per head, P rebuilt from lse tile by tile (three launches: delta, dk/dv, dq; no atomics, deterministic).
+ *   q, k, v      : [B][N][ld]  dtype rows, head h in columns h*d.. (ld >= C: slices of one fused QKV buffer are fine)
+ *   qt, kt       : [B][C][N]   dtype, q and k transposed (contiguous)
+ *   dout, out    : [B][N][C]   dtype (contiguous);   doutt : [B][C][N] = dout transposed
+ *   lse          : [B][heads][N] float32 from sta_selfattn_fwd_lse;   delta : [B][heads][N] float32 workspace
+ *   dq, dk, dv   : [B][N][ldg] dtype rows (ldg >= C, e.g. the three column blocks of one [B][N][3C] gradient)
+ * Requires N % 64 == 0, d = C/heads <= 96, d % 8 == 0, ld % 8 == 0, ldg % 4 == 0.
+ */
+int sta_selfattn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* dout,
+                     const void* doutt, const void* out, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                     int B, int N, int C, int heads, int ld, int ldg, float scale, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

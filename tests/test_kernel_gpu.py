@@ -361,6 +361,74 @@ def test_self_attention_deferred_rescale_branches(dtype):
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
 
 
+SA_BWD_SHAPES = [(2, 256, 320, 8), (2, 128, 160, 2), (1, 64, 64, 4), (1, 192, 96, 1), (3, 320, 128, 2), (1, 4096, 320, 8), (1, 1024, 640, 8)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,N,C,heads", SA_BWD_SHAPES)
+def test_self_attention_backward_matches_fp64(B, N, C, heads, dtype):
+    """Differentiable self-attention (sta_selfattn_fwd_lse + sta_selfattn_bwd behind sta.ops.SelfAttentionQKV) against the
+    fp64 autograd of softmax(q k^T scale) v on the same 16-bit [B, N, 3C] projection buffer (attention.py:175-197 with
+    context = x): out, lse and the three column blocks of the gradient. Head dims 40 / 80 (SD-v1 levels 0 / 1), 16, 64, 96."""
+    from sta import ops
+    g = torch.Generator().manual_seed(N + C + B)
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dtype)
+    dout = torch.randn(B, N, C, generator=g).to(dtype)
+    d, scale = C // heads, (C // heads) ** -0.5
+    x = qkv.cuda().requires_grad_(True)
+    out = ops.SelfAttentionQKV.apply(x, heads, scale)
+    out.backward(dout.cuda())
+    _, lse = ops.self_attention_lse(x.detach()[..., :C], x.detach()[..., C:2 * C], x.detach()[..., 2 * C:].transpose(1, 2).contiguous(), heads, scale)
+    torch.cuda.synchronize()
+    dev64 = "cuda" if N > 1024 else "cpu"                 # the fp64 reference of the N = 4096 case runs on the GPU (PyTorch fp64 ops)
+    r = qkv.double().to(dev64).requires_grad_(True)
+    q64, k64, v64 = (r[..., i * C:(i + 1) * C].view(B, N, heads, d).transpose(1, 2) for i in range(3))
+    logits = q64 @ k64.transpose(-1, -2) * scale
+    ref = (torch.softmax(logits, -1) @ v64).transpose(1, 2).reshape(B, N, C)
+    ref.backward(dout.double().to(dev64))
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (out.detach().double().cpu() - ref.detach().cpu()).abs()
+    assert (err <= 4 * eps * (1.0 + ref.detach().cpu().abs())).all(), err.max()
+    lse_ref = torch.logsumexp(logits.detach(), -1).cpu() * 1.4426950408889634
+    assert (lse.double().cpu() - lse_ref).abs().max() < 1e-3
+    gref = r.grad.cpu()
+    got = x.grad.double().cpu()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a, b_ = got[..., i * C:(i + 1) * C], gref[..., i * C:(i + 1) * C]
+        # P and dS enter the gradient MFMAs rounded to 16 bits (as in every flash backward): the error of one output is a sum
+        # of N rounded terms, bounded here relative to the largest gradient of the tensor
+        assert (a - b_).abs().max() <= 6 * eps * b_.abs().max(), (name, (a - b_).abs().max(), b_.abs().max())
+        assert ((a - b_).norm() / b_.norm()) < 2 * eps, (name, (a - b_).norm() / b_.norm())
+
+
+def test_self_attention_tracked_module_matches_sdpa():
+    """CrossAttention (attn1) with autograd enabled and frozen weights takes the HIP forward + backward; its input gradient
+    and output against PyTorch SDPA autograd on the same module (sta.ops.SELFATTN_ENABLED off)."""
+    from ldm.modules.attention import CrossAttention
+    from sta import ops
+    from sta.synth import seeded_fill_
+    B, N, C, heads = 2, 1024, 320, 8
+    attn = CrossAttention(query_dim=C, heads=heads, dim_head=C // heads)
+    seeded_fill_(attn, 5)
+    attn = attn.cuda().to(torch.float16).requires_grad_(False)
+    x0 = torch.randn(B, N, C, generator=torch.Generator().manual_seed(1)).to(torch.float16).cuda()
+    w = torch.randn(B, N, C, generator=torch.Generator().manual_seed(2)).to(torch.float16).cuda()
+    res = []
+    for enabled in (True, False):
+        ops.SELFATTN_ENABLED = enabled
+        try:
+            x = x0.clone().requires_grad_(True)
+            y = attn(x)
+            (y.float() * w.float()).sum().backward()
+            res.append((y.detach().float(), x.grad.float()))
+        finally:
+            ops.SELFATTN_ENABLED = True
+    torch.cuda.synchronize()
+    assert getattr(attn, "_wqkv", None) is not None          # the tracked HIP path ran
+    for a, b_ in zip(res[0], res[1]):
+        assert (a - b_).abs().max() <= 2.0 ** -7 * b_.abs().max(), ((a - b_).abs().max(), b_.abs().max())
+
+
 def test_self_attention_module_large_batch():
     """CrossAttention's inference path at CFG batch 40 (20 prompts per UNet call): q/k from one fused GEMM, V^T from ONE
     plain GEMM over the flattened batch. (A weight-broadcast batched matmul for V^T faulted inside the GEMM library from
