@@ -4,7 +4,7 @@
 //   sim = einsum(q, k) * scale; attn = softmax(sim); out = einsum(attn, v)   over N = H*W keys,
 // which materialises [16, N, N] scores (N = 4096 at 512^2: 537 MB in fp16). SURVEY.md §8f ranks this the
 // next component after the fused cross-attention: it shares the same transformer block and the same MFMA
-// tile machinery. Inference only (the weight-optimisation path keeps PyTorch's differentiable SDPA).
+// tile machinery. The differentiable path adds the log-sum-exp output (p.lse) for sta_selfattn_bwd.hip.
 //
 // Same "pixel is the MFMA column" layout as sta_xattn.hip (16x16x32 MFMA, lane = 16g + c):
 //   S^T[key][px]  = K[key][:] . Q[px][:]       A = K rows (16 B per lane straight from the [B][N][ld] rows)
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 
 template <typename T, int NKS, int NDT, bool SUMROW>
 int launch_sa_cfg(const SParams& p, hipStream_t st) {
-  constexpr int QT = 2;
+  constexpr int QT = NDT > 6 ? 1 : 2;     // d > 96: one query tile per wave keeps the 4*NDT accumulator + 8*NDT V^T registers under 256
   constexpr int lds = 3 * (((4 * NKS + 2 * NDT) + 3) / 4 * 4) * FRAG;
   static StaLdsAttr attr;
   if (!attr.ensure((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
@@ -313,8 +313,12 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
     case 4: return launch_sa<T, 2, 4>(p, st);
     case 5: return launch_sa<T, 3, 5>(p, st);
     case 6: return launch_sa<T, 3, 6>(p, st);
+    case 7: return launch_sa<T, 4, 7>(p, st);
+    case 8: return launch_sa<T, 4, 8>(p, st);
+    case 9: return launch_sa<T, 5, 9>(p, st);
+    case 10: return launch_sa<T, 5, 10>(p, st);
   }
-  return sta_fail(STA_E_UNSUP, "self-attention head dim %d unsupported (d <= 96)", p.d);
+  return sta_fail(STA_E_UNSUP, "self-attention head dim %d unsupported (d <= 160)", p.d);
 }
 
 }  // namespace
@@ -327,8 +331,8 @@ static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* 
   if (B < 1 || B > 65535 || N < 8 || N % 8 || C <= 0 || heads <= 0 || C % heads)
     return sta_fail(STA_E_ARG, "bad shape B=%d N=%d C=%d heads=%d (need N %% 8 == 0)", B, N, C, heads);
   const int d = C / heads;
-  if (d % 8 || d > 96 || ldq < C || ldk < C || ldq % 8 || ldk % 8)
-    return sta_fail(STA_E_UNSUP, "self-attention needs d %% 8 == 0, d <= 96, row strides >= C and %% 8 == 0 (d=%d)", d);
+  if (d % 8 || d > 160 || ldq < C || ldk < C || ldq % 8 || ldk % 8)
+    return sta_fail(STA_E_UNSUP, "self-attention needs d %% 8 == 0, d <= 160, row strides >= C and %% 8 == 0 (d=%d)", d);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   if (vt_row_stride < N || vt_row_stride % 8 || vt_batch_stride % 8)
     return sta_fail(STA_E_ARG, "selfattn: vt strides (%ld, %ld) must be multiples of 8 with row stride >= N", vt_row_stride, vt_batch_stride);

@@ -368,4 +368,4 @@ def self_attention_supported(x, heads):
         return False
     B, N, C = x.shape
     d = C // heads
-    return x.is_cuda and x.dtype in _DTYPES and N % 8 == 0 and N >= 64 and d % 8 == 0 and d <= 96 and C % heads == 0
+    return x.is_cuda and x.dtype in _DTYPES and N % 8 == 0 and N >= 64 and d % 8 == 0 and d <= 160 and C % heads == 0

@@ -171,7 +171,7 @@ int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const 
  *         b*vt_batch_stride + c*vt_row_stride + n (elements; both multiples of 8). [B][C][N] is (N, C*N);
  *         ONE plain GEMM W_v . X^T over the flattened batch gives [C][B*N], i.e. (B*N, N) — no batched GEMM.
  *   out : [B][N][C]    dtype
- * Requires N % 8 == 0, d = C/heads <= 96, d % 8 == 0.
+ * Requires N % 8 == 0, d = C/heads <= 160, d % 8 == 0.
  */
 int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, int B, int N, int C, int heads,
                      int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype, void* stream);

@@ -279,7 +279,10 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters):
 
 
 @pytest.mark.parametrize("B,N,C,heads", [(2, 4096, 320, 8), (4, 1024, 640, 8), (2, 144, 640, 8), (2, 576, 192, 4),
-                                          (2, 64, 64, 8), (3, 200, 256, 4), (2, 2304, 640, 8)])
+                                          (2, 64, 64, 8), (3, 200, 256, 4), (2, 2304, 640, 8),
+                                          # d = 160 (SD-v1 levels 2 and mid at 512^2 / 768^2), 128, 112, 144
+                                          (2, 256, 1280, 8), (4, 64, 1280, 8), (2, 576, 1280, 8), (2, 144, 1280, 8),
+                                          (1, 128, 256, 2), (1, 72, 112, 1), (2, 192, 288, 2)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_self_attention_matches_reference(B, N, C, heads, dtype):
     """Flash-style self-attention kernel (attn1) vs softmax(q k^T scale) v in fp64 on the same 16-bit inputs;
