@@ -36,6 +36,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.sta_xattn_packed_kv_bytes(4, 8, 40) == 4 * 8 * 2 * (5 * 2 + 3 * 3) * 1024
     assert L.sta_xattn_packed_kv_bytes(4, 8, 168) == 0 and L.sta_xattn_packed_kv_bytes(4, 8, 20) == 0
     assert L.sta_selfattn_fwd(0, 0, 0, 0, 2, 64, 64, 8, 64, 64, 64, 4096, 1.0, 0, 0) == -1 and b"null" in L.sta_last_error()
+    assert L.sta_selfattn_fwd_lse(8, 8, 8, 8, 0, 2, 64, 64, 8, 64, 64, 64, 4096, 1.0, 0, 0) == -1 and b"null" in L.sta_last_error()
+    assert L.sta_selfattn_bwd(*([0] * 13), 2, 64, 64, 8, 64, 64, 1.0, 0, 0) == -1 and b"null" in L.sta_last_error()
+    # the backward streams whole 64-row blocks: N % 64 != 0 is refused before anything is launched
+    assert L.sta_selfattn_bwd(*([8] * 13), 2, 72, 64, 8, 64, 64, 1.0, 0, 0) == -2 and b"N % 64" in L.sta_last_error()
     assert L.sta_groupnorm_silu(0, 0, 0, 0, 0, 2, 320, 4096, 32, 1e-5, 1, 0, 0) == -1 and b"null" in L.sta_last_error()
     assert L.sta_geglu(0, 0, 4, 64, 0, 0) == -1 and L.sta_add_layernorm(0, 0, 0, 0, 0, 0, 0, 4, 64, 1e-5, 0, 0) == -1
     assert L.sta_add_bias_nchw(0, 0, 0, 0, 2, 4, 64, 0, 0) == -1 and L.sta_add_bias_rows(0, 0, 0, 0, 8, 64, 0, 0) == -1

@@ -404,6 +404,40 @@ def test_self_attention_backward_matches_fp64(B, N, C, heads, dtype):
         assert ((a - b_).norm() / b_.norm()) < 2 * eps, (name, (a - b_).norm() / b_.norm())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_self_attention_backward_768_level0(dtype):
+    """BASELINE configs[4] size (768x768: N = 9216 at level 0, d = 40): the HIP backward against fp32 autograd of the explicit
+    softmax on the GPU (the fp64 form would need 22 GB per tensor), plus linearity in dout — a size-independent property of
+    the backward: bwd(2 a - 3 b) = 2 bwd(a) - 3 bwd(b) up to the 16-bit rounding of the outputs."""
+    from sta import ops
+    B, N, C, heads = 1, 9216, 320, 8
+    d, scale = C // heads, (C // heads) ** -0.5
+    g = torch.Generator().manual_seed(77)
+    qkv = torch.randn(B, N, 3 * C, generator=g).to(dtype).cuda()
+    da = torch.randn(B, N, C, generator=g).to(dtype).cuda()
+    db = torch.randn(B, N, C, generator=g).to(dtype).cuda()
+
+    def hip_grad(dout):
+        x = qkv.clone().requires_grad_(True)
+        ops.SelfAttentionQKV.apply(x, heads, scale).backward(dout)
+        return x.grad.float()
+    ga, gb = hip_grad(da), hip_grad(db)
+    mix = (2.0 * da.float() - 3.0 * db.float()).to(dtype)
+    gm = hip_grad(mix)
+    r = qkv.float().requires_grad_(True)
+    q, k, v = (r[..., i * C:(i + 1) * C].view(B, N, heads, d).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * scale, -1) @ v).transpose(1, 2).reshape(B, N, C)
+    ref.backward(da.float())
+    torch.cuda.synchronize()
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a, b_ = ga[..., i * C:(i + 1) * C], r.grad[..., i * C:(i + 1) * C]
+        assert (a - b_).abs().max() <= 6 * eps * b_.abs().max(), (name, (a - b_).abs().max(), b_.abs().max())
+        assert (a - b_).norm() / b_.norm() < 2 * eps, name
+    lin = 2.0 * ga - 3.0 * gb
+    assert (gm - lin).norm() / lin.norm() < 4 * eps, (gm - lin).norm() / lin.norm()
+
+
 def test_self_attention_tracked_module_matches_sdpa():
     """CrossAttention (attn1) with autograd enabled and frozen weights takes the HIP forward + backward; its input gradient
     and output against PyTorch SDPA autograd on the same module (sta.ops.SELFATTN_ENABLED off)."""

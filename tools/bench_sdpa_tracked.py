@@ -1,5 +1,5 @@
 """bench.py with the differentiable self-attention forced back to PyTorch SDPA (the round-1 tracked path) — the A side of
-the A/B behind profiles/r02_selfattn_bwd.md:   python tools/bench_sdpa_tracked.py --opt-epochs 3 --steps 2 --warmup 1 ..."""
+the A/B behind profiles/r02_selfattn_bwd_bench.txt:   python tools/bench_sdpa_tracked.py --opt-epochs 3 --steps 2 --warmup 1 ..."""
 import os
 import sys
 
