@@ -122,6 +122,10 @@ def load():
         raise StaLibraryError(
             "%s is missing — run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU or eager fallback for the fused cross-attention)" % LIB_PATH)
+    # PyTorch ships its own HIP runtime; the library must bind to the one torch initialised (the tensors it is handed live
+    # there). Loaded the other way round — libsta first, then torch — the process ends up with two runtimes and every launch
+    # of this library fails with "no ROCm-capable device is detected". Importing torch first pins the order.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
