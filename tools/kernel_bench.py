@@ -58,9 +58,14 @@ if __name__ == "__main__":
     ap.add_argument("--imgs", type=int, default=1)
     ap.add_argument("--level", type=int, default=-1, help="only this level (0..3) of the resolution")
     ap.add_argument("--kernel", type=int, default=0, help="sta_set_option(STA_OPT_FWD_KERNEL): 0 auto, 1 LDS-resident, 2 split / one context at a time")
+    ap.add_argument("--opt", action="append", default=[], help="sta_set_option override KEY=VALUE (KEY = index in include/sta_xattn.h), repeatable")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16")
     a = ap.parse_args()
+    from sta import lib
     if a.kernel:
-        from sta import lib
         lib.set_option(lib.OPT_FWD_KERNEL, a.kernel)
+    for kv in a.opt:
+        k_, v_ = kv.split("=")
+        lib.set_option(int(k_), int(v_))
     for N, C in (LEVELS[a.res] if a.level < 0 else [LEVELS[a.res][a.level]]):
-        print(json.dumps(bench_level(N, C, a.K, iters=a.iters, bwd=a.bwd, imgs=a.imgs)))
+        print(json.dumps(bench_level(N, C, a.K, iters=a.iters, bwd=a.bwd, imgs=a.imgs, dtype=torch.float16 if a.dtype == 'fp16' else torch.bfloat16)))
