@@ -53,7 +53,10 @@ __device__ __forceinline__ float bfly_sum(float x) {
 // SUMROW (head dims that are not a multiple of 16, e.g. 40): the first PADDED row of V^T is set to ones in
 // registers, so the PV MFMAs accumulate the softmax denominator as row d of O^T — 16 v_add per 64 keys per query
 // tile less in a kernel whose VALU pipe is 73 % busy; the running rescale covers it like any other row.
-template <typename T, int NKS, int NDT, int QT, bool SUMROW>
+// PRE (q arrives pre-multiplied by scale*log2(e), p.sl2e == 1 — the host folds the factor into W_q): the running maximum
+// is the INITIAL VALUE of the S^T accumulators, so the MFMAs deliver s - m and the exponent needs no multiply-subtract:
+// 2.5 instead of 3.5 vector instructions per score in a loop whose time is the vector pipe's.
+template <typename T, int NKS, int NDT, int QT, bool SUMROW, bool PRE>
 __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   float mrun[QT], lrun[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
-    mrun[qt] = -3.0e38f;
+    mrun[qt] = PRE ? 0.f : -3.0e38f;      // PRE: block 0 always takes the exact maximum (see below)
     lrun[qt] = 0.f;
 #pragma unroll
     for (int u = 0; u < NDT; ++u) o[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -176,9 +179,10 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float i0 = PRE ? -mrun[qt] : 0.f;       // (a loop-carried {-m,-m,-m,-m} vector as C operand measured the same: 2190-2259 vs 2233-2276 us)
+        st[qt][t] = Tr<T>::mfma(ka[t * NKS], qf[qt][0], f32x4{i0, i0, i0, i0});
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
+        for (int s = 1; s < NKS; ++s) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
       }
     __builtin_amdgcn_s_setprio(0);
     V8 va[NVF];
@@ -220,6 +224,34 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       // ones row of V^T (or lrun) sums the same P, so the ratio O / l is unchanged. Wave-uniform branch. Measured
       // 1385 -> 1344 us at B = 32, N = 4096, d = 40 (neutral at d = 80); both sides of the branch are forced in
       // tests/test_kernel_gpu.py::test_self_attention_deferred_rescale_branches.
+      float rs = 0.f;
+      if constexpr (PRE) {
+        // bm = max(s) - m (the accumulators started at -m). Block 0 moves m to the exact maximum whatever its sign (m starts
+        // at 0 and O^T, l at 0: nothing to rescale); later blocks only when some pixel's maximum grew by more than 2^RESCALE_LOG2.
+        const bool first = blk == 0;
+        if (first || __any(bm > RESCALE_LOG2)) {
+          const float delta = first ? bm : fmaxf(bm, 0.f);
+          mrun[qt] += delta;
+          if (!first) {
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+            if constexpr (!SUMROW) lrun[qt] *= alpha;
+#pragma unroll
+            for (int u = 0; u < NDT; ++u) o[qt][u] *= alpha;
+          }
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[qt][t][r] -= delta;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(st[qt][t][r]);
+            st[qt][t][r] = e;
+            if constexpr (!SUMROW) rs += e;
+          }
+      } else {
       if (__any((bm - mrun[qt]) * p.sl2e > RESCALE_LOG2)) {
         const float mnew = fmaxf(mrun[qt], bm);
         const float alpha = __builtin_amdgcn_exp2f((mrun[qt] - mnew) * p.sl2e);
@@ -230,7 +262,6 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       }
       const float mnew = mrun[qt];
       const float off = mnew * p.sl2e;
-      float rs = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -239,6 +270,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
           st[qt][t][r] = e;
           if constexpr (!SUMROW) rs += e;
         }
+      }
       if constexpr (!SUMROW) lrun[qt] += rs;
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -287,21 +319,22 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   }
 }
 
-template <typename T, int NKS, int NDT, bool SUMROW>
+template <typename T, int NKS, int NDT, bool SUMROW, bool PRE>
 int launch_sa_cfg(const SParams& p, hipStream_t st) {
   constexpr int QT = NDT > 6 ? 1 : 2;     // d > 96: one query tile per wave keeps the 4*NDT accumulator + 8*NDT V^T registers under 256
   constexpr int lds = 3 * (((4 * NKS + 2 * NDT) + 3) / 4 * 4) * FRAG;
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
+  if (!attr.ensure((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW, PRE>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
   const int tiles = (p.N + 64 * QT - 1) / (64 * QT);
-  hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW>), dim3(tiles * p.H, p.B), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW, PRE>), dim3(tiles * p.H, p.B), dim3(256), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn launch: %s", hipGetErrorString(e));
 }
 
 template <typename T, int NKS, int NDT>
 int launch_sa(const SParams& p, hipStream_t st) {
-  return (p.d & 15) ? launch_sa_cfg<T, NKS, NDT, true>(p, st) : launch_sa_cfg<T, NKS, NDT, false>(p, st);
+  if (p.sl2e == 1.0f) return (p.d & 15) ? launch_sa_cfg<T, NKS, NDT, true, true>(p, st) : launch_sa_cfg<T, NKS, NDT, false, true>(p, st);
+  return (p.d & 15) ? launch_sa_cfg<T, NKS, NDT, true, false>(p, st) : launch_sa_cfg<T, NKS, NDT, false, false>(p, st);
 }
 
 template <typename T>
@@ -336,7 +369,9 @@ static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* 
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   if (vt_row_stride < N || vt_row_stride % 8 || vt_batch_stride % 8)
     return sta_fail(STA_E_ARG, "selfattn: vt strides (%ld, %ld) must be multiples of 8 with row stride >= N", vt_row_stride, vt_batch_stride);
-  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, scale * 1.4426950408889634f, lse};
+  float sl2e = scale * 1.4426950408889634f;
+  if (fabsf(sl2e - 1.0f) < 1e-6f) sl2e = 1.0f;       // scale = ln 2: q is already in log2 units (pre-scaled W_q) -> the PRE kernels
+  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, sl2e, lse};
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_sa<__bf16>(p, st) : dispatch_sa<_Float16>(p, st);
 }

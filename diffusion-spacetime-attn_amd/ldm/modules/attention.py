@@ -111,12 +111,15 @@ class CrossAttention(nn.Module):
         wq, wk = self.to_q.weight, self.to_k.weight
         key = (wq.data_ptr(), wq._version, wk.data_ptr(), wk._version)
         if getattr(self, "_wqk_key", None) != key:
-            self._wqk, self._wqk_key = torch.cat([wq.detach(), wk.detach()]), key
+            # softmax scale * log2(e) rides in W_q (multiplied in fp32, rounded once): q leaves the GEMM in log2 units and the
+            # kernel's exponent is a bare exp2 of the MFMA result (sta_selfattn.hip, PRE)
+            wq2 = (wq.detach().float() * (self.scale * 1.4426950408889634)).to(wq.dtype)
+            self._wqk, self._wqk_key = torch.cat([wq2, wk.detach()]), key
         c = wq.shape[0]
         qk = F.linear(x, self._wqk)                                   # [B, N, 2C]
         b, n, _ = x.shape
         vt = torch.mm(self.to_v.weight, x.reshape(b * n, c).t()).view(c, b, n).permute(1, 0, 2)    # [B, C, N] view of [C, B*N]
-        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
+        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, _ops.LN2)
         return self.to_out(o)
 
 
@@ -125,14 +128,14 @@ class CrossAttention(nn.Module):
         feeds both fp8 GEMMs — [Wq; Wk] (row scales concatenated) and the transposed W_v . x^T."""
         from sta import fp8 as _fp8
         if getattr(self, "_wqk8", None) is None or self._wqk8_src is not self.to_q.weight_q:
-            self._wqk8 = _fp8.Fp8Linear(torch.cat([self.to_q.weight_q, self.to_k.weight_q]),
-                                        torch.cat([self.to_q.weight_scale, self.to_k.weight_scale], dim=1), None)
+            self._wqk8 = _fp8.Fp8Linear(torch.cat([self.to_q.weight_q, self.to_k.weight_q]),          # scale * log2(e) rides in q's fp32 row scales
+                                        torch.cat([self.to_q.weight_scale * (self.scale * 1.4426950408889634), self.to_k.weight_scale], dim=1), None)
             self._wqk8_src = self.to_q.weight_q
         b, n, c = x.shape
         xq, sx = _fp8.quant_rows(x.reshape(b * n, c))
         qk = _fp8.scaled_mm(xq, self._wqk8.weight_q.t(), sx, self._wqk8.weight_scale, None, x.dtype).view(b, n, 2 * c)
         vt = self.to_v.forward_transposed(xq, sx, x.dtype).view(c, b, n).permute(1, 0, 2)
-        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, self.scale)
+        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, _ops.LN2)
         return self.to_out(o)
 
 

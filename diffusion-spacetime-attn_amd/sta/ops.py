@@ -278,6 +278,9 @@ def xattn_blend(q, coef, packed, mask, scale):
     return _XAttnBlend.apply(q, coef, packed, mask, scale)
 
 
+LN2 = 0.6931471805599453     # pass as `scale` when q is already multiplied by (softmax scale * log2 e): the kernel's log2-domain fast path
+
+
 def self_attention(q, k, vt, heads, scale):
     """Flash-style self-attention through the HIP kernel (inference only, no autograd).
     q, k: [B, N, C] (last dim contiguous; a row stride > C is allowed, e.g. slices of a fused QKV buffer);

@@ -307,6 +307,15 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     err = (out.float().cpu().double() - ref).abs()
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
+    # log2-domain fast path (what the module runs: scale * log2 e folded into W_q): q' = round16(q * scale * log2 e), scale = ln 2;
+    # the kernel then takes the exponent of the MFMA result directly. Reference: softmax of the SAME rounded q'.
+    qs = (qk[..., :C].float() * (scale * 1.4426950408889634)).to(dtype)
+    out3 = ops.self_attention(qs.cuda(), qk_d[..., C:], vt_d, heads, ops.LN2)
+    torch.cuda.synchronize()
+    qs64 = qs.double().view(B, N, heads, d).transpose(1, 2)
+    ref3 = (torch.softmax(qs64 @ k64.transpose(-1, -2) * ops.LN2, -1) @ v64).transpose(1, 2).reshape(B, N, C)
+    err3 = (out3.float().cpu().double() - ref3).abs()
+    assert (err3 <= 4 * eps * (1.0 + ref3.abs())).all(), (err3.max(), ref3.abs().max())
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -332,8 +341,9 @@ def test_self_attention_768_level0(dtype):
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
 
 
+@pytest.mark.parametrize("pre", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_self_attention_deferred_rescale_branches(dtype):
+def test_self_attention_deferred_rescale_branches(dtype, pre):
     """The running maximum of the online softmax is moved only when a pixel's maximum grew by more than 2^8 since the
     last move (sta_selfattn.hip). Inputs that force both sides of that branch at chosen key blocks: (a) keys whose norm
     ramps up along the sequence, so the maximum creeps up by less than the threshold per block but far more than it in
@@ -348,7 +358,10 @@ def test_self_attention_deferred_rescale_branches(dtype):
     k = torch.randn(B, N, C, generator=g) * (0.3 + 2.7 * torch.arange(N).view(1, N, 1) / N)        # (a)
     for key, px in ((700, 5), (701, 260), (990, 17)):                                                 # (b), (c)
         k[:, key] = 4.0 * q[:, px]
+    k[:, :64] = -1.5 * q[:, 40:41]              # (d) every score of pixel 40 in block 0 is far below zero: the first maximum is negative
     v = torch.randn(B, N, C, generator=g)
+    if pre:                                    # the log2-domain kernels: q pre-multiplied by scale * log2 e, scale = ln 2
+        q, scale = q * (scale * 1.4426950408889634), ops.LN2
     q, k, v = (t.to(dtype) for t in (q, k, v))
     out = ops.self_attention(q.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda(), heads, scale)
     torch.cuda.synchronize()
