@@ -384,10 +384,12 @@ def main():
         # reported beside the headline, never part of `value`: the other 16-bit type, and BASELINE configs[2]
         if a.other_dtype:
             out["other_dtype"] = side_run(dev, "bf16" if a.dtype == "fp16" else "fp16", 0, I, 1, 1, a.res, a.ddim_steps, K)
-        # MIOpen's per-shape solver search is switched off for this leg (immediate mode): searching the backward
-        # convolutions of the UNet and the VAE decoder costs ~10 min on a fresh box for one timed step
-        torch.backends.cudnn.benchmark = False
-        out["weight_optimisation"] = side_run(dev, a.dtype, 3, 2, 1, 1, a.res, a.ddim_steps, K, find=False)
+        # MIOpen's per-shape solver search for the backward convolutions of the UNet and the VAE decoder costs ~10 min on a
+        # fresh box; the shipped user find-db (sta/data/miopen_userdb) holds them for fp16 at 512^2, other cases run in
+        # immediate mode (no search, slower solvers)
+        find = a.dtype == "fp16" and a.res == 512
+        torch.backends.cudnn.benchmark = find
+        out["weight_optimisation"] = side_run(dev, a.dtype, 3, 2, 1, 1, a.res, a.ddim_steps, K, find=find)
         out["weight_optimisation"]["config"] = "BASELINE configs[2]: %dx%d, %d PLMS steps, %d objects, 3 epochs of per-step blend-weight optimisation" % (
             a.res, a.res, a.ddim_steps, K)
     _phase("side runs done")
