@@ -327,6 +327,10 @@ class SelfAttentionQKV(torch.autograd.Function):
     def forward(ctx, qkv, heads, scale):
         B, N, C3 = qkv.shape
         C = C3 // 3
+        if C3 != 3 * C or C % heads or (C // heads) % 8 or C // heads > 96 or N % 64 or not qkv.is_cuda or qkv.dtype not in _DTYPES:
+            # refused here rather than at backward time (sta_selfattn_bwd streams whole 64-row blocks, d <= 96)
+            raise ValueError("SelfAttentionQKV needs a CUDA 16-bit [B, N, 3C] buffer with N %% 64 == 0 and head dim %% 8 == 0, <= 96; "
+                             "got %s heads=%d %s" % (tuple(qkv.shape), heads, qkv.dtype))
         qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
         vt = qkv[..., 2 * C:].transpose(1, 2).contiguous()
         out, lse = self_attention_lse(qkv[..., :C], qkv[..., C:2 * C], vt, heads, scale)

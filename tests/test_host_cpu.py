@@ -57,6 +57,11 @@ def test_missing_gpu_fails_loudly():
     packed = ops.PackedKV(torch.zeros(1, dtype=torch.uint8), 2, 8, 77, 64, torch.bfloat16)
     with pytest.raises(RuntimeError, match="no CPU path"):
         ops.xattn_blend(q, None, packed, None, 1.0)
+    # the differentiable self-attention refuses CPU tensors and shapes its backward cannot take, at forward time
+    with pytest.raises(ValueError, match="SelfAttentionQKV needs a CUDA"):
+        ops.SelfAttentionQKV.apply(torch.zeros(2, 64, 3 * 64, dtype=torch.float16), 8, 0.35)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.self_attention(q, q, torch.zeros(2, 64, 16, dtype=torch.bfloat16), 8, 0.35)
 
 
 def test_product_disc_masks_bit_exact():
