@@ -297,14 +297,26 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const SBParams p)
 #pragma unroll
     for (int u = 0; u < NDT; ++u) dk[kt][u] = dv[kt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Two LDS buffers where they fit (d <= 96); above, one 64-pixel block of [Q | dO | Q^T | dO^T] is 81 KB at d = 160 and the
+  // loop is stage -> barrier -> compute -> barrier (those levels have N <= 576: at most 9 blocks).
+  constexpr bool DB = 2 * BB <= 160 * 1024;
   const int nblk = N / KB;
-  stage(smem_sb);
+  if constexpr (DB) stage(smem_sb);
   for (int blk = 0; blk < nblk; ++blk) {
-    char* cur = smem_sb + (blk & 1) * BB;
+    char* cur = DB ? smem_sb + (blk & 1) * BB : smem_sb;
+    if constexpr (!DB) {
+      if (blk) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // every wave has read block blk-1 out of the single buffer
+      }
+      stage(cur);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (blk + 1 < nblk) stage(smem_sb + ((blk + 1) & 1) * BB);
+    if constexpr (DB) {
+      if (blk + 1 < nblk) stage(smem_sb + ((blk + 1) & 1) * BB);
+    }
     const V8* fr = (const V8*)cur + lane;
     f32x4 st[KT_][4], dp[KT_][4];
     {
@@ -418,7 +430,8 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const SBParams p)
 template <typename T, int NKS, int NDT, int QT>
 int launch_sb(const SBParams& p, hipStream_t st) {
   constexpr int lds_q = 2 * 4 * ((2 * 4 * NKS + 2 * NDT + 3) / 4) * FRAG;
-  constexpr int lds_kv = 2 * 4 * ((2 * 4 * NKS + 4 * NDT + 1 + 3) / 4) * FRAG;
+  constexpr int bb_kv = 4 * ((2 * 4 * NKS + 4 * NDT + 1 + 3) / 4) * FRAG;
+  constexpr int lds_kv = (2 * bb_kv <= 160 * 1024 ? 2 : 1) * bb_kv;
   static StaLdsAttr attr_q, attr_kv;
   if (!attr_q.ensure((const void*)selfattn_bwd_dq_kernel<T, NKS, NDT, QT>, lds_q) ||
       !attr_kv.ensure((const void*)selfattn_bwd_dkv_kernel<T, NKS, NDT, QT>, lds_kv))
@@ -441,8 +454,12 @@ int dispatch_sb(const SBParams& p, hipStream_t st) {
     case 4: return launch_sb<T, 2, 4, 2>(p, st);
     case 5: return launch_sb<T, 3, 5, 1>(p, st);
     case 6: return launch_sb<T, 3, 6, 1>(p, st);
+    case 7: return launch_sb<T, 4, 7, 1>(p, st);
+    case 8: return launch_sb<T, 4, 8, 1>(p, st);
+    case 9: return launch_sb<T, 5, 9, 1>(p, st);
+    case 10: return launch_sb<T, 5, 10, 1>(p, st);
   }
-  return sta_fail(STA_E_UNSUP, "self-attention backward: head dim %d unsupported (d <= 96)", p.d);
+  return sta_fail(STA_E_UNSUP, "self-attention backward: head dim %d unsupported (d <= 160)", p.d);
 }
 
 }  // namespace
@@ -456,8 +473,8 @@ extern "C" int sta_selfattn_bwd(const void* q, const void* k, const void* v, con
   if (B < 1 || B > 65535 || N < 64 || C <= 0 || heads <= 0 || C % heads)
     return sta_fail(STA_E_ARG, "bad shape B=%d N=%d C=%d heads=%d", B, N, C, heads);
   const int d = C / heads;
-  if (N % 64 || d % 8 || d > 96 || ld < C || ldg < C || ld % 8 || ldg % 4)
-    return sta_fail(STA_E_UNSUP, "self-attention backward needs N %% 64 == 0, d %% 8 == 0, d <= 96, row strides >= C (N=%d d=%d)", N, d);
+  if (N % 64 || d % 8 || d > 160 || ld < C || ldg < C || ld % 8 || ldg % 4)
+    return sta_fail(STA_E_UNSUP, "self-attention backward needs N %% 64 == 0, d %% 8 == 0, d <= 160, row strides >= C (N=%d d=%d)", N, d);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   SBParams p{q, k, v, qt, kt, doutt, dout, out, lse, delta, dq, dk, dv, B, N, C, heads, d, ld, ldg,
              scale * 1.4426950408889634f, scale};

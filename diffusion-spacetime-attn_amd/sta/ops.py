@@ -327,9 +327,9 @@ class SelfAttentionQKV(torch.autograd.Function):
     def forward(ctx, qkv, heads, scale):
         B, N, C3 = qkv.shape
         C = C3 // 3
-        if C3 != 3 * C or C % heads or (C // heads) % 8 or C // heads > 96 or N % 64 or not qkv.is_cuda or qkv.dtype not in _DTYPES:
-            # refused here rather than at backward time (sta_selfattn_bwd streams whole 64-row blocks, d <= 96)
-            raise ValueError("SelfAttentionQKV needs a CUDA 16-bit [B, N, 3C] buffer with N %% 64 == 0 and head dim %% 8 == 0, <= 96; "
+        if C3 != 3 * C or C % heads or (C // heads) % 8 or C // heads > 160 or N % 64 or not qkv.is_cuda or qkv.dtype not in _DTYPES:
+            # refused here rather than at backward time (sta_selfattn_bwd streams whole 64-row blocks, d <= 160)
+            raise ValueError("SelfAttentionQKV needs a CUDA 16-bit [B, N, 3C] buffer with N %% 64 == 0 and head dim %% 8 == 0, <= 160; "
                              "got %s heads=%d %s" % (tuple(qkv.shape), heads, qkv.dtype))
         qkv = qkv if qkv.is_contiguous() else qkv.contiguous()
         vt = qkv[..., 2 * C:].transpose(1, 2).contiguous()
@@ -365,7 +365,7 @@ def self_attention_train_supported(x, heads):
         return False
     B, N, C = x.shape
     d = C // heads
-    return x.is_cuda and x.dtype in _DTYPES and N % 64 == 0 and d % 8 == 0 and d <= 96 and C % heads == 0
+    return x.is_cuda and x.dtype in _DTYPES and N % 64 == 0 and d % 8 == 0 and d <= 160 and C % heads == 0
 
 
 def self_attention_supported(x, heads):

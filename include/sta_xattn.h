@@ -198,7 +198,7 @@ int sta_selfattn_fwd_lse(const void* q, const void* k, const void* vt, void* out
  *   dout, out    : [B][N][C]   dtype (contiguous);   doutt : [B][C][N] = dout transposed
  *   lse          : [B][heads][N] float32 from sta_selfattn_fwd_lse;   delta : [B][heads][N] float32 workspace
  *   dq, dk, dv   : [B][N][ldg] dtype rows (ldg >= C, e.g. the three column blocks of one [B][N][3C] gradient)
- * Requires N % 64 == 0, d = C/heads <= 96, d % 8 == 0, ld % 8 == 0, ldg % 4 == 0.
+ * Requires N % 64 == 0, d = C/heads <= 160, d % 8 == 0, ld % 8 == 0, ldg % 4 == 0.
  */
 int sta_selfattn_bwd(const void* q, const void* k, const void* v, const void* qt, const void* kt, const void* dout,
                      const void* doutt, const void* out, const float* lse, float* delta, void* dq, void* dk, void* dv,

@@ -377,7 +377,9 @@ def test_self_attention_deferred_rescale_branches(dtype, pre):
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
 
 
-SA_BWD_SHAPES = [(2, 256, 320, 8), (2, 128, 160, 2), (1, 64, 64, 4), (1, 192, 96, 1), (3, 320, 128, 2), (1, 4096, 320, 8), (1, 1024, 640, 8)]
+SA_BWD_SHAPES = [(2, 256, 320, 8), (2, 128, 160, 2), (1, 64, 64, 4), (1, 192, 96, 1), (3, 320, 128, 2), (1, 4096, 320, 8), (1, 1024, 640, 8),
+                 # d = 160 (levels 2 / mid at 512^2, level 2 at 768^2: single-buffered dk/dv kernel), 128, 112, 144
+                 (2, 256, 1280, 8), (2, 64, 1280, 8), (1, 576, 1280, 8), (1, 128, 256, 2), (1, 64, 112, 1), (2, 192, 288, 2)]
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -385,7 +387,7 @@ SA_BWD_SHAPES = [(2, 256, 320, 8), (2, 128, 160, 2), (1, 64, 64, 4), (1, 192, 96
 def test_self_attention_backward_matches_fp64(B, N, C, heads, dtype):
     """Differentiable self-attention (sta_selfattn_fwd_lse + sta_selfattn_bwd behind sta.ops.SelfAttentionQKV) against the
     fp64 autograd of softmax(q k^T scale) v on the same 16-bit [B, N, 3C] projection buffer (attention.py:175-197 with
-    context = x): out, lse and the three column blocks of the gradient. Head dims 40 / 80 (SD-v1 levels 0 / 1), 16, 64, 96."""
+    context = x): out, lse and the three column blocks of the gradient. Head dims 40 / 80 / 160 (the SD-v1 levels), 16 .. 144."""
     from sta import ops
     g = torch.Generator().manual_seed(N + C + B)
     qkv = torch.randn(B, N, 3 * C, generator=g).to(dtype)
