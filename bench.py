@@ -350,7 +350,11 @@ def main():
         pmc = os.path.join(REPO, "profiles", "xattn_fwd_hbm_traffic.json")
         if os.path.exists(pmc):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed per kernel and images-per-launch
             traffic = json.load(open(pmc)).get("by_kernel", {}).get("%s_N%d_C%d_I%d" % (dom + (I,)), {}).get("bytes_per_launch")
-        kname = {"proj": "xattn_fwd_proj_pair_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, a head pair per workgroup)",
+        # which projection-fused kernel the library dispatches (csrc/sta_xattn_proj.hip): a head pair per workgroup when two
+        # heads' compact operand images fit one CU's LDS (d = 40, K <= 2) and the launch has >= 256 pair workgroups
+        pair = dom[2] == 320 and K <= 2 and (dom[1] // 128) * 4 * I >= 256
+        kname = {"proj": ("xattn_fwd_proj_pair_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, a head pair per workgroup)" if pair else
+                          "xattn_fwd_proj_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, one head per workgroup)"),
                  "attn": "xattn_fwd{,_staged}_kernel (QK^T + softmax + disc mask + blend + PV)"}[dom[0]]
         bound = "hbm" if t_hbm >= t_mfma else "mfma"
         out["roofline"] = {
