@@ -47,7 +47,12 @@ def _broadcast_flat(flat, src, world):
     per = (n + world - 1) // world
     padded = flat if per * world == n else torch.cat([flat, flat.new_zeros(per * world - n)])
     piece = torch.empty(per, dtype=flat.dtype, device=flat.device)
-    dist.scatter(piece, list(padded.view(world, per).unbind(0)) if dist.get_rank() == src else None, src=src)
+    try:
+        dist.scatter(piece, list(padded.view(world, per).unbind(0)) if dist.get_rank() == src else None, src=src)
+    except (RuntimeError, NotImplementedError):
+        # a backend without scatter refuses on every rank before anything is sent: the plain broadcast is the same on all of them
+        dist.broadcast(flat, src=src)
+        return
     gathered = torch.empty(per * world, dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(gathered, piece)
     flat.copy_(gathered[:n])
