@@ -1,6 +1,16 @@
-import sys, torch, json
-from sta import ops
-def timed(fn, iters=30):
+"""Self-attention forward at the bench shapes (64 images x 8 heads): the scaled path against the log2-domain path the
+module runs (scale * log2 e folded into W_q, scale = ln 2). Stand-alone or under tools/lib_ab.py."""
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "diffusion-spacetime-attn_amd"))
+from sta import ops  # noqa: E402
+
+
+def timed(fn, iters=int(os.environ.get("SA_ITERS", "30"))):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
