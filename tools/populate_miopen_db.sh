@@ -5,8 +5,10 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd $R
 export MIOPEN_USER_DB_PATH=$R/diffusion-spacetime-attn_amd/sta/data/miopen_userdb
 run() { echo "== $*"; ( time timeout 1500 python bench.py --no-cpu-baseline --no-side-runs --no-roofline --steps 1 "$@" > /dev/null 2> /tmp/pop.log ) 2>&1 | grep real; grep "warm-up" /tmp/pop.log; }
-run                                        # fp16, 16 prompts per step (the default bench)
+run                                        # fp16, 32 prompts per step (the default bench)
 run --dtype bf16
+run --images-per-step 16
+run --images-per-step 16 --dtype bf16
 run --images-per-step 8
 run --images-per-step 1
 run --images-per-step 24
