@@ -314,7 +314,7 @@ def main():
                                        "%d weight-optimisation epochs, CLIP stand-in loss (BASELINE configs[2])" % a.opt_epochs),
                    "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt, sharded i %% %d" % world,
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
-                   "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
+                   "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "tuned_gemm_table": bool(torch.cuda.tunable.is_enabled()), "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,
                    "peak_hbm_gib": round(peak_gb, 1), **({"recompute": ckpt_mode} if a.opt_epochs > 1 else {})},
     }
