@@ -214,6 +214,11 @@ class PLMSSampler(object):
             # Only the image of the last epoch is kept and the weights are discarded afterwards, so the
             # backward + Adam step of the last epoch cannot change any output (reference :275-288).
             track = W.requires_grad and not last
+            # The measured GEMM-kernel table (sta.pipeline.use_tuned_gemms) is a per-call lookup on the host: free under hipGraph
+            # replay, a loss in the launch-bound eager autograd of a tracked epoch (0.425 vs 0.443 images/s) -> off while tracking.
+            tuned = track and torch.cuda.is_available() and torch.cuda.tunable.is_enabled()
+            if tuned:
+                torch.cuda.tunable.enable(False)
             with torch.set_grad_enabled(track):
                 img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
                                        time_range, W if batched else W[0], block_boxes, text_index,
@@ -227,6 +232,8 @@ class PLMSSampler(object):
                     loss.backward()
                     optimizer.step()
                     result.setdefault("losses", []).append(float(loss.detach()))
+            if tuned:
+                torch.cuda.tunable.enable(True)
             if last:
                 result.update(x0=img.detach(), image=None if x_img is None else x_img.detach(),
                               W=(W if batched else W[0]).detach().clone())
