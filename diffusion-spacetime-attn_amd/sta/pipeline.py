@@ -27,7 +27,7 @@ if os.path.isdir(USER_DB) and os.access(USER_DB, os.W_OK):
 
 # The GEMM library picks a kernel per shape by heuristic; for the Linear layers of the bench shapes (fp16, 32 prompts per
 # step) PyTorch's TunableOp measured every hipBLASLt / rocBLAS candidate once on an MI355X (e.g. the level-0 GEGLU
-# projection: 446 us instead of 639 us) and the 32 answers ship in sta/data/tunableop: +1.5 % images/s. Applied with
+# projection: 446 us instead of 639 us) and the answers (fp16 and bf16 default bench, 768^2, tracked epochs: 160 shapes) ship in sta/data/tunableop: +1.5 % images/s. Applied with
 # tuning OFF (a lookup, nothing is measured at run time); a different PyTorch / hipBLASLt build fails the file's
 # validators and is ignored. PYTORCH_TUNABLEOP_ENABLED in the environment (0 or 1) leaves everything to the caller.
 TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tunableop", "gfx950_gemm_results.csv")
