@@ -72,11 +72,19 @@ def parse():
                          "one that meets north_star's 1e-3 attention-map tolerance; bf16 runs at the same MFMA rate but rounding "
                          "the block input alone to 8 mantissa bits moves the maps by 2e-3 (DESIGN.md section 2)")
     ap.add_argument("--fp8", action="store_true", help="e4m3 Linear weights in the transformer blocks (BASELINE configs[4]; sta.fp8)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): every rank samples --images-per-step prompts per step, whatever the world size. strong: a step "
+                         "is the 64-prompt batch of BASELINE configs[3] split 64/world per rank (8 prompts per GPU per UNet call at 8 GPUs)")
     ap.add_argument("--cpu-calls", type=int, default=2, help="timed CPU UNet calls of the baseline sample")
     ap.add_argument("--opt-epochs", type=int, default=0,
                     help="weight-optimisation epochs (0 = fixed weights = BASELINE configs[1], the headline; 3 = configs[2] "
                          "with a CLIP stand-in loss, reported as a side measurement)")
     a = ap.parse_args()
+    if a.scaling == "strong":
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if 64 % world:
+            raise SystemExit("--scaling strong splits the 64 prompts of BASELINE configs[3]: the world size must divide 64")
+        a.images_per_step = 64 // world
     if a.images_per_step is None:
         a.images_per_step = (32 if a.res <= 512 else 4) if a.opt_epochs == 0 else 1
     return a
@@ -234,8 +242,10 @@ def main():
     dev = torch.device("cuda", local)
     from ldm.models.diffusion.plms import PLMSSampler
     from sta import lib
-    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, set_recompute
+    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, set_recompute, use_shipped_miopen_db, use_tuned_gemms
     lib.load()
+    use_shipped_miopen_db(local)      # per-rank copy of the shipped MIOpen find-db (before the first convolution)
+    use_tuned_gemms()                 # measured GEMM-kernel table for the bench shapes (process-wide TunableOp lookup, tuning off)
 
     K, dt = a.objects, (torch.float16 if a.dtype == "fp16" else torch.bfloat16)
     ckpt_mode = None
@@ -253,7 +263,11 @@ def main():
         from sta import fp8
         fp8.convert_transformer_linears_(model.model.diffusion_model)
     prompts = load_prompts(64)
-    mine = parallel.shard_indices(len(prompts), rank, world)
+    I = a.images_per_step
+    # Step j of rank r samples prompts (j * world + r) * I ... + I - 1 (mod 64): the I prompts of one UNet call are distinct and
+    # the ranks of a step take disjoint slices of the list. --scaling strong: I = 64 / world, a step is exactly the 64-prompt batch
+    # of BASELINE configs[3], rank r holding prompts r * I .. (the reference loops over them one by one, txt2img-gpt.py:305-341).
+    mine = lambda j: [((j * world + rank) * I + i) % len(prompts) for i in range(I)]
     lat = a.res // 8
     centres = [list(c) for c in DEFAULT_CENTRES[:K]]
     loss_model = None
@@ -263,13 +277,12 @@ def main():
         loss_model = DCLIPLoss(SyntheticCLIP().to(dev))
     sampler = PLMSSampler(model, opt_epochs=a.opt_epochs, loss_model=loss_model, use_graph=not a.no_graph, save_images=False)
 
-    I = a.images_per_step
     g = torch.Generator(device=dev).manual_seed(1)                          # seed = 1 for every prompt (txt2img-gpt.py:304)
     x_T1 = torch.randn([1, 4, lat, lat], generator=g, device=dev)
 
     def one_step(j):
         """One step = I independent prompts of this rank's shard sampled together (I = 1: the reference's loop body)."""
-        recs = [prompts[mine[(j * I + i) % len(mine)]] for i in range(I)]
+        recs = [prompts[i] for i in mine(j)]
         names = [(r["objects"] + ["object"] * K)[:K] for r in recs]
         conds = [conditionings(model, r["prompt"], nm, dt) for r, nm in zip(recs, names)]
         if I == 1:
@@ -307,12 +320,12 @@ def main():
     out = {
         "metric": "images/sec at 512x512, 50 PLMS steps, 2 objects", "value": world * a.steps * I / elapsed, "unit": "images/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
         "config": {"workload": "SD-v1-4 UNet+VAE (synthetic weights), %dx%d, %d PLMS steps (%d CFG UNet calls), %d objects, "
                                "%s" % (a.res, a.res, a.ddim_steps, a.ddim_steps + 1, K,
                                        "fixed blend weights (BASELINE configs[1])" if a.opt_epochs == 0 else
                                        "%d weight-optimisation epochs, CLIP stand-in loss (BASELINE configs[2])" % a.opt_epochs),
-                   "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt, sharded i %% %d" % world,
+                   "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt; step j of rank r takes prompts ((j * %d + r) * %d + i) %% 64" % (world, I),
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
                    "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "tuned_gemm_table": bool(torch.cuda.tunable.is_enabled()), "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,
@@ -321,7 +334,7 @@ def main():
     if not a.no_roofline:
         # per-launch times of the cross-attention forward kernels on the tensors of a real CFG UNet call
         from sta import prompt_state
-        rec = prompts[mine[0]]
+        rec = prompts[mine(0)[0]]
         names = (rec["objects"] + ["object"] * K)[:K]
         uc, c, local_c = conditionings(model, rec["prompt"], names, dt)
         pair = lambda u, v: torch.stack([u, v], dim=1).reshape(2 * I, *u.shape[1:])

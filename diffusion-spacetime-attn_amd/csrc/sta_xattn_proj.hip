@@ -25,6 +25,7 @@
 #include "sta_internal.h"
 #include "sta_xattn_dev.h"
 #include "sta_xattn_proj2.h"
+#include "sta_xattn_proj3.h"
 
 namespace {
 
@@ -365,7 +366,8 @@ int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype,
 size_t sta_xattn_packed_kv_proj_bytes(int n_ctx, int heads, int d) {
   if (n_ctx <= 0 || heads <= 0 || d <= 0 || d % 8 || d > STA_MAX_HEAD_DIM) return 0;
   // + the compact per-(ctx, head) blocks of the head-pair kernel where it applies (d = 40, even head count)
-  return (size_t)n_ctx * heads * fwd_frags((d + 15) / 16) * FRAG + ((d == sta_pair::D && heads % 2 == 0) ? sta_pair::kv_bytes(n_ctx, heads) : 0);
+  return (size_t)n_ctx * heads * fwd_frags((d + 15) / 16) * FRAG +
+         ((d == sta_pair::D && heads % 2 == 0) ? sta_pair::kv_bytes(n_ctx, heads) + sta_p3::kv_bytes(n_ctx, heads) : 0);
 }
 
 int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype,
@@ -387,7 +389,10 @@ int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx
     hipLaunchKernelGGL(pack_kv_proj_kernel<_Float16>, grid, dim3(64), 0, st, (const _Float16*)k, (const _Float16*)v,
                        (_Float16*)packed, M, C, heads, d, ndt);
   if (d == sta_pair::D && heads % 2 == 0 && M <= sta_pair::KROWS) {
-    if (int rc = sta_pair::pack_kv(k, v, (char*)packed + (size_t)n_ctx * heads * fwd_frags(ndt) * FRAG, n_ctx, M, C, heads, dtype, st)) return rc;
+    char* pair = (char*)packed + (size_t)n_ctx * heads * fwd_frags(ndt) * FRAG;
+    if (int rc = sta_pair::pack_kv(k, v, pair, n_ctx, M, C, heads, dtype, st)) return rc;
+    if (M <= sta_p3::KR)
+      if (int rc = sta_p3::pack_kv(k, v, pair + sta_pair::kv_bytes(n_ctx, heads), n_ctx, M, C, heads, dtype, st)) return rc;
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_kv_proj launch: %s", hipGetErrorString(e));
@@ -417,6 +422,12 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
   // launch still fills the chip with one pair workgroup per CU (level 0, 16 / 8 / 4 / 2 images: 73 / 42 / 25 / 16 us
   // against 92 / 51 / 29 / 17 us one head per workgroup; one image: 128 pair workgroups, 14.8 vs 12.1 us).
   const long pair_wgs = (long)((N + 127) / 128) * (heads / 2) * n_img;
+  if (g_sta_opt[STA_OPT_PROJ_PAIR] == 3 && sta_p3::eligible(C, heads, M, K)) {
+    const int ndt = (p.d + 15) / 16;
+    const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
+    const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG + sta_pair::kv_bytes(n_img * (K + 2), heads);
+    return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st);
+  }
   if (sta_pair::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2 && (pair_wgs >= 256 || g_sta_opt[STA_OPT_PROJ_PAIR] == 1)) {
     const int ndt = (p.d + 15) / 16;
     const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;

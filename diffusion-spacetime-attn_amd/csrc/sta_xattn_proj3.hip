@@ -1,0 +1,510 @@
+// sta_xattn_proj3.hip — projection-fused forward for HEAD PAIRS, second generation (d = 40: SD-v1 level 0, K <= 2).
+//
+// Same decomposition as its predecessor (a workgroup = 8 waves x 16 pixels keeps ONE head pair's operands in LDS — the
+// pair's Wq fragments and the K / V^T of every context — and walks strided pixel tiles: per tile the projection
+// Q^T = Wq_pair y^T of both batch rows, then per head the K+2 attentions and the masked blend), rebuilt around what the
+// round-2 instruction stream showed (profiles/r03_level0.md): the waves were parked on LDS latency — every operand
+// was requested right before the MFMA that consumed it — and a third of the vector instructions were register moves
+// that re-assembled operands from pairs of 8-byte reads.
+//
+//   * operand images are laid out so that ONE ds_read_b128 (or ds_read_b64) is one MFMA operand, with no padding FLOPs:
+//       S^T = K Q^T     per key tile: v_mfma_16x16x32 over 32 head dims + v_mfma_16x16x16 over the remaining 8 (+ 8 zeros)
+//       O^T = V^T P^T   per dim tile: 2 x v_mfma_16x16x32 over keys 0..63 + v_mfma_16x16x16 over keys 64..79
+//     K row = 96 B: 4 chunks [dims 4g.. | dims 16+4g..] + 4 units (dims 32..39, zeros)  (head B: shifted by the 8 dims
+//     that share projection tile 2 with head A — the ZEROS sit in the image, the q operands are plain conversions of
+//     the projection accumulators, one small operand serves both heads);  V^T row = 160 B: keys in S^T accumulator
+//     order (2 x 64 B) + keys 64..79; row 40 = ones (softmax denominator out of the PV MFMAs).
+//     13952 B per (ctx, head): 4 contexts x 2 heads + 50 KiB of Wq = 162816 B of the CU's 163840.
+//   * explicit software pipeline: the Wq fragments of k-step s+1 are requested before the MFMAs of step s; the K
+//     operands of the NEXT context are requested after this context's S^T MFMAs and land under its softmax, the V^T
+//     operands before them; sched_barrier(0) pins the request points (hipcc otherwise sinks every read to its use).
+//   * the denominator is broadcast with two permlane swaps instead of an LDS bpermute round trip.
+//
+// Reference replaced: ldm/modules/attention.py:178 (to_q), :175-197 (the K+2 attentions), :278-294 (masked blend);
+// reached through sta_xattn_fwd_proj (sta_xattn_proj.hip dispatches here). tools/emu_pair3.py holds the layout algebra.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "sta_xattn.h"
+#include "sta_internal.h"
+#include "sta_xattn_dev.h"
+#include "sta_xattn_proj3.h"
+
+// Ablation builds for tools/ (never in the product library; tools/lib_ab.py -DP3_ABL=n): 1 no output stores, 2 no y refills
+// (the ring is loaded once), 3 no attention (the projected q is stored instead), 4 no projection MFMAs, 5 no local contexts.
+#ifndef P3_ABL
+#define P3_ABL 0
+#endif
+
+namespace {
+
+using namespace sta_p3;
+
+template <typename T> struct M16;           // the k = 16 MFMA of the same type family
+template <> struct M16<_Float16> {
+  static __device__ __forceinline__ f32x4 mfma(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+template <> struct M16<__bf16> {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  static __device__ __forceinline__ f32x4 mfma(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+};
+
+// K, V [n_ctx][M][C] -> [ctx][head][K rows | V^T rows], BLK bytes each (layout: file header, tools/emu_pair3.py)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_kv_p3_kernel(const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ packed,
+                                                         int M, int C, int H) {
+  const int ch = blockIdx.x;                  // ctx * H + h
+  const int ctx = ch / H, h = ch % H, hp = h & 1;
+  T* blk = (T*)((char*)packed + (size_t)ch * BLK);
+  const T* kh = k + (size_t)ctx * M * C + h * D;
+  const T* vh = v + (size_t)ctx * M * C + h * D;
+  for (int i = threadIdx.x; i < BLK / 2; i += blockDim.x) {
+    T x = (T)0.0f;
+    if (i < KBYTES / 2) {
+      const int key = i / (KROW / 2), pos = i % (KROW / 2);
+      int dim = -1;
+      if (pos < 32) {
+        const int g = pos >> 3, j = pos & 7;
+        dim = hp == 0 ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : (j < 4 ? 8 + 4 * g + j : 24 + 4 * g + (j - 4));
+      } else {
+        const int g = (pos - 32) >> 2, j = (pos - 32) & 3;
+        if (hp == 0) { if (g < 2) dim = 32 + 4 * g + j; } else { if (g >= 2) dim = 4 * (g - 2) + j; }
+      }
+      if (key < M && dim >= 0) x = kh[(size_t)key * C + dim];
+    } else {
+      const int i2 = i - KBYTES / 2;
+      const int r = i2 / (VROW / 2), pos = i2 % (VROW / 2);
+      int key;
+      if (pos < 64) {
+        const int s = pos >> 5, g = (pos >> 3) & 3, j = pos & 7;
+        key = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
+      } else {
+        const int g = (pos - 64) >> 2, j = (pos - 64) & 3;
+        key = 64 + 4 * g + j;
+      }
+      if (key < M) x = r < D ? vh[(size_t)key * C + r] : (T)1.0f;
+    }
+    blk[i] = x;
+  }
+}
+
+struct P3 {
+  const void* y;
+  const char* wq;        // pair fragments: [pair][nkc][NT], 1 KiB each
+  const char* kv;        // [I][K+2][H][BLK]
+  const uint8_t* mask;
+  const float* coef;
+  void* out;
+  int N, C, H, M, K, W, tiles, iters;
+  float sl2e;
+};
+
+template <typename T> struct KFr {            // the K operands of one (context, head): 5 key tiles
+  typename Tr<T>::V8 big[NKT];
+  typename Tr<T>::V4 sm[NKT];
+};
+
+template <typename T>
+__device__ __forceinline__ void load_k(KFr<T>& kf, const char* kb, const char* ks) {
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    kf.big[t] = *(const typename Tr<T>::V8*)(kb + t * 16 * KROW);
+    kf.sm[t] = *(const typename Tr<T>::V4*)(ks + t * 16 * KROW);
+  }
+}
+
+// lane (g, c) <- lane (2, c): the denominator sits in lane row 2 (row 40 of O^T = tile 2, row 8). Two row swaps:
+// v_permlane32_swap (rows 0,1 <- rows 2,3), then v_permlane16_swap (odd rows <- even rows). Hand-placed wait states: with the
+// builtins hipcc let LDS reads stand in for the 2 wait states a swap needs after the VALU write of its operands, and the second
+// swap of every context but the first then read stale registers on gfx950 (tools/p3_debug2.py) — the s_nop are inside the string.
+__device__ __forceinline__ float bcast_row2(float x) {
+  unsigned t0, t1;
+  asm volatile("s_nop 1\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\t"
+               "v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %1, %0\n\ts_nop 1"
+               : "=&v"(t0), "=&v"(t1) : "v"(x));
+  return __uint_as_float(t1);
+}
+
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::V8 cat8(const f32x4& lo, const f32x4& hi) {
+  typename Tr<T>::V8 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = (T)lo[j]; r[4 + j] = (T)hi[j]; }
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ typename Tr<T>::V4 cvt4(const f32x4& a) {
+  typename Tr<T>::V4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = (T)a[j];
+  return r;
+}
+
+// One context of one head. kf holds its K operands on entry (requested a context earlier) and the NEXT context's on
+// exit (`knb`, `kns`: that block's per-lane K addresses). vb / vs: this context's per-lane V^T addresses.
+// KIND 0: "" on the uncond row -> au;  1: global prompt on the cond row -> ac;  2: local prompt, ac += w (A - au).
+template <typename T, int KIND>
+__device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* vs, const char* knb, const char* kns,
+                                        const typename Tr<T>::V8& qbig, const typename Tr<T>::V4& qsm, const f32x4 kb4,
+                                        const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3]) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  // V^T operands first: they land under the S^T MFMAs and the softmax
+  V8 vbig[3][2];
+  V4 vsm[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    vbig[u][0] = *(const V8*)(vb + u * 16 * VROW);
+    vbig[u][1] = *(const V8*)(vb + u * 16 * VROW + 64);
+    vsm[u] = *(const V4*)(vs + u * 16 * VROW);
+  }
+  f32x4 st[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = Tr<T>::mfma(kf.big[t], qbig, acc);
+    acc = M16<T>::mfma(kf.sm[t], qsm, acc);
+    st[t] = acc;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_k<T>(kf, knb, kns);                       // the next context's K operands: under this softmax and PV
+  softmax_biased(st, sl2e, false);               // denominator: ones row of V^T
+  const V8 p0 = cat8<T>(st[0], st[1]), p1 = cat8<T>(st[2], st[3]);
+  const V4 p2 = cvt4<T>(st[4]);
+  f32x4 o[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = Tr<T>::mfma(vbig[u][0], p0, acc);
+    acc = Tr<T>::mfma(vbig[u][1], p1, acc);
+    acc = M16<T>::mfma(vsm[u], p2, acc);
+    o[u] = acc;
+  }
+  // the reciprocal is taken in every lane BEFORE the broadcast (a VALU instruction hipcc pads against the MFMA that wrote
+  // o[2]); the asm then only moves registers
+  const float inv = bcast_row2(__builtin_amdgcn_rcpf(o[2][0]));
+  const float wi = w * inv;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    if (KIND == 0) au[u] = o[u] * inv;
+    else if (KIND == 1) ac[u] = o[u] * inv;
+    else ac[u] = o[u] * wi + (ac[u] - au[u] * w);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// Workgroup = 8 waves x 16 pixels, one HEAD PAIR, one image; walks `iters` strided pixel tiles.
+//
+// y rows (B operands of the projection): a 16x16x32 B operand wants lane (g, c) to hold 16 bytes of pixel c — one load
+// instruction then touches 16 rows x 64 B, i.e. 16 half-used 128-byte lines, and the vector-memory path (L1 tag rate, ~4
+// cycles per line per CU whatever the hit rate: tools/ubench/l2_gather.hip) was what bound both generations of this kernel.
+// YFULL: a load instruction covers 8 rows x one FULL line instead — lane (g, c) fetches row (c & 7), 16-byte slot
+// g + 4 (c >> 3) of the line that holds k-steps 2m and 2m+1 — and one DPP row_ror:8 move per dword hands the halves to the
+// lanes that need them (lanes c < 8 got their own pixel's step-2m slots and pixel c's ... see unit_operands). Same bytes,
+// same instruction count, half the lines.
+template <typename T, int NKC, bool YFULL>
+__global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  constexpr int NWV = 8, TP = 16 * NWV;
+  constexpr int RING = YFULL ? NKC : 5;           // k-steps of y in flight per batch row (YFULL: the whole row of the next tile)
+  static_assert(NKC % RING == 0 && (!YFULL || NKC % 2 == 0), "k-steps per tile: a multiple of the ring depth; full-line loads pair them");
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int PAIRS = p.H >> 1;
+  // block -> (image, tile group, pair): XCD-contiguous over the grid; the PAIRS workgroups of a tile group share y rows
+  const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int Lg = xcd_remap(lin, (int)(gridDim.x * gridDim.y));
+  const int img = Lg / (int)gridDim.x;
+  const int L = Lg - img * (int)gridDim.x;
+  const int wt = L / PAIRS, pr = L - wt * PAIRS;
+  const int N = p.N, C = p.C, K = p.K, W = p.W;
+  const unsigned row_bytes = (unsigned)C * (unsigned)sizeof(T);
+  const size_t act = (size_t)2 * N * row_bytes;
+  const char* yb = (const char*)p.y + img * act;
+  T* ob = (T*)((char*)p.out + img * act);
+  const uint8_t* mask = p.mask + (size_t)img * N;
+  const float coef_lane = p.coef[(size_t)img * K + min(lane, K > 0 ? K - 1 : 0)];
+  constexpr int nwq = NT * NKC;                   // Wq fragments of the pair (1 KiB each)
+  char* lds_kv = smem;                            // [ctx][hp][BLK]
+  char* lds_wq = smem + kv_region(K);             // behind the blocks: the V^T over-reads of the last block stay finite
+
+  // ---- prologue: LDS-DMA of every context (both heads: CTXB contiguous bytes each) and of the pair's Wq ----------
+  // The K/V region is copied as 1-KiB pieces at 1-KiB-ALIGNED LDS offsets (a piece = one global_load_lds_dwordx4 of the wave;
+  // a destination that is not 1-KiB aligned put a whole context in the wrong place on gfx950): a context is CTXB = 27.25 KiB,
+  // so a piece may straddle two contexts — every lane derives its own source address from its LDS offset. Lanes past the end
+  // of the region re-read its last 16 bytes into the gap in front of the Wq fragments (no exec-masked DMA).
+  {
+    const char* src0 = p.kv + ((size_t)img * (K + 2) * p.H + 2 * pr) * BLK;
+    const unsigned cstride = (unsigned)p.H * BLK;
+    const unsigned total = (unsigned)(K + 2) * CTXB;
+    for (unsigned f = (unsigned)wv; f * 1024u < total; f += NWV) {
+      unsigned b = f * 1024u + (unsigned)lane * 16u;
+      b = b < total ? b : total - 16u;
+      const unsigned c = b / (unsigned)CTXB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src0 + (size_t)c * cstride + (b - c * CTXB)),
+                                       (__attribute__((address_space(3))) void*)(lds_kv + f * 1024u), 16, 0, 0);
+    }
+    stage_frags(p.wq + (size_t)pr * nwq * FRAG, lds_wq, nwq, wv, NWV, lane);
+  }
+  const int mine = (p.tiles - wt + W - 1) / W;
+  const int iters = mine < p.iters ? mine : p.iters;
+  const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
+  const unsigned row1 = (unsigned)N * row_bytes;
+  auto tile_of = [&](int it) -> int { return wt + it * W; };
+  // per-lane byte offset of this lane's load(s) for tile `it`. Half-line shape: row c16, slot g. Full-line shape: two loads per
+  // line pair — `half` 0: rows 0..7 of the wave's 16 pixels, 1: rows 8..15 — lane (g, c) takes row (c & 7), slot g + 4 (c >> 3)
+  auto voff_of = [&](int it, int half = 0) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + (YFULL ? (c16 & 7) + 8 * half : c16);
+    const unsigned slot = YFULL ? (unsigned)(g + 4 * (c16 >> 3)) : (unsigned)g;
+    return (it < iters && px < N) ? (unsigned)px * row_bytes + slot * 16u : 0xfffffff0u;
+  };
+  auto mask_of = [&](int it) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + c16;
+    return mask[(it < iters && px < N) ? px : 0];
+  };
+  // ring slot j: half-line shape = k-step j of both batch rows; full-line shape = (line pair j >> 1, rows-half j & 1)
+  V8 yr0[RING], yr1[RING];
+  unsigned voff = voff_of(0), voffn = voff_of(1);
+  unsigned voffh = YFULL ? voff_of(0, 1) : 0u, voffhn = YFULL ? voff_of(1, 1) : 0u;
+  unsigned mb = mask_of(0);
+#pragma unroll
+  for (int j = 0; j < RING; ++j) {
+    const unsigned vo = (YFULL && (j & 1)) ? voffh : voff;
+    const unsigned so = YFULL ? 128u * (unsigned)(j >> 1) : 64u * (unsigned)j;
+    yr0[j] = srd_load16<V8>(y_srd, vo, so);
+    yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+  }
+  const f32x4 kb4 = last_tile_bias(g, p.M);
+  const float sl2e = p.sl2e;
+  const unsigned kmask = (1u << K) - 1u;
+  // per-lane byte offsets into a (ctx, head) block
+  const int koffb = c16 * KROW + 16 * g, koffs = c16 * KROW + 64 + 8 * g;
+  const int voffb = KBYTES + c16 * VROW + 16 * g, voffs = KBYTES + c16 * VROW + 128 + 8 * g;
+  const V8* wf = (const V8*)lds_wq + lane;
+  STA_T_INIT();
+  STA_T(0);
+  wait_dma_and_sync();
+  STA_T(1);
+
+  for (int it = 0; it < iters; ++it) {
+    if (it == 1) STA_T(2);
+    // ---- projection: 5 column tiles x both batch rows; Wq fragments one k-step ahead -------------------------------
+    f32x4 qa0[NT], qa1[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      qa0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      qa1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    V8 a[2][NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) a[0][u] = wf[u * 64];
+#pragma unroll
+    for (int s = 0; s < NKC; ++s) {
+      if (s + 1 < NKC) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) a[(s + 1) & 1][u] = wf[((s + 1) * NT + u) * 64];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (YFULL) {
+        // slots s & ~1 (rows 0..7: lanes c < 8 hold their own pixel's step-2m slots, lanes c >= 8 pixel c-8's step-2m+1 slots)
+        // and s | 1 (rows 8..15: lanes c < 8 hold pixel c+8's step-2m slots, lanes c >= 8 their own step-2m+1 slots).
+        // even step: c < 8 keeps A, c >= 8 takes ror8(B);  odd step: c < 8 takes ror8(A), c >= 8 keeps B.
+        const int ja = s & ~1, jb = s | 1;
+        V8 b0, b1;
+        {
+          const u32x4 A0 = __builtin_bit_cast(u32x4, yr0[ja]), B0 = __builtin_bit_cast(u32x4, yr0[jb]);
+          const u32x4 A1 = __builtin_bit_cast(u32x4, yr1[ja]), B1 = __builtin_bit_cast(u32x4, yr1[jb]);
+          u32x4 r0, r1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            if ((s & 1) == 0) {
+              r0[q] = (unsigned)__builtin_amdgcn_update_dpp((int)A0[q], (int)B0[q], 0x128, 0xF, 0xC, false);
+              r1[q] = (unsigned)__builtin_amdgcn_update_dpp((int)A1[q], (int)B1[q], 0x128, 0xF, 0xC, false);
+            } else {
+              r0[q] = (unsigned)__builtin_amdgcn_update_dpp((int)B0[q], (int)A0[q], 0x128, 0xF, 0x3, false);
+              r1[q] = (unsigned)__builtin_amdgcn_update_dpp((int)B1[q], (int)A1[q], 0x128, 0xF, 0x3, false);
+            }
+          }
+          b0 = __builtin_bit_cast(V8, r0);
+          b1 = __builtin_bit_cast(V8, r1);
+        }
+#if P3_ABL == 4
+#pragma unroll
+        for (int u = 0; u < NT; ++u) asm volatile("" :: "v"(a[s & 1][u]));
+        asm volatile("" :: "v"(b0), "v"(b1));
+        if (s == 0) { qa0[0] = __builtin_bit_cast(f32x4, b0); qa1[0] = __builtin_bit_cast(f32x4, b1); }
+#else
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          qa0[u] = Tr<T>::mfma(a[s & 1][u], b0, qa0[u]);
+          qa1[u] = Tr<T>::mfma(a[s & 1][u], b1, qa1[u]);
+        }
+#endif
+        if ((s & 1) && P3_ABL != 2) {       // the line pair is consumed: request the same pair of the NEXT tile into both slots
+          const unsigned so = 128u * (unsigned)(s >> 1);
+          yr0[ja] = srd_load16<V8>(y_srd, voffn, so);
+          yr1[ja] = srd_load16<V8>(y_srd, voffn, row1 + so);
+          yr0[jb] = srd_load16<V8>(y_srd, voffhn, so);
+          yr1[jb] = srd_load16<V8>(y_srd, voffhn, row1 + so);
+        }
+      } else {
+        const int j = s % RING;
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          qa0[u] = Tr<T>::mfma(a[s & 1][u], yr0[j], qa0[u]);
+          qa1[u] = Tr<T>::mfma(a[s & 1][u], yr1[j], qa1[u]);
+        }
+        // refill this ring slot with k-step s + RING: of this tile, or of the next one (zeros past the last tile)
+        const bool wrap = s + RING >= NKC;              // compile time after unrolling
+        const unsigned vo = wrap ? voffn : voff;
+        const unsigned so = 64u * (unsigned)(wrap ? s + RING - NKC : s + RING);
+        yr0[j] = srd_load16<V8>(y_srd, vo, so);
+        yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if ((s & 1) && s < 9) if (it == 1) STA_T(9 + (s >> 1));
+    }
+    if (it == 1) STA_T(3);
+    // K operands of the first context (head A, ctx 0): requested here, they land under the accumulator conversions
+    KFr<T> kf;
+    load_k<T>(kf, lds_kv + koffb, lds_kv + koffs);
+    const int px_own = tile_of(it) * TP + wv * 16 + c16;
+    const bool valid = px_own < N;
+    voff = voffn;
+    voffn = voff_of(it + 2);
+    if constexpr (YFULL) {
+      voffh = voffhn;
+      voffhn = voff_of(it + 2, 1);
+    }
+    const unsigned mbn = mask_of(it + 1);
+    const unsigned mbits = valid ? (mb & kmask) : 0u;
+    // local contexts some pixel of this wave needs (wave-uniform bit set)
+    unsigned wneed = 0;
+    for (int i = 0; i < K; ++i) wneed |= __ballot((mbits >> i) & 1u) ? (1u << i) : 0u;
+#if P3_ABL == 5
+    wneed = 0;
+#endif
+
+    // accumulators -> S^T B operands (rounded to T once). Head A: tiles 0 | 1 (+ tile 2 rows g < 2), head B: tiles 3 | 4
+    // (+ tile 2 rows g >= 2); the small operand (tile 2) serves both heads, the K images carry the zeros.
+    const V8 qA0 = cat8<T>(qa0[0], qa0[1]), qA1 = cat8<T>(qa1[0], qa1[1]);
+    const V8 qB0 = cat8<T>(qa0[3], qa0[4]), qB1 = cat8<T>(qa1[3], qa1[4]);
+    const V4 qs0 = cvt4<T>(qa0[2]), qs1 = cvt4<T>(qa1[2]);
+
+    // ---- attention + blend, head A then head B ------------------------------------------------------------------
+    auto head = [&](auto hb_tag, const V8& q0, const V8& q1) {
+      constexpr int HB = decltype(hb_tag)::value;
+      f32x4 au[3], ac[3];
+      const char* blk = lds_kv + HB * BLK;                       // (ctx 0, this head); contexts are CTXB apart
+      const char* other = lds_kv + (HB ^ 1) * BLK;               // what follows this head: head B's ctx 0, or head A's of the next tile
+      // block whose K operands to request during context `cur` (0, 1, or 2 + i): the next needed local context, else `other`
+      auto next_of = [&](int first_local) -> const char* {
+        const unsigned rest = wneed >> first_local;
+        return rest ? blk + (size_t)(2 + first_local + __builtin_ctz(rest)) * CTXB : other;
+      };
+      attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sl2e, 0.f, au, ac);
+      {
+        const char* nx = next_of(0);
+        attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sl2e, 0.f, au, ac);
+      }
+      for (int i = 0; i < K; ++i) {
+        if (!((wneed >> i) & 1u)) continue;
+        const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+        const float w = ((mbits >> i) & 1u) ? cw : 0.f;
+        const char* cb = blk + (size_t)(2 + i) * CTXB;
+        const char* nx = next_of(i + 1);
+        attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sl2e, w, au, ac);
+      }
+#if P3_ABL == 1
+#pragma unroll
+      for (int u = 0; u < 3; ++u) asm volatile("" :: "v"(au[u]), "v"(ac[u]));
+#else
+      if (valid) {
+        T* obase = ob + (size_t)px_own * C + (2 * pr + HB) * D;
+        store_row16<T, 3>(obase, au, g, D);
+        store_row16<T, 3>(obase + (size_t)N * C, ac, g, D);
+      }
+#endif
+    };
+#if P3_ABL == 3
+    if (valid) {        // no attention: store the projected q (same store instructions and bytes)
+      const f32x4 a0[3] = {qa0[0], qa0[1], qa0[2]}, a1[3] = {qa1[0], qa1[1], qa1[2]};
+      const f32x4 b0[3] = {qa0[2], qa0[3], qa0[4]}, b1[3] = {qa1[2], qa1[3], qa1[4]};
+      T* obase = ob + (size_t)px_own * C + (2 * pr) * D;
+      store_row16<T, 3>(obase, a0, g, D);
+      store_row16<T, 3>(obase + (size_t)N * C, a1, g, D);
+      store_row16<T, 3>(obase + D, b0, g, D);
+      store_row16<T, 3>(obase + D + (size_t)N * C, b1, g, D);
+    }
+    asm volatile("" :: "v"(kf.big[0]), "v"(qA0), "v"(qB1), "v"(qs0), "v"(qs1), "v"(qA1), "v"(qB0));
+#else
+    head(std::integral_constant<int, 0>{}, qA0, qA1);
+    if (it == 1) STA_T(4);
+    head(std::integral_constant<int, 1>{}, qB0, qB1);
+    if (it == 1) STA_T(5);
+#endif
+    mb = mbn;
+  }
+  STA_T(8);
+  STA_T_END();
+}
+
+template <typename T, int NKC, bool YFULL>
+int launch_p3(P3 p, int n_img, hipStream_t st) {
+  constexpr int TP = 128;
+  const int pairs = p.H / 2;
+  p.tiles = (p.N + TP - 1) / TP;
+  long wg = 256L / ((long)pairs * n_img);          // workgroups per (pair, image): one round of one workgroup per CU
+  if (wg < 1) wg = 1;
+  if (wg > p.tiles) wg = p.tiles;
+  p.iters = (int)((p.tiles + wg - 1) / wg);
+  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
+  p.W = (p.tiles + p.iters - 1) / p.iters;
+  const int lds = lds_bytes(p.C, p.K);
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YFULL>, 160 * 1024))
+    return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj p3) failed");
+  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YFULL>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj p3 launch: %s", hipGetErrorString(e));
+}
+
+}  // namespace
+
+#ifdef STA_TRACE
+extern "C" int sta_debug_set_trace_p3(void* buf) {      // trace build only (tools/trace_proj.py)
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
+
+namespace sta_p3 {
+
+int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype, hipStream_t st) {
+  const dim3 grid(n_ctx * heads);
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(pack_kv_p3_kernel<__bf16>, grid, dim3(256), 0, st, (const __bf16*)k, (const __bf16*)v, (__bf16*)packed, M, C, heads);
+  else
+    hipLaunchKernelGGL(pack_kv_p3_kernel<_Float16>, grid, dim3(256), 0, st, (const _Float16*)k, (const _Float16*)v, (_Float16*)packed, M, C, heads);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_kv_p3 launch: %s", hipGetErrorString(e));
+}
+
+int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* mask, const float* coef, void* out, int n_img,
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st) {
+  P3 p{};
+  p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv; p.mask = mask; p.coef = coef; p.out = out;
+  p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.sl2e = sl2e;
+  const bool half_lines = g_sta_opt[STA_OPT_PROJ_RING] == 5;       // A/B: the 16-rows-x-64-bytes load shape of the first generation
+  if (C == 320) {
+    if (dtype == STA_BF16) return half_lines ? launch_p3<__bf16, 10, false>(p, n_img, st) : launch_p3<__bf16, 10, true>(p, n_img, st);
+    return half_lines ? launch_p3<_Float16, 10, false>(p, n_img, st) : launch_p3<_Float16, 10, true>(p, n_img, st);
+  }
+  return dtype == STA_BF16 ? launch_p3<__bf16, 5, false>(p, n_img, st) : launch_p3<_Float16, 5, false>(p, n_img, st);
+}
+
+}  // namespace sta_p3

@@ -98,8 +98,15 @@ def object_crop_box(centre, height, width, half=0.2):
 
 class PLMSSampler(object):
     def __init__(self, model, schedule="linear", loss_model=None, opt_epochs=3, lr=0.005, weight_init=5.0,
-                 local_loss_weight=5.0, use_graph=True, save_images=True, outdir="result_outputs/", **kwargs):
+                 local_loss_weight=5.0, use_graph=True, save_images=True, outdir="result_outputs/", loss_scale=None, **kwargs):
+        """`loss_scale`: the fidelity loss is multiplied by it before backward and W.grad divided by it before the Adam step.
+        None = 2^12 when the model computes in fp16, 1 otherwise. The backward of a tracked epoch runs through 2 x 51 UNet calls
+        and the VAE decoder in the model's 16-bit type: with a CLIP loss the per-pixel gradients are ~1e-6 and smaller, i.e.
+        fp16-subnormal or zero, and W.grad would lose precision or flush to 0 silently (bf16 has fp32's exponent range and needs
+        nothing). A power of two scales exactly, so the unscaled W.grad equals the unscaled computation wherever that one is
+        representable (the reference relies on CUDA autocast with fp32 parameters and no scaler, scripts/txt2img-gpt.py:301)."""
         super().__init__()
+        self.loss_scale = loss_scale
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
@@ -219,21 +226,26 @@ class PLMSSampler(object):
             tuned = track and torch.cuda.is_available() and torch.cuda.tunable.is_enabled()
             if tuned:
                 torch.cuda.tunable.enable(False)
-            with torch.set_grad_enabled(track):
-                img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
-                                       time_range, W if batched else W[0], block_boxes, text_index,
-                                       graph=self.use_graph and not track)
-                x_img = None
-                if self.model.first_stage_model is not None:
-                    x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
-                if track:
-                    loss = sum(self._fidelity_loss(x_img[i].float(), texts[i], boxes[i], names[i]) for i in range(b))
-                    optimizer.zero_grad()
-                    loss.backward()
-                    optimizer.step()
-                    result.setdefault("losses", []).append(float(loss.detach()))
-            if tuned:
-                torch.cuda.tunable.enable(True)
+            try:
+                with torch.set_grad_enabled(track):
+                    img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
+                                           time_range, W if batched else W[0], block_boxes, text_index,
+                                           graph=self.use_graph and not track)
+                    x_img = None
+                    if self.model.first_stage_model is not None:
+                        x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
+                    if track:
+                        loss = sum(self._fidelity_loss(x_img[i].float(), texts[i], boxes[i], names[i]) for i in range(b))
+                        optimizer.zero_grad()
+                        scale = self._loss_scale()
+                        (loss * scale if scale != 1.0 else loss).backward()
+                        if scale != 1.0:
+                            W.grad.div_(scale)
+                        optimizer.step()
+                        result.setdefault("losses", []).append(float(loss.detach()))
+            finally:
+                if tuned:            # an exception inside the epoch (OOM, missing CLIP, Ctrl-C) must not leave the process-wide switch off
+                    torch.cuda.tunable.enable(True)
             if last:
                 result.update(x0=img.detach(), image=None if x_img is None else x_img.detach(),
                               W=(W if batched else W[0]).detach().clone())
@@ -242,6 +254,11 @@ class PLMSSampler(object):
                         self._save(x_img[i], epochs - 1, seed, pidx[i])
         self.last_result = result
         return None
+
+    def _loss_scale(self):
+        if self.loss_scale is not None:
+            return float(self.loss_scale)
+        return 4096.0 if next(self.model.model.parameters()).dtype == torch.float16 else 1.0
 
     def _fidelity_loss(self, image, curr_text, bboxs_curr, object_names):
         if self.clip_loss_model is None:

@@ -78,7 +78,7 @@ def run(kind, default_dataset):
         raise SystemExit("--n_samples must be 1 (the blocks reshape to the CFG batch of 2, attention.py:282)")
     from ldm.models.diffusion.plms import PLMSSampler
     from sta import datasets, parallel
-    from sta.pipeline import build_sd_v1, conditionings
+    from sta.pipeline import build_sd_v1, conditionings, use_shipped_miopen_db, use_tuned_gemms
 
     rank, world, local = parallel.init_from_env()
     if not torch.cuda.is_available():
@@ -86,6 +86,8 @@ def run(kind, default_dataset):
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float16
+    use_shipped_miopen_db(local)      # per-rank copy of the shipped MIOpen find-db; a different MIOpen build ignores it
+    use_tuned_gemms()                 # measured GEMM table (lookup only); ignored by a different PyTorch / hipBLASLt build
 
     prompts = datasets.load_prompts(opt.dataset, kind, opt.limit)
     layouts = datasets.load_layouts(opt.layout) if opt.layout else None
@@ -93,7 +95,7 @@ def run(kind, default_dataset):
     if ckpt is None and not opt.synthetic:
         raise SystemExit("checkpoint %s not found (pass --synthetic to run with synthetic weights)" % opt.ckpt)
     loss_model = None
-    if opt.opt_epochs > 0:        # fail here, not after the first 51-call trajectory
+    if opt.opt_epochs > 1:        # the sampler evaluates the loss only when an epoch is tracked (opt_epochs > 1); fail here, not after the first 51-call trajectory
         from ldm.models.diffusion.plms import DCLIPLoss, load_clip_model
         if opt.clip == "synthetic":
             from sta.synth import SyntheticCLIP

@@ -39,20 +39,23 @@ def _broadcast_flat(flat, src, world):
     """One bucket from `src` to every rank as SCATTER + ALL-GATHER instead of a ring broadcast: xGMI is a full mesh
     of point-to-point links (7 x ~153 GB/s per GPU), so the root sends a different 1/world of the bucket down each
     of its links at once and the ranks then exchange their pieces over all links — the root's egress carries the
-    bucket once in total instead of once per ring hop. Falls back to dist.broadcast for tiny buckets."""
+    bucket once in total instead of once per ring hop.
+
+    The algorithm is a pure function of (bucket length, world size) — the same on every rank, decided before anything
+    is sent — and no exception is caught around a collective: a rank that failed alone inside one would otherwise leave
+    the group with mismatched calls (hang). Both backends used here implement scatter (RCCL through send/recv, gloo
+    natively). Tiny buckets go as one plain broadcast."""
     n = flat.numel()
     if n < 4096 * world:
         dist.broadcast(flat, src=src)
         return
     per = (n + world - 1) // world
-    padded = flat if per * world == n else torch.cat([flat, flat.new_zeros(per * world - n)])
     piece = torch.empty(per, dtype=flat.dtype, device=flat.device)
-    try:
-        dist.scatter(piece, list(padded.view(world, per).unbind(0)) if dist.get_rank() == src else None, src=src)
-    except (RuntimeError, NotImplementedError):
-        # a backend without scatter refuses on every rank before anything is sent: the plain broadcast is the same on all of them
-        dist.broadcast(flat, src=src)
-        return
+    pieces = None
+    if dist.get_rank() == src:           # only the root builds the (padded) scatter list
+        padded = flat if per * world == n else torch.cat([flat, flat.new_zeros(per * world - n)])
+        pieces = list(padded.view(world, per).unbind(0))
+    dist.scatter(piece, pieces, src=src)
     gathered = torch.empty(per * world, dtype=flat.dtype, device=flat.device)
     dist.all_gather_into_tensor(gathered, piece)
     flat.copy_(gathered[:n])

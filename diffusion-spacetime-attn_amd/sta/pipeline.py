@@ -22,8 +22,29 @@ from sta import synth
 # and is used unless the caller points MIOPEN_USER_DB_PATH elsewhere. A different MIOpen build ignores the file (its
 # name carries the build id) and searches as before; new shapes are searched and appended.
 USER_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "miopen_userdb")
-if os.path.isdir(USER_DB) and os.access(USER_DB, os.W_OK):
-    os.environ.setdefault("MIOPEN_USER_DB_PATH", USER_DB)
+
+
+def use_shipped_miopen_db(rank=None):
+    """Point MIOpen's USER find-db at a per-user (and per-rank) COPY of the shipped one. MIOpen appends newly searched shapes
+    to the files of that directory, so the tracked files inside the package are never the live db (they would change on every
+    run, and all ranks of a multi-GPU job would write them at once). Explicit opt-in of bench.py and the entry-point scripts;
+    importing this module changes nothing in the environment. A MIOPEN_USER_DB_PATH the caller already set wins."""
+    if "MIOPEN_USER_DB_PATH" in os.environ or not os.path.isdir(USER_DB):
+        return os.environ.get("MIOPEN_USER_DB_PATH")
+    import shutil
+    if rank is None:
+        rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dst = os.path.join(os.path.expanduser(os.environ.get("XDG_CACHE_HOME", "~/.cache")), "sta", "miopen", "rank%d" % rank)
+    try:
+        os.makedirs(dst, exist_ok=True)
+        for name in os.listdir(USER_DB):
+            if not os.path.exists(os.path.join(dst, name)):
+                shutil.copy(os.path.join(USER_DB, name), os.path.join(dst, name))
+    except OSError:
+        return None                      # read-only home: MIOpen searches as on a fresh box
+    os.environ["MIOPEN_USER_DB_PATH"] = dst
+    return dst
+
 
 # The GEMM library picks a kernel per shape by heuristic; for the Linear layers of the bench shapes (fp16, 32 prompts per
 # step) PyTorch's TunableOp measured every hipBLASLt / rocBLAS candidate once on an MI355X (e.g. the level-0 GEGLU
@@ -34,14 +55,14 @@ TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "
 
 
 def use_tuned_gemms():
+    """Explicit opt-in (bench.py, the entry-point scripts): TunableOp is a PROCESS-WIDE switch other models share."""
     if "PYTORCH_TUNABLEOP_ENABLED" in os.environ or not os.path.exists(TUNED_GEMMS) or not torch.cuda.is_available():
         return False
-    import tempfile
     import torch.cuda.tunable as tun
     try:
         tun.enable(True)
         tun.tuning_enable(False)
-        tun.set_filename(os.path.join(tempfile.gettempdir(), "sta_tunableop_%d.csv" % os.getpid()))   # its exit-time dump stays out of the package
+        tun.write_file_on_exit(False)              # a lookup table: nothing is measured, nothing to dump at exit
         ok = bool(tun.read_file(TUNED_GEMMS))
     except Exception:
         ok = False
@@ -81,8 +102,6 @@ def build_sd_v1(device="cuda", dtype=torch.float16, ckpt=None, seed=0, with_vae=
     else:
         text = SyntheticTextEmbedder().to(device)
     model = LatentDiffusion(unet_config=unet, first_stage_config=vae, cond_stage_config=text).to(device)
-    if torch.device(device).type == "cuda":
-        use_tuned_gemms()
     if channels_last and torch.device(device).type == "cuda":
         # NHWC activations and weights for the UNet trunk: MIOpen's bf16 convolutions are NHWC kernels (the NCHW path
         # wraps each of them in two transposes), the b c h w <-> b (hw) c reshapes around the transformer blocks
@@ -100,7 +119,9 @@ def build_sd_v1(device="cuda", dtype=torch.float16, ckpt=None, seed=0, with_vae=
     for p in model.parameters():
         p.requires_grad_(False)      # frozen: the optimisation variable is the weights tensor only (plms.py:214)
     if ckpt is not None:
-        sd = torch.load(ckpt, map_location="cpu")
+        # sd-v1-4.ckpt pickles pytorch_lightning callback objects next to the state_dict: torch >= 2.6 refuses them under the
+        # weights_only default. The checkpoint is the user's own trusted file (as for the reference, txt2img-gpt.py:57).
+        sd = torch.load(ckpt, map_location="cpu", weights_only=False)
         sd = sd.get("state_dict", sd)
         missing, unexpected = model.load_state_dict(sd, strict=False)
         # parameters were materialised uninitialised (to_empty): a key the checkpoint lacks would stay HBM garbage

@@ -204,10 +204,11 @@ def test_domain_properties_full_size():
 
 
 @pytest.mark.parametrize("N,C,heads,K", [(4096, 320, 8, 2), (1024, 640, 8, 2), (64, 1280, 8, 2), (100, 128, 4, 3), (256, 192, 8, 0)])
-def test_batched_images_match_oracle_per_image(N, C, heads, K):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_batched_images_match_oracle_per_image(N, C, heads, K, dtype):
     """n_img = 3 images in one launch (forward and backward) == the oracle on each image."""
     from sta import ops
-    I, dtype, dev = 3, torch.bfloat16, "cuda"
+    I, dev = 3, "cuda"
     cases = [_case(N, C, heads, K, dtype, seed=20 + i) for i in range(I)]
     q = torch.cat([c[0] for c in cases]); k = torch.cat([c[1] for c in cases]); v = torch.cat([c[2] for c in cases])
     masks = [c[3] for c in cases]; coef = torch.stack([c[4] for c in cases]) if K else None
@@ -219,7 +220,7 @@ def test_batched_images_match_oracle_per_image(N, C, heads, K):
     dout = torch.randn(2 * I, N, C, generator=g).to(dtype)
     dq, dcoef = ops.xattn_backward(q.to(dev), packed, mb, coef.to(dev) if K else None, dout.to(dev), scale)
     torch.cuda.synchronize()
-    eps = 2.0 ** -8
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     for i in range(I):
         qi, ki, vi, mi, ci = cases[i]
         qd = qi.double().requires_grad_(True)
@@ -245,13 +246,19 @@ def test_batched_images_match_oracle_per_image(N, C, heads, K):
     (4000, 320, 8, 3, 4, 5),       # N not a multiple of the tile, forced tile count
     (4096, 384, 8, 6, 4, 3),       # 8 contexts do not fit LDS together: groups are re-staged for every tile
     (256, 1280, 8, 2, 8, None),    # d = 160: two LDS groups per tile
+    # the launches of the default bench step (bench.py: 32 prompts per UNet call, fp16) at the four SD-v1 levels
+    (4096, 320, 8, 2, 32, None),   # level 0 through sta_xattn_fwd (the tracked epochs / K > 2 take it; fixed weights fuse to_q)
+    (1024, 640, 8, 2, 32, None),   # level 1
+    (256, 1280, 8, 2, 32, None),   # level 2
+    (64, 1280, 8, 2, 32, None),    # middle block
 ])
-def test_multi_tile_workgroups(N, C, heads, K, I, iters):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_multi_tile_workgroups(N, C, heads, K, I, iters, dtype):
     """Throughput-regime launches (several images, workgroups that keep one head's fragments in LDS and walk
     several strided pixel tiles): every image equals (a) the same image launched alone through the
     wave-per-context kernel and (b), for the first and last image, the CPU oracle."""
     from sta import ops
-    dtype, dev = torch.bfloat16, "cuda"
+    dev = "cuda"
     from sta import lib
     if iters is not None:
         lib.set_option(lib.OPT_STAGED_TILES, iters)
@@ -265,8 +272,8 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters):
     torch.cuda.synchronize()
     lib.set_option(lib.OPT_STAGED_TILES, 0)
     lib.set_option(lib.OPT_FWD_KERNEL, lib.FWD_SPLIT)
-    eps = 2.0 ** -8
-    for i in range(I):
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for i in (range(I) if I <= 16 else (0, 1, I // 2, I - 2, I - 1)):
         qi, ki, vi, mi, ci = cases[i]
         alone, _ = ops.xattn_forward(qi.to(dev), ops.pack_kv(ki.to(dev), vi.to(dev), heads), ops.mask_bits(mi).to(dev), ci.to(dev), scale)
         a, b = out[2 * i:2 * i + 2].float(), alone.float()
@@ -539,6 +546,7 @@ PROJ_SHAPES = [
     (4096, 320, 8, 2, 4, None, 0, True),     # BASELINE level 0, 4 prompts
     (4096, 320, 8, 2, 16, None, 0, True),    # the bench launch: 16 prompts, 4 head pairs x 4 workgroups per image, 8 tiles each
     (4096, 320, 8, 2, 16, None, 0, False),   # 16 tiles per workgroup, one head each
+    (4096, 320, 8, 2, 32, None, 0, True),    # the DEFAULT bench launch (32 prompts per UNet call): 256 pair workgroups x 16 tiles, one round
     (4096, 320, 8, 1, 3, None, 4, True),     # one object, 4-wave workgroups
     (4096, 320, 8, 0, 2, None, 0, True),     # no objects
     (1000, 160, 4, 2, 2, 3, 4, True),        # ragged N, 2 head pairs, forced tile count
@@ -583,6 +591,57 @@ def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, pair, dtype):
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     a, b = out.float(), unfused.float()
     # same arithmetic up to the summation order of the projection (a q element may round the other way: 1 ulp of q)
+    assert ((a - b).abs() <= 4 * eps * (1.0 + b.abs())).all(), (a - b).abs().max().item()
+    for i in sorted({0, I - 1}):
+        yi, ki, vi, mi, ci = cases[i]
+        q16 = (yi.double() @ wq.double().t()).to(dtype)
+        ref = orc.fused_xattn(q16.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
+        err = (a[2 * i:2 * i + 2].cpu().double() - ref).abs()
+        assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
+
+
+P3_SHAPES = [
+    # N, C, heads, K, images, forced tiles per workgroup, keys
+    (256, 320, 8, 2, 1, None, 77),        # two 128-pixel tiles, one per workgroup
+    (4096, 320, 8, 2, 4, None, 77),
+    (4096, 320, 8, 2, 32, None, 77),      # the default bench launch: 256 pair workgroups x 16 tiles, one round
+    (4096, 320, 8, 1, 3, None, 77),       # one object: ragged tile counts per workgroup
+    (4096, 320, 8, 0, 2, None, 77),       # no objects
+    (1000, 160, 4, 2, 2, 3, 77),          # ragged N, C = 160 (5 k-steps), 2 head pairs, forced tile count
+    (1000, 160, 4, 2, 2, 3, 66),          # fewer keys than rows stored: rows 66 .. 76 are zero, the bias masks them
+    (9216, 320, 8, 2, 2, None, 77),       # 768^2 with 2 objects
+]
+
+
+@pytest.mark.parametrize("N,C,heads,K,I,tiles,M", P3_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fwd_proj_p3_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
+    """Second-generation head-pair kernel (csrc/sta_xattn_proj3.hip: single-read operand images, 16x16x32 + 16x16x16 MFMAs,
+    software-pipelined LDS reads) vs the oracle fed with q = round16(y Wq^T), image 0 and the last image, and vs the
+    unfused GPU path on every image."""
+    from sta import lib, ops
+    dev = "cuda"
+    g = torch.Generator().manual_seed(N + C + K)
+    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype)
+    cases = [_case(N, C, heads, K, dtype, seed=170 + i, M=M) for i in range(I)]
+    y = torch.cat([c[0] for c in cases]).to(dev)
+    k = torch.cat([c[1] for c in cases]).to(dev)
+    v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    scale = (C // heads) ** -0.5
+    if tiles is not None:
+        lib.set_option(lib.OPT_STAGED_TILES, tiles)
+    lib.set_option(lib.OPT_PROJ_PAIR, 3)
+    out = ops.xattn_forward_proj(y, ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I), mb, coef, scale)
+    torch.cuda.synchronize()
+    lib.set_option(lib.OPT_STAGED_TILES, 0)
+    lib.set_option(lib.OPT_PROJ_PAIR, 0)
+    q_gemm = torch.nn.functional.linear(y, wq.to(dev))
+    unfused, _ = ops.xattn_forward(q_gemm, ops.pack_kv(k, v, heads, n_img=I), mb, coef, scale)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    a, b = out.float(), unfused.float()
+    assert torch.isfinite(a).all()
     assert ((a - b).abs() <= 4 * eps * (1.0 + b.abs())).all(), (a - b).abs().max().item()
     for i in sorted({0, I - 1}):
         yi, ki, vi, mi, ci = cases[i]

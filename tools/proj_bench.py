@@ -78,8 +78,14 @@ def main():
             lib.set_option(lib.OPT_PROJ_RING, 0)
             return r
         arms["pair_w%d_r%d" % (w, ring)] = pair
+    def p3():
+        lib.set_option(lib.OPT_PROJ_PAIR, 3)
+        r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
+        lib.set_option(lib.OPT_PROJ_PAIR, 0)
+        return r
+    arms["p3"] = p3
     if a.only:
-        arms = {k_: f for k_, f in arms.items() if k_.startswith(a.only) or (a.only == "proj" and k_.startswith("pair"))}
+        arms = {k_: f for k_, f in arms.items() if any(k_.startswith(o) for o in a.only.split(",")) or (a.only == "proj" and k_.startswith("pair"))}
     res = {n: [] for n in arms}
     for _ in range(a.rounds):
         for n, f in arms.items():
@@ -89,7 +95,7 @@ def main():
     byts = I * (8.0 * N * C + 4.0 * (K + 2) * M * C + K * N) + 2.0 * C * C
     out = {"N": N, "C": C, "K": K, "imgs": I, "dtype": a.dtype, "us": res, "attn_gflop": f_attn / 1e9, "proj_gflop": f_proj / 1e9, "mbytes": byts / 1e6}
     for n, v_ in res.items():
-        if n.startswith("proj") or n.startswith("pair"):
+        if n.startswith("proj") or n.startswith("pair") or n.startswith("p3"):
             us = min(v_)
             out[n + "_tflops"] = round((f_attn + f_proj) / us / 1e6, 1)
             out[n + "_gbps"] = round(byts / us / 1e3, 1)
