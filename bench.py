@@ -56,11 +56,12 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue the UNet eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="(default when --opt-epochs 0) NHWC UNet trunk")
-    ap.add_argument("--checkpoint", choices=["auto", "all", "res", "none"], default="auto",
+    ap.add_argument("--checkpoint", choices=["auto", "all", "res", "none", "call"], default="auto",
                     help="weight optimisation: which blocks recompute their forward in backward. all = ResBlocks and "
                          "transformer blocks (the reference); res = ResBlocks only; none = keep every activation of the 51 "
-                         "UNet calls (79.5 GiB per prompt at 512x512 — 288 GB of HBM hold two prompts). auto = none for "
-                         "<= 2 prompts per step, res for <= 4, all otherwise (sta.pipeline.set_recompute)")
+                         "UNet calls (79.5 GiB per prompt at 512x512 — 288 GB of HBM hold two prompts); call = per UNet CALL behind "
+                         "the fixed-weight forward (16 KB kept per call and image). auto = none for <= 2 prompts per step, call "
+                         "above (sta.pipeline.set_recompute)")
     ap.add_argument("--nchw", action="store_true", help="keep the UNet trunk in NCHW (2.6%% slower at 8 prompts per step)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the bounded side measurement after the headline run "
@@ -190,6 +191,20 @@ def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps
     lat = res // 8
     centres = [list(c) for c in DEFAULT_CENTRES[:K]]
     x_T1 = torch.randn([1, 4, lat, lat], generator=torch.Generator(device=dev).manual_seed(1), device=dev)
+    calib = None
+    if opt_epochs > 1:
+        # synthetic VAE weights saturate the image clamp (zero loss gradient): rescale the decoder's last convolution on one
+        # fixed-weight sample so that the tracked epochs optimise something (sta.synth.calibrate_decoder_)
+        from sta.synth import calibrate_decoder_
+        pre = PLMSSampler(model, opt_epochs=0, use_graph=False, save_images=False)
+        rec = prompts[0]
+        nm = (rec["objects"] + ["object"] * K)[:K]
+        uc0, c0, l0 = conditionings(model, rec["prompt"], nm, dt)
+        pre.sample(S=ddim_steps, conditioning=c0, batch_size=1, shape=[4, lat, lat], verbose=False, unconditional_guidance_scale=7.5,
+                   unconditional_conditioning=uc0, eta=0.0, x_T=x_T1, text_index=0, curr_text=rec["prompt"], bboxs_curr=centres, seed=1,
+                   prompt_idx=0, object_names=nm, local_conditionings=l0)
+        calib = calibrate_decoder_(model, pre.last_result["x0"])
+        del pre
 
     def step(j):
         recs = [prompts[(j * images + i) % len(prompts)] for i in range(images)]
@@ -213,6 +228,10 @@ def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps
     out = {"value": steps * images / el, "unit": "images/s", "dtype": dtype_name, "images_per_step": images, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * el / steps}
     if opt_epochs:
+        w0 = sampler.weight_init / max(K, 1)
+        moved = float((r["W"] - w0).abs().max()) if K else 0.0
+        assert K == 0 or opt_epochs < 2 or moved > 0.0, "the tracked epochs did not move the blend weights (zero gradient)"
+        out.update(W_moved=moved, decoder_calibration={"mean_before": calib[0], "std_before": calib[1], "std_after": 0.25} if calib else None)
         out.update(opt_epochs=opt_epochs, recompute=mode, miopen_find=bool(find), loss="CLIP stand-in (sta.synth.SyntheticCLIP): real front-end, VAE decode "
                    "and backward through 2 x 51 UNet calls; the third epoch runs the fixed-weight path", losses=r.get("losses"))
     del sampler, model
@@ -406,7 +425,7 @@ def main():
         # immediate mode (no search, slower solvers)
         find = a.dtype == "fp16" and a.res == 512
         torch.backends.cudnn.benchmark = find
-        out["weight_optimisation"] = side_run(dev, a.dtype, 3, 2, 1, 1, a.res, a.ddim_steps, K, find=find)
+        out["weight_optimisation"] = side_run(dev, a.dtype, 3, 16 if a.res <= 512 else 2, 1, 1, a.res, a.ddim_steps, K, find=find)
         out["weight_optimisation"]["config"] = "BASELINE configs[2]: %dx%d, %d PLMS steps, %d objects, 3 epochs of per-step blend-weight optimisation" % (
             a.res, a.res, a.ddim_steps, K)
     _phase("side runs done")

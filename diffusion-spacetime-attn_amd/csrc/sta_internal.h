@@ -22,7 +22,14 @@ struct StaLdsAttr {
   }
 };
 
-// kernel-selection overrides set through sta_set_option (include/sta_xattn.h); 0 = automatic
+// kernel-selection overrides set through sta_set_option (include/sta_xattn.h); 0 = automatic. Relaxed atomics: a test or tool
+// thread may flip one while another thread launches (each launch reads every key it needs exactly once per decision).
+#include <atomic>
 #include "sta_xattn.h"
-extern int g_sta_opt[STA_OPT_COUNT];
+struct StaOpt {
+  std::atomic<int> v{0};
+  operator int() const { return v.load(std::memory_order_relaxed); }
+  void operator=(int x) { v.store(x, std::memory_order_relaxed); }
+};
+extern StaOpt g_sta_opt[STA_OPT_COUNT];
 #endif

@@ -943,7 +943,7 @@ __global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restri
 // error text shared by every translation unit of the library (sta_internal.h)
 thread_local char g_sta_err[256] = "";
 // kernel-selection overrides (sta_set_option): 0 = automatic. Written by tests/tools only, read at launch.
-int g_sta_opt[STA_OPT_COUNT] = {};
+StaOpt g_sta_opt[STA_OPT_COUNT];
 int sta_fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

@@ -24,7 +24,6 @@
 #include "sta_xattn.h"
 #include "sta_internal.h"
 #include "sta_xattn_dev.h"
-#include "sta_xattn_proj2.h"
 #include "sta_xattn_proj3.h"
 
 namespace {
@@ -109,7 +108,7 @@ struct PParams {
 //                 (attend_staged, shared with sta_xattn.hip) — blend in registers, 16-byte stores.
 // No barrier after the prologue: waves drift apart, one wave's projection MFMAs run beside another's softmax VALU.
 template <typename T, int NDT, int NWV, int RING>
-__global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 2) void xattn_fwd_proj_kernel(const PParams p) {
+__global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PParams p) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
   constexpr int NFWD = fwd_frags(NDT);
@@ -272,15 +271,10 @@ int launch_proj_cfg(PParams p, int n_img, int lds, hipStream_t st) {
 
 template <typename T, int NDT>
 int launch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
-  int nwv = 8;
-  if (const int v = g_sta_opt[STA_OPT_STAGED_WAVES]) nwv = v == 12 ? 12 : (v == 4 ? 4 : 8);
-  // ring depth 5 ships. The 10-deep ring (a whole row of a tile at C = 320, 198 registers) measured SLOWER — 96.8 vs
-  // 89 us: the y stream is throughput bound in the L2 -> L1 path (7.6 TB/s chip-wide for these half-line gathers,
-  // profiles/r02_proj_fusion.md), more loads in flight only lengthen the queue — and stays reachable for A/B runs.
-  const bool deep = p.nkc % 10 == 0 && g_sta_opt[STA_OPT_PROJ_RING] == 10;
-  if (nwv == 12) return launch_proj_cfg<T, NDT, 12, 5>(p, n_img, lds, st);
-  if (nwv == 4) return deep ? launch_proj_cfg<T, NDT, 4, 10>(p, n_img, lds, st) : launch_proj_cfg<T, NDT, 4, 5>(p, n_img, lds, st);
-  return deep ? launch_proj_cfg<T, NDT, 8, 10>(p, n_img, lds, st) : launch_proj_cfg<T, NDT, 8, 5>(p, n_img, lds, st);
+  // 8 waves (two per SIMD) x a 5-deep y ring ship; a 12-wave workgroup and a 10-deep ring measured no better in round 2
+  // (profiles/r02_proj_fusion.md) and are gone. 4-wave workgroups stay reachable for small launches (tests).
+  if (g_sta_opt[STA_OPT_STAGED_WAVES] == 4) return launch_proj_cfg<T, NDT, 4, 5>(p, n_img, lds, st);
+  return launch_proj_cfg<T, NDT, 8, 5>(p, n_img, lds, st);
 }
 
 template <typename T>
@@ -335,8 +329,8 @@ size_t sta_xattn_packed_wq_bytes(int C, int heads) {
   if (C <= 0 || heads <= 0 || C % heads || C % 32) return 0;
   const int d = C / heads;
   if (d % 8 || d > STA_MAX_HEAD_DIM) return 0;
-  // + the head-PAIR fragments (sta_xattn_proj2.hip) where that kernel applies
-  return (size_t)heads * ((d + 15) / 16) * (C / 32) * FRAG + (sta_pair::shape_ok(C, heads) ? sta_pair::wq_bytes(C, heads) : 0);
+  // + the head-PAIR fragments (sta_xattn_proj3.hip) where that kernel applies
+  return (size_t)heads * ((d + 15) / 16) * (C / 32) * FRAG + (sta_p3::shape_ok(C, heads) ? sta_p3::wq_bytes(C, heads) : 0);
 }
 
 int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype, void* stream) {
@@ -351,13 +345,13 @@ int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype,
     hipLaunchKernelGGL(pack_wq_kernel<__bf16>, grid, dim3(64), 0, st, (const __bf16*)wq, (__bf16*)packed, C, d, ndt);
   else
     hipLaunchKernelGGL(pack_wq_kernel<_Float16>, grid, dim3(64), 0, st, (const _Float16*)wq, (_Float16*)packed, C, d, ndt);
-  if (sta_pair::shape_ok(C, heads)) {      // the same weights per head PAIR: 2d = 80 output columns = 5 tiles, no padding
+  if (sta_p3::shape_ok(C, heads)) {      // the same weights per head PAIR: 2d = 80 output columns = 5 tiles, no padding
     char* pair = (char*)packed + (size_t)heads * ndt * (C / 32) * FRAG;
-    const dim3 g2(sta_pair::NT * (C / 32), heads / 2);
+    const dim3 g2(sta_p3::NT * (C / 32), heads / 2);
     if (dtype == STA_BF16)
-      hipLaunchKernelGGL(pack_wq_kernel<__bf16>, g2, dim3(64), 0, st, (const __bf16*)wq, (__bf16*)pair, C, 2 * d, sta_pair::NT);
+      hipLaunchKernelGGL(pack_wq_kernel<__bf16>, g2, dim3(64), 0, st, (const __bf16*)wq, (__bf16*)pair, C, 2 * d, sta_p3::NT);
     else
-      hipLaunchKernelGGL(pack_wq_kernel<_Float16>, g2, dim3(64), 0, st, (const _Float16*)wq, (_Float16*)pair, C, 2 * d, sta_pair::NT);
+      hipLaunchKernelGGL(pack_wq_kernel<_Float16>, g2, dim3(64), 0, st, (const _Float16*)wq, (_Float16*)pair, C, 2 * d, sta_p3::NT);
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_wq launch: %s", hipGetErrorString(e));
@@ -365,9 +359,8 @@ int sta_xattn_pack_wq(const void* wq, void* packed, int C, int heads, int dtype,
 
 size_t sta_xattn_packed_kv_proj_bytes(int n_ctx, int heads, int d) {
   if (n_ctx <= 0 || heads <= 0 || d <= 0 || d % 8 || d > STA_MAX_HEAD_DIM) return 0;
-  // + the compact per-(ctx, head) blocks of the head-pair kernel where it applies (d = 40, even head count)
-  return (size_t)n_ctx * heads * fwd_frags((d + 15) / 16) * FRAG +
-         ((d == sta_pair::D && heads % 2 == 0) ? sta_pair::kv_bytes(n_ctx, heads) + sta_p3::kv_bytes(n_ctx, heads) : 0);
+  // + the per-(ctx, head) blocks of the head-pair kernel where it applies (d = 40, even head count)
+  return (size_t)n_ctx * heads * fwd_frags((d + 15) / 16) * FRAG + ((d == sta_p3::D && heads % 2 == 0) ? sta_p3::kv_bytes(n_ctx, heads) : 0);
 }
 
 int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype,
@@ -388,11 +381,8 @@ int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx
   else
     hipLaunchKernelGGL(pack_kv_proj_kernel<_Float16>, grid, dim3(64), 0, st, (const _Float16*)k, (const _Float16*)v,
                        (_Float16*)packed, M, C, heads, d, ndt);
-  if (d == sta_pair::D && heads % 2 == 0 && M <= sta_pair::KROWS) {
-    char* pair = (char*)packed + (size_t)n_ctx * heads * fwd_frags(ndt) * FRAG;
-    if (int rc = sta_pair::pack_kv(k, v, pair, n_ctx, M, C, heads, dtype, st)) return rc;
-    if (M <= sta_p3::KR)
-      if (int rc = sta_p3::pack_kv(k, v, pair + sta_pair::kv_bytes(n_ctx, heads), n_ctx, M, C, heads, dtype, st)) return rc;
+  if (d == sta_p3::D && heads % 2 == 0 && M <= sta_p3::KR) {
+    if (int rc = sta_p3::pack_kv(k, v, (char*)packed + (size_t)n_ctx * heads * fwd_frags(ndt) * FRAG, n_ctx, M, C, heads, dtype, st)) return rc;
   }
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_kv_proj launch: %s", hipGetErrorString(e));
@@ -418,21 +408,15 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
   p.sl2e = scale * 1.4426950408889634f;
   const int lds = proj_lds_bytes(C, heads, K);
   hipStream_t st = (hipStream_t)stream;
-  // Head pairs share one read of y where both heads' operands fit a CU in compact form (d = 40, K <= 2) and the
-  // launch still fills the chip with one pair workgroup per CU (level 0, 16 / 8 / 4 / 2 images: 73 / 42 / 25 / 16 us
-  // against 92 / 51 / 29 / 17 us one head per workgroup; one image: 128 pair workgroups, 14.8 vs 12.1 us).
+  // Head pairs share one read of y where both heads' operands fit a CU (d = 40, C = 160 / 320, K <= 2: sta_xattn_proj3.hip)
+  // and the launch still fills the chip with one pair workgroup per CU (level 0 at 32 / 16 images: 147 / 72 us against
+  // 156 / 92 us one head per workgroup; a one-image launch has 128 pair workgroups and takes the one-head kernel).
   const long pair_wgs = (long)((N + 127) / 128) * (heads / 2) * n_img;
-  if (g_sta_opt[STA_OPT_PROJ_PAIR] == 3 && sta_p3::eligible(C, heads, M, K)) {
+  if (sta_p3::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2 && (pair_wgs >= 256 || g_sta_opt[STA_OPT_PROJ_PAIR] == 1)) {
     const int ndt = (p.d + 15) / 16;
     const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
-    const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG + sta_pair::kv_bytes(n_img * (K + 2), heads);
+    const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
     return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st);
-  }
-  if (sta_pair::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2 && (pair_wgs >= 256 || g_sta_opt[STA_OPT_PROJ_PAIR] == 1)) {
-    const int ndt = (p.d + 15) / 16;
-    const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
-    const char* kv_pair = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
-    return sta_pair::forward(y, wq_pair, kv_pair, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st);
   }
   return dtype == STA_BF16 ? dispatch_proj<__bf16>(p, n_img, lds, st) : dispatch_proj<_Float16>(p, n_img, lds, st);
 }

@@ -21,10 +21,11 @@ static_assert(KBYTES % 16 == 0 && BLK % 16 == 0, "16-byte LDS reads need aligned
 
 inline bool shape_ok(int C, int heads) { return heads > 0 && heads % 2 == 0 && C == heads * D && (C == 160 || C == 320); }
 __host__ __device__ constexpr int kv_region(int K) { return ((K + 2) * CTXB + 1023) / 1024 * 1024; }   // LDS bytes in front of the Wq fragments
-inline int lds_bytes(int C, int K) { return kv_region(K) + NT * (C / 32) * 1024; }
+inline int lds_bytes(int C, int K) { return kv_region(K) + NT * (C / 32) * 1024 + 16; }     // + the work-item counter
 inline bool eligible(int C, int heads, int M, int K) {
   return shape_ok(C, heads) && M > 64 && M <= KR && K >= 0 && lds_bytes(C, K) <= 160 * 1024;
 }
+inline size_t wq_bytes(int C, int heads) { return (size_t)(heads / 2) * NT * (C / 32) * 1024; }      // pair fragments of to_q.weight
 inline size_t kv_bytes(int n_ctx, int heads) { return (size_t)n_ctx * heads * BLK + 1024; }   // + slack: the last DMA piece is read whole
 
 int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype, hipStream_t st);

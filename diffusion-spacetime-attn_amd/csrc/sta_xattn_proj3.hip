@@ -31,11 +31,6 @@
 #include "sta_xattn_dev.h"
 #include "sta_xattn_proj3.h"
 
-// Ablation builds for tools/ (never in the product library; tools/lib_ab.py -DP3_ABL=n): 1 no output stores, 2 no y refills
-// (the ring is loaded once), 3 no attention (the projected q is stored instead), 4 no projection MFMAs, 5 no local contexts.
-#ifndef P3_ABL
-#define P3_ABL 0
-#endif
 
 namespace {
 
@@ -170,10 +165,12 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     st[t] = acc;
   }
   __builtin_amdgcn_sched_barrier(0);
-  load_k<T>(kf, knb, kns);                       // the next context's K operands: under this softmax and PV
   softmax_biased(st, sl2e, false);               // denominator: ones row of V^T
   const V8 p0 = cat8<T>(st[0], st[1]), p1 = cat8<T>(st[2], st[3]);
   const V4 p2 = cvt4<T>(st[4]);
+  __builtin_amdgcn_sched_barrier(0);
+  load_k<T>(kf, knb, kns);                       // the next context's K operands: requested once the scores are dead (register
+                                                 // budget), they land under the PV MFMAs and the blend
   f32x4 o[3];
 #pragma unroll
   for (int u = 0; u < 3; ++u) {
@@ -197,21 +194,13 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
 }
 
 // Workgroup = 8 waves x 16 pixels, one HEAD PAIR, one image; walks `iters` strided pixel tiles.
-//
-// y rows (B operands of the projection): a 16x16x32 B operand wants lane (g, c) to hold 16 bytes of pixel c — one load
-// instruction then touches 16 rows x 64 B, i.e. 16 half-used 128-byte lines, and the vector-memory path (L1 tag rate, ~4
-// cycles per line per CU whatever the hit rate: tools/ubench/l2_gather.hip) was what bound both generations of this kernel.
-// YFULL: a load instruction covers 8 rows x one FULL line instead — lane (g, c) fetches row (c & 7), 16-byte slot
-// g + 4 (c >> 3) of the line that holds k-steps 2m and 2m+1 — and one DPP row_ror:8 move per dword hands the halves to the
-// lanes that need them (lanes c < 8 got their own pixel's step-2m slots and pixel c's ... see unit_operands). Same bytes,
-// same instruction count, half the lines.
-template <typename T, int NKC, bool YFULL>
+template <typename T, int NKC>
 __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NWV = 8, TP = 16 * NWV;
-  constexpr int RING = YFULL ? NKC : 5;           // k-steps of y in flight per batch row (YFULL: the whole row of the next tile)
-  static_assert(NKC % RING == 0 && (!YFULL || NKC % 2 == 0), "k-steps per tile: a multiple of the ring depth; full-line loads pair them");
+  constexpr int RING = 5;                         // k-steps of y in flight per batch row
+  static_assert(NKC % RING == 0, "k-steps per tile: a multiple of the ring depth");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -251,33 +240,37 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     }
     stage_frags(p.wq + (size_t)pr * nwq * FRAG, lds_wq, nwq, wv, NWV, lane);
   }
+  // Work items = (pixel tile of the workgroup, 16-pixel sub-tile): a wave takes the next item from an LDS counter when it is one
+  // item ahead of its y ring, instead of owning sub-tile `wv` of every tile: the second-dispatched half of the workgroup loses
+  // the issue arbitration on every SIMD (its waves needed 25 % longer for the same 16 sub-tiles: profiles/r03_level0.md) and
+  // disc-crossing sub-tiles cost two more contexts — with the queue every wave ends within one item of the others.
   const int mine = (p.tiles - wt + W - 1) / W;
   const int iters = mine < p.iters ? mine : p.iters;
+  const int nitems = iters * NWV;
+  unsigned* qcount = (unsigned*)(lds_wq + (size_t)nwq * FRAG);     // behind the Wq fragments
+  if (threadIdx.x == 0) *qcount = 2u * NWV;                          // items 0 .. 2 NWV - 1 are handed out statically below
   const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
   const unsigned row1 = (unsigned)N * row_bytes;
-  auto tile_of = [&](int it) -> int { return wt + it * W; };
-  // per-lane byte offset of this lane's load(s) for tile `it`. Half-line shape: row c16, slot g. Full-line shape: two loads per
-  // line pair — `half` 0: rows 0..7 of the wave's 16 pixels, 1: rows 8..15 — lane (g, c) takes row (c & 7), slot g + 4 (c >> 3)
-  auto voff_of = [&](int it, int half = 0) -> unsigned {
-    const int px = tile_of(it) * TP + wv * 16 + (YFULL ? (c16 & 7) + 8 * half : c16);
-    const unsigned slot = YFULL ? (unsigned)(g + 4 * (c16 >> 3)) : (unsigned)g;
-    return (it < iters && px < N) ? (unsigned)px * row_bytes + slot * 16u : 0xfffffff0u;
+  auto px0_of = [&](int q) -> int { return (wt + (q >> 3) * W) * TP + (q & (NWV - 1)) * 16; };
+  // per-lane byte offset of this lane's y loads for item `q`: row c16, 16-byte slot g of a k-step (pixels >= N and items
+  // past the end are pushed out of the descriptor's range: they read as zeros)
+  auto voff_of = [&](int q) -> unsigned {
+    const int px = px0_of(q) + c16;
+    return (q < nitems && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
   };
-  auto mask_of = [&](int it) -> unsigned {
-    const int px = tile_of(it) * TP + wv * 16 + c16;
-    return mask[(it < iters && px < N) ? px : 0];
+  auto mask_of = [&](int q) -> unsigned {
+    const int px = px0_of(q) + c16;
+    return mask[(q < nitems && px < N) ? px : 0];
   };
-  // ring slot j: half-line shape = k-step j of both batch rows; full-line shape = (line pair j >> 1, rows-half j & 1)
+  int qcur = wv, qnext = NWV + wv;
+  // ring slot j = k-step j (mod RING) of both batch rows
   V8 yr0[RING], yr1[RING];
-  unsigned voff = voff_of(0), voffn = voff_of(1);
-  unsigned voffh = YFULL ? voff_of(0, 1) : 0u, voffhn = YFULL ? voff_of(1, 1) : 0u;
-  unsigned mb = mask_of(0);
+  unsigned voff = voff_of(qcur), voffn = voff_of(qnext);
+  unsigned mb = mask_of(qcur);
 #pragma unroll
   for (int j = 0; j < RING; ++j) {
-    const unsigned vo = (YFULL && (j & 1)) ? voffh : voff;
-    const unsigned so = YFULL ? 128u * (unsigned)(j >> 1) : 64u * (unsigned)j;
-    yr0[j] = srd_load16<V8>(y_srd, vo, so);
-    yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * (unsigned)j);
+    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * (unsigned)j);
   }
   const f32x4 kb4 = last_tile_bias(g, p.M);
   const float sl2e = p.sl2e;
@@ -291,7 +284,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   wait_dma_and_sync();
   STA_T(1);
 
-  for (int it = 0; it < iters; ++it) {
+  for (int it = 0; qcur < nitems; ++it) {
     if (it == 1) STA_T(2);
     // ---- projection: 5 column tiles x both batch rows; Wq fragments one k-step ahead -------------------------------
     f32x4 qa0[NT], qa1[NT];
@@ -310,49 +303,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         for (int u = 0; u < NT; ++u) a[(s + 1) & 1][u] = wf[((s + 1) * NT + u) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (YFULL) {
-        // slots s & ~1 (rows 0..7: lanes c < 8 hold their own pixel's step-2m slots, lanes c >= 8 pixel c-8's step-2m+1 slots)
-        // and s | 1 (rows 8..15: lanes c < 8 hold pixel c+8's step-2m slots, lanes c >= 8 their own step-2m+1 slots).
-        // even step: c < 8 keeps A, c >= 8 takes ror8(B);  odd step: c < 8 takes ror8(A), c >= 8 keeps B.
-        const int ja = s & ~1, jb = s | 1;
-        V8 b0, b1;
-        {
-          const u32x4 A0 = __builtin_bit_cast(u32x4, yr0[ja]), B0 = __builtin_bit_cast(u32x4, yr0[jb]);
-          const u32x4 A1 = __builtin_bit_cast(u32x4, yr1[ja]), B1 = __builtin_bit_cast(u32x4, yr1[jb]);
-          u32x4 r0, r1;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            if ((s & 1) == 0) {
-              r0[q] = (unsigned)__builtin_amdgcn_update_dpp((int)A0[q], (int)B0[q], 0x128, 0xF, 0xC, false);
-              r1[q] = (unsigned)__builtin_amdgcn_update_dpp((int)A1[q], (int)B1[q], 0x128, 0xF, 0xC, false);
-            } else {
-              r0[q] = (unsigned)__builtin_amdgcn_update_dpp((int)B0[q], (int)A0[q], 0x128, 0xF, 0x3, false);
-              r1[q] = (unsigned)__builtin_amdgcn_update_dpp((int)B1[q], (int)A1[q], 0x128, 0xF, 0x3, false);
-            }
-          }
-          b0 = __builtin_bit_cast(V8, r0);
-          b1 = __builtin_bit_cast(V8, r1);
-        }
-#if P3_ABL == 4
-#pragma unroll
-        for (int u = 0; u < NT; ++u) asm volatile("" :: "v"(a[s & 1][u]));
-        asm volatile("" :: "v"(b0), "v"(b1));
-        if (s == 0) { qa0[0] = __builtin_bit_cast(f32x4, b0); qa1[0] = __builtin_bit_cast(f32x4, b1); }
-#else
-#pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          qa0[u] = Tr<T>::mfma(a[s & 1][u], b0, qa0[u]);
-          qa1[u] = Tr<T>::mfma(a[s & 1][u], b1, qa1[u]);
-        }
-#endif
-        if ((s & 1) && P3_ABL != 2) {       // the line pair is consumed: request the same pair of the NEXT tile into both slots
-          const unsigned so = 128u * (unsigned)(s >> 1);
-          yr0[ja] = srd_load16<V8>(y_srd, voffn, so);
-          yr1[ja] = srd_load16<V8>(y_srd, voffn, row1 + so);
-          yr0[jb] = srd_load16<V8>(y_srd, voffhn, so);
-          yr1[jb] = srd_load16<V8>(y_srd, voffhn, row1 + so);
-        }
-      } else {
+      {
         const int j = s % RING;
 #pragma unroll
         for (int u = 0; u < NT; ++u) {
@@ -373,22 +324,16 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     // K operands of the first context (head A, ctx 0): requested here, they land under the accumulator conversions
     KFr<T> kf;
     load_k<T>(kf, lds_kv + koffb, lds_kv + koffs);
-    const int px_own = tile_of(it) * TP + wv * 16 + c16;
+    const int px_own = px0_of(qcur) + c16;
     const bool valid = px_own < N;
-    voff = voffn;
-    voffn = voff_of(it + 2);
-    if constexpr (YFULL) {
-      voffh = voffhn;
-      voffhn = voff_of(it + 2, 1);
-    }
-    const unsigned mbn = mask_of(it + 1);
+    // the item after next: one LDS atomic by lane 0, consumed at the end of this item (its latency sits under the attention)
+    unsigned qtake = 0;
+    if (lane == 0) qtake = atomicAdd(qcount, 1u);
+    const unsigned mbn = mask_of(qnext);
     const unsigned mbits = valid ? (mb & kmask) : 0u;
     // local contexts some pixel of this wave needs (wave-uniform bit set)
     unsigned wneed = 0;
     for (int i = 0; i < K; ++i) wneed |= __ballot((mbits >> i) & 1u) ? (1u << i) : 0u;
-#if P3_ABL == 5
-    wneed = 0;
-#endif
 
     // accumulators -> S^T B operands (rounded to T once). Head A: tiles 0 | 1 (+ tile 2 rows g < 2), head B: tiles 3 | 4
     // (+ tile 2 rows g >= 2); the small operand (tile 2) serves both heads, the K images carry the zeros.
@@ -420,41 +365,27 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const char* nx = next_of(i + 1);
         attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sl2e, w, au, ac);
       }
-#if P3_ABL == 1
-#pragma unroll
-      for (int u = 0; u < 3; ++u) asm volatile("" :: "v"(au[u]), "v"(ac[u]));
-#else
       if (valid) {
         T* obase = ob + (size_t)px_own * C + (2 * pr + HB) * D;
         store_row16<T, 3>(obase, au, g, D);
         store_row16<T, 3>(obase + (size_t)N * C, ac, g, D);
       }
-#endif
     };
-#if P3_ABL == 3
-    if (valid) {        // no attention: store the projected q (same store instructions and bytes)
-      const f32x4 a0[3] = {qa0[0], qa0[1], qa0[2]}, a1[3] = {qa1[0], qa1[1], qa1[2]};
-      const f32x4 b0[3] = {qa0[2], qa0[3], qa0[4]}, b1[3] = {qa1[2], qa1[3], qa1[4]};
-      T* obase = ob + (size_t)px_own * C + (2 * pr) * D;
-      store_row16<T, 3>(obase, a0, g, D);
-      store_row16<T, 3>(obase + (size_t)N * C, a1, g, D);
-      store_row16<T, 3>(obase + D, b0, g, D);
-      store_row16<T, 3>(obase + D + (size_t)N * C, b1, g, D);
-    }
-    asm volatile("" :: "v"(kf.big[0]), "v"(qA0), "v"(qB1), "v"(qs0), "v"(qs1), "v"(qA1), "v"(qB0));
-#else
     head(std::integral_constant<int, 0>{}, qA0, qA1);
     if (it == 1) STA_T(4);
     head(std::integral_constant<int, 1>{}, qB0, qB1);
     if (it == 1) STA_T(5);
-#endif
     mb = mbn;
+    qcur = qnext;
+    qnext = (int)__builtin_amdgcn_readfirstlane(qtake);
+    voff = voffn;
+    voffn = voff_of(qnext);
   }
   STA_T(8);
   STA_T_END();
 }
 
-template <typename T, int NKC, bool YFULL>
+template <typename T, int NKC>
 int launch_p3(P3 p, int n_img, hipStream_t st) {
   constexpr int TP = 128;
   const int pairs = p.H / 2;
@@ -467,9 +398,9 @@ int launch_p3(P3 p, int n_img, hipStream_t st) {
   p.W = (p.tiles + p.iters - 1) / p.iters;
   const int lds = lds_bytes(p.C, p.K);
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YFULL>, 160 * 1024))
+  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj p3) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YFULL>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj p3 launch: %s", hipGetErrorString(e));
 }
@@ -499,12 +430,8 @@ int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* m
   P3 p{};
   p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv; p.mask = mask; p.coef = coef; p.out = out;
   p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.sl2e = sl2e;
-  const bool half_lines = g_sta_opt[STA_OPT_PROJ_RING] == 5;       // A/B: the 16-rows-x-64-bytes load shape of the first generation
-  if (C == 320) {
-    if (dtype == STA_BF16) return half_lines ? launch_p3<__bf16, 10, false>(p, n_img, st) : launch_p3<__bf16, 10, true>(p, n_img, st);
-    return half_lines ? launch_p3<_Float16, 10, false>(p, n_img, st) : launch_p3<_Float16, 10, true>(p, n_img, st);
-  }
-  return dtype == STA_BF16 ? launch_p3<__bf16, 5, false>(p, n_img, st) : launch_p3<_Float16, 5, false>(p, n_img, st);
+  if (dtype == STA_BF16) return C == 320 ? launch_p3<__bf16, 10>(p, n_img, st) : launch_p3<__bf16, 5>(p, n_img, st);
+  return C == 320 ? launch_p3<_Float16, 10>(p, n_img, st) : launch_p3<_Float16, 5>(p, n_img, st);
 }
 
 }  // namespace sta_p3

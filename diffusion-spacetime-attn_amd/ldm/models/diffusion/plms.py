@@ -96,6 +96,35 @@ def object_crop_box(centre, height, width, half=0.2):
     return int(height * y1), int(height * y2), int(width * x1), int(width * x2)
 
 
+class _CallRecompute(torch.autograd.Function):
+    """Activation recomputation at UNet-CALL granularity (second half): the forward of a tracked epoch
+    runs the whole CFG UNet call WITHOUT autograd — through the inference kernels and the captured hipGraph, exactly like a
+    fixed-weight trajectory — and keeps only the call's inputs (the 16 KB latent per image and the weights column). Backward
+    re-runs that one call eagerly with autograd and differentiates it w.r.t. (x, coef). The reference checkpoints every block
+    instead (util.py:105-145) because 51 calls of saved activations do not fit its GPU; here one call's activations
+    (~1.6 GiB per prompt at 512^2) exist only while that call is differentiated, so 32 prompts per step fit in 288 GB and the
+    launch-bound eager autograd is amortised over all of them. The gradient is the recomputed call's (16-bit roundings of the
+    two forward chains differ in the last bit; tests/test_modules_gpu.py holds dW to the float64 chain)."""
+
+    @staticmethod
+    def forward(ctx, fast_fn, slow_fn, t, x, coef):
+        ctx.slow_fn, ctx.t = slow_fn, t
+        ctx.save_for_backward(x, coef)
+        with torch.no_grad():
+            return fast_fn(x, t, coef).clone()          # the graph's output buffer is reused by the next replay
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, coef = ctx.saved_tensors
+        x_ = x.detach().requires_grad_(True)
+        c_ = coef.detach().requires_grad_(True)
+        with torch.enable_grad():
+            out = ctx.slow_fn(x_, ctx.t, c_)
+            gx, gc = torch.autograd.grad(out, (x_, c_), grad_out.to(out.dtype), allow_unused=True)
+        ctx.slow_fn = None
+        return None, None, None, gx, gc
+
+
 class PLMSSampler(object):
     def __init__(self, model, schedule="linear", loss_model=None, opt_epochs=3, lr=0.005, weight_init=5.0,
                  local_loss_weight=5.0, use_graph=True, save_images=True, outdir="result_outputs/", loss_scale=None, **kwargs):
@@ -228,9 +257,12 @@ class PLMSSampler(object):
                 torch.cuda.tunable.enable(False)
             try:
                 with torch.set_grad_enabled(track):
+                    # tracked epochs: eager autograd through the 51 calls, or (sta.pipeline.set_recompute mode "call") the
+                    # fixed-weight forward per call + one re-run of the call under autograd in backward
+                    by_call = track and getattr(self.model, "sta_call_recompute", False)
                     img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
                                            time_range, W if batched else W[0], block_boxes, text_index,
-                                           graph=self.use_graph and not track)
+                                           graph=self.use_graph and (not track or by_call), call_recompute=by_call)
                     x_img = None
                     if self.model.first_stage_model is not None:
                         x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
@@ -279,10 +311,10 @@ class PLMSSampler(object):
         Image.fromarray(arr).save(os.path.join(self.outdir, "final%d_s%d_index_%d.png" % (epoch, seed, prompt_idx)))
 
     # --------------------------------------------------------------------------------------------------
-    def _trajectory(self, img, cond, uncond, scale, time_range, W, bboxs_curr, text_index, graph=False):
+    def _trajectory(self, img, cond, uncond, scale, time_range, W, bboxs_curr, text_index, graph=False, call_recompute=False):
         """W: [K, S] for one image or [I, K, S] for a batch; column i of every image is used at step i."""
         S, b, device = len(time_range), img.shape[0], img.device
-        eps_fn = self._make_eps_fn(cond, uncond, scale, bboxs_curr, text_index, graph, img)
+        eps_fn = self._make_eps_fn(cond, uncond, scale, bboxs_curr, text_index, graph, img, call_recompute)
         old_eps = []
         for i, step in enumerate(time_range):
             index = S - i - 1
@@ -294,7 +326,7 @@ class PLMSSampler(object):
                 old_eps.pop(0)
         return img
 
-    def _make_eps_fn(self, cond, uncond, scale, bboxs_curr, text_index, graph, img):
+    def _make_eps_fn(self, cond, uncond, scale, bboxs_curr, text_index, graph, img, call_recompute=False):
         """eps(x, t, coef) with classifier-free guidance. The UNet batch is [uncond_0, cond_0, uncond_1, cond_1, ...]:
         for one image this is the reference's `cat([uc, c])` (:304-308); for a batch the pairs stay adjacent,
         which is the layout the fused kernel indexes (image-major, row 0 = uncond, row 1 = cond)."""
@@ -312,8 +344,15 @@ class PLMSSampler(object):
                 self._graphs = GraphedEps(self.model)
             apply_fn = self._graphs.bind(c_in, bboxs_curr, text_index)
 
+        def unet(fn, x, t, coef):
+            return fn(pair(x, x), text_index, pair(t, t), c_in, coef=coef, bboxs_curr=bboxs_curr)
+
         def eps(x, t, coef):
-            out = apply_fn(pair(x, x), text_index, pair(t, t), c_in, coef=coef, bboxs_curr=bboxs_curr)
+            if call_recompute and torch.is_grad_enabled():
+                out = _CallRecompute.apply(lambda x_, t_, c_: unet(apply_fn, x_, t_, c_),
+                                           lambda x_, t_, c_: unet(self.model.apply_model_extra, x_, t_, c_), t, x, coef)
+            else:
+                out = unet(apply_fn, x, t, coef)
             out = out.reshape(b, 2, *out.shape[1:])
             e_u, e_c = out[:, 0], out[:, 1]
             return e_u + scale * (e_c - e_u)

@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj2.hip", "sta_xattn_proj3.hip", "sta_selfattn.hip", "sta_selfattn_bwd.hip", "sta_unet.hip", "sta_fp8.hip")]
+SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj3.hip", "sta_selfattn.hip", "sta_selfattn_bwd.hip", "sta_unet.hip", "sta_fp8.hip")]
 
 # Self-attention keeps its MFMA accumulators in VGPRs: hipcc otherwise parks them in AGPRs and brackets the
 # online-softmax rescale with v_accvgpr_read/write pairs (120 extra VALU instructions per key block in a kernel
@@ -28,7 +28,7 @@ SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip"
 PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
                     "sta_selfattn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
                     "sta_xattn.hip": ["-ffinite-math-only"], "sta_xattn_proj.hip": ["-ffinite-math-only"],
-                    "sta_xattn_proj2.hip": ["-ffinite-math-only"], "sta_xattn_proj3.hip": ["-ffinite-math-only"]}
+                    "sta_xattn_proj3.hip": ["-ffinite-math-only"]}
 
 STA_BF16, STA_F16 = 0, 1
 OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_PROJ_RING, OPT_PROJ_PAIR = range(8)
@@ -74,7 +74,7 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h"), os.path.join(CSRC, "sta_xattn_proj2.h"), os.path.join(CSRC, "sta_xattn_proj3.h"), os.path.join(CSRC, "sta_selfattn_dev.h")]
+    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h"), os.path.join(CSRC, "sta_xattn_proj3.h"), os.path.join(CSRC, "sta_selfattn_dev.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 

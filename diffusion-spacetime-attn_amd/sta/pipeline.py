@@ -149,10 +149,14 @@ def set_recompute(model, mode="auto", prompts_per_step=1):
     recomputation and an MI355X has 288 GB, so the policy is sized to HBM instead:
       none — keep everything (<= 2 prompts per step: 156 GiB; +22 % images/s over `all`)
       res  — ResBlocks recompute, transformer blocks keep their activations (<= 4 prompts: 240 GiB; +8 %)
-      all  — the reference's policy (more prompts per step)
-    Returns the mode applied."""
+      all  — the reference's policy
+      call — recompute at UNet-CALL granularity (ldm.models.diffusion.plms._CallRecompute): the forward of a tracked epoch
+             is the fixed-weight path (inference kernels, hipGraph) and keeps 16 KB per call and image; backward re-runs one
+             call under autograd at a time (1.6 GiB per prompt) — what lets 16-32 prompts share a step
+    auto = none for <= 2 prompts per step, call above. Returns the mode applied."""
     if mode == "auto":
-        mode = "none" if prompts_per_step <= 2 else ("res" if prompts_per_step <= 4 else "all")
+        mode = "none" if prompts_per_step <= 2 else "call"
+    model.sta_call_recompute = mode == "call"
     unet = model.model.diffusion_model
     from ldm.modules.diffusionmodules.openaimodel import ResBlock
     for m in unet.modules():

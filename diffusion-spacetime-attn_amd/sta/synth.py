@@ -63,6 +63,21 @@ def device_fill_(module, seed=0):
             t.copy_(n.to(t.dtype))
 
 
+def calibrate_decoder_(model, latent, target_std=0.25):
+    """Synthetic VAE weights decode a sampled latent to values far outside [-1, 1]: the image clamp of plms.py:249-250 then
+    saturates everywhere and the fidelity loss has an exactly-zero gradient. Rescale the decoder's last convolution so that
+    the decoded `latent` (one already-sampled x0) has mean 0 and the given std — (img + 1) / 2 stays inside (0, 1) almost
+    everywhere, as it does with real weights. Benchmarks / timing runs with synthetic weights only. Returns (mean, std) before."""
+    conv = model.first_stage_model.decoder.conv_out
+    with torch.no_grad():
+        img = model.decode_first_stage(latent.to(conv.weight.dtype)).float()
+        mean, std = float(img.mean()), float(img.std())
+        s = target_std / max(std, 1e-12)
+        conv.weight.mul_(s)
+        conv.bias.sub_(mean).mul_(s)       # decode is affine in (weight, bias) of its last layer: out -> (out - mean) * s
+    return mean, std
+
+
 class SyntheticCLIP(torch.nn.Module):
     """Stand-in for the third-party CLIP ViT-B/32 the reference's fidelity loss calls (plms.py:21-45):
     same interface (`encode_image([1,3,224,224])`, `encode_text(str)`, 512-d features), tiny frozen

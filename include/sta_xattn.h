@@ -62,11 +62,11 @@ enum {
   STA_OPT_FWD_KERNEL = 0,   /* 1: LDS-resident ("staged") kernel, 2: wave-per-context ("split") kernel; the backward reads it
                                the same way: 1 = LDS-resident multi-tile backward where it fits, 2 = one context at a time */
   STA_OPT_STAGED_TILES = 1, /* pixel tiles a staged workgroup walks (1..12) */
-  STA_OPT_STAGED_WAVES = 2, /* waves per staged workgroup: 4, 8 or 12 */
+  STA_OPT_STAGED_WAVES = 2, /* waves per staged workgroup: 4, 8 or 12 (sta_xattn_fwd_proj, one head per workgroup: 4 or 8) */
   STA_OPT_STAGED_QT = 3,    /* 2: two 16-pixel sub-tiles per wave */
   STA_OPT_HEAD_MAJOR = 4,   /* 1: block b -> head b % heads; 2: XCD-contiguous tile ranges */
   STA_OPT_SPLIT_QT = 5,     /* sub-tiles per wave of the split kernel: 1, 2, 4 */
-  STA_OPT_PROJ_RING = 6,    /* sta_xattn_fwd_proj: k-steps of y in flight per row, 5 or 10; 2 = software-pipelined head-pair build */
+  STA_OPT_PROJ_RING = 6,    /* reserved (round-2 experiment variants, removed); ignored */
   STA_OPT_PROJ_PAIR = 7,    /* sta_xattn_fwd_proj: 1 = head-pair kernel whenever the shape allows, 2 = one head per workgroup */
   STA_OPT_COUNT = 8
 };

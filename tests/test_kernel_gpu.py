@@ -540,7 +540,7 @@ def test_error_convention():
 # ---------------------------------------------------------------------------------------------------
 PROJ_SHAPES = [
     # N, C, heads, K, images, forced tiles per workgroup (None = heuristic), waves per workgroup (0 = default),
-    # pair (True: d = 40 and K <= 2 take the head-PAIR kernel, sta_xattn_proj2.hip; False: one head per workgroup forced)
+    # pair (True: d = 40, C = 160 / 320 and K <= 2 take the head-PAIR kernel, sta_xattn_proj3.hip; False: one head per workgroup forced)
     (256, 320, 8, 2, 1, None, 0, True),      # level-0 head dim, two 128-pixel tiles
     (256, 320, 8, 2, 1, None, 0, False),
     (4096, 320, 8, 2, 4, None, 0, True),     # BASELINE level 0, 4 prompts
@@ -550,7 +550,7 @@ PROJ_SHAPES = [
     (4096, 320, 8, 1, 3, None, 4, True),     # one object, 4-wave workgroups
     (4096, 320, 8, 0, 2, None, 0, True),     # no objects
     (1000, 160, 4, 2, 2, 3, 4, True),        # ragged N, 2 head pairs, forced tile count
-    (4096, 320, 8, 4, 2, None, 12, True),    # 4 objects do not fit as pairs -> per-head kernel (6 contexts + Wq = 144 KiB), 12 waves
+    (4096, 320, 8, 4, 2, None, 0, True),     # 4 objects do not fit as pairs -> per-head kernel (6 contexts + Wq = 144 KiB)
     (1000, 160, 4, 3, 2, 3, 4, True),        # K = 3: per-head kernel, ragged N, forced tile count, 4-wave workgroups
     (1024, 320, 4, 1, 2, None, 0, True),     # d = 80: 50 KiB of Wq + 3 contexts (per head)
     (576, 480, 10, 0, 1, None, 0, True),     # d = 48 with 10 heads (15 k-steps), no objects (per head)
@@ -590,8 +590,10 @@ def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, pair, dtype):
     unfused, _ = ops.xattn_forward(q_gemm, ops.pack_kv(k, v, heads, n_img=I), mb, coef, scale)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     a, b = out.float(), unfused.float()
-    # same arithmetic up to the summation order of the projection (a q element may round the other way: 1 ulp of q)
-    assert ((a - b).abs() <= 4 * eps * (1.0 + b.abs())).all(), (a - b).abs().max().item()
+    # two 16-bit evaluations of the same formula in different summation orders (a q element may round the other way; the
+    # head-pair kernel splits the S^T and PV sums 32 + 8 dims / 64 + 16 keys): each side is held to 4 eps against the oracle
+    # below, against each other to the sum of the two bounds
+    assert ((a - b).abs() <= 8 * eps * (1.0 + b.abs())).all(), (a - b).abs().max().item()
     for i in sorted({0, I - 1}):
         yi, ki, vi, mi, ci = cases[i]
         q16 = (yi.double() @ wq.double().t()).to(dtype)
@@ -600,7 +602,7 @@ def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, pair, dtype):
         assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
 
 
-P3_SHAPES = [
+PAIR_SHAPES = [
     # N, C, heads, K, images, forced tiles per workgroup, keys
     (256, 320, 8, 2, 1, None, 77),        # two 128-pixel tiles, one per workgroup
     (4096, 320, 8, 2, 4, None, 77),
@@ -613,11 +615,11 @@ P3_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("N,C,heads,K,I,tiles,M", P3_SHAPES)
+@pytest.mark.parametrize("N,C,heads,K,I,tiles,M", PAIR_SHAPES)
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fwd_proj_p3_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
-    """Second-generation head-pair kernel (csrc/sta_xattn_proj3.hip: single-read operand images, 16x16x32 + 16x16x16 MFMAs,
-    software-pipelined LDS reads) vs the oracle fed with q = round16(y Wq^T), image 0 and the last image, and vs the
+def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
+    """Head-pair kernel (csrc/sta_xattn_proj3.hip: single-read operand images, 16x16x32 + 16x16x16 MFMAs, software-pipelined
+    LDS reads, work items handed out through an LDS counter) vs the oracle fed with q = round16(y Wq^T), image 0 and the last image, and vs the
     unfused GPU path on every image."""
     from sta import lib, ops
     dev = "cuda"
@@ -632,7 +634,7 @@ def test_fwd_proj_p3_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
     scale = (C // heads) ** -0.5
     if tiles is not None:
         lib.set_option(lib.OPT_STAGED_TILES, tiles)
-    lib.set_option(lib.OPT_PROJ_PAIR, 3)
+    lib.set_option(lib.OPT_PROJ_PAIR, 1)
     out = ops.xattn_forward_proj(y, ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I), mb, coef, scale)
     torch.cuda.synchronize()
     lib.set_option(lib.OPT_STAGED_TILES, 0)
@@ -642,39 +644,16 @@ def test_fwd_proj_p3_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     a, b = out.float(), unfused.float()
     assert torch.isfinite(a).all()
-    assert ((a - b).abs() <= 4 * eps * (1.0 + b.abs())).all(), (a - b).abs().max().item()
+    # two 16-bit evaluations of the same formula in different summation orders (a q element may round the other way, the
+    # S^T and PV sums are split 32 + 8 dims / 64 + 16 keys here): each is held to 4 eps against the oracle below, against
+    # each other to the sum of the two bounds
+    assert ((a - b).abs() <= 8 * eps * (1.0 + b.abs())).all(), (a - b).abs().max().item()
     for i in sorted({0, I - 1}):
         yi, ki, vi, mi, ci = cases[i]
         q16 = (yi.double() @ wq.double().t()).to(dtype)
         ref = orc.fused_xattn(q16.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
         err = (a[2 * i:2 * i + 2].cpu().double() - ref).abs()
-        assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
-
-
-@pytest.mark.parametrize("N,C,heads,K,I", [(4096, 320, 8, 2, 16), (4096, 320, 8, 2, 3), (1000, 160, 4, 2, 2), (9216, 320, 8, 1, 2)])
-def test_fwd_proj_pair_software_pipelined(N, C, heads, K, I):
-    """The software-pipelined head-pair kernel (projection of tile t+1 issued inside the attention of tile t) computes
-    every accumulator in the same order as the plain pair kernel: outputs must be IDENTICAL, tile order, ragged tails
-    and the discarded projection past the last tile included."""
-    from sta import lib, ops
-    dtype, dev = torch.float16, "cuda"
-    g = torch.Generator().manual_seed(N + I)
-    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype).to(dev)
-    cases = [_case(N, C, heads, K, dtype, seed=90 + i) for i in range(I)]
-    y = torch.cat([c[0] for c in cases]).to(dev)
-    k = torch.cat([c[1] for c in cases]).to(dev)
-    v = torch.cat([c[2] for c in cases]).to(dev)
-    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
-    coef = torch.stack([c[4] for c in cases]).to(dev)
-    scale = (C // heads) ** -0.5
-    wqf, kvp = ops.pack_wq(wq, heads), ops.pack_kv_proj(k, v, heads, n_img=I)
-    lib.set_option(lib.OPT_PROJ_PAIR, 1)
-    plain = ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale)
-    lib.set_option(lib.OPT_PROJ_RING, 2)
-    piped = ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale)
-    torch.cuda.synchronize()
-    assert torch.equal(plain, piped)
-    assert piped.float().abs().max() > 0
+        assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item(), (err / (1.0 + ref.abs())).max().item() / eps)
 
 
 def test_fwd_proj_rejects_what_it_cannot_hold():

@@ -326,13 +326,14 @@ def test_unet_backward_vs_fp64_oracle(recompute):
     assert e_c < 0.03 and e_x < 0.03 and m_x < 0.01, (e_c, e_x, m_x)
 
 
-@pytest.mark.parametrize("recompute", ["all", "res", "none"])
+@pytest.mark.parametrize("recompute", ["all", "res", "none", "call"])
 def test_weight_optimisation_on_gpu(recompute):
     """BASELINE configs[2] in miniature: 2 epochs x 6 PLMS steps through the HIP forward AND backward
     kernels, block recomputation, the VAE decoder and the CLIP-loss front end (CLIP itself is a stand-in).
     The first Adam step moves every weight by exactly lr = 5e-3 (its sign is the sign of the gradient).
     Runs under each recomputation policy of sta.pipeline.set_recompute (the reference's per-block checkpointing,
-    ResBlocks only, none): the loss of the first epoch must agree across them."""
+    ResBlocks only, none, and recomputation per UNet CALL behind the fixed-weight forward + hipGraph): the loss of the
+    first epoch must agree across them."""
     from ldm.models.autoencoder import AutoencoderKL
     from ldm.models.diffusion.ddpm import LatentDiffusion
     from ldm.models.diffusion.plms import DCLIPLoss, PLMSSampler
@@ -362,7 +363,7 @@ def test_weight_optimisation_on_gpu(recompute):
     assert (step > 0).all() and (step <= 0.005 + 1e-5).all(), step
     assert (step > 0.0049).float().mean() >= 0.8, step
     _LOSSES[recompute] = r["losses"][0]
-    if len(_LOSSES) == 3:      # same forward maths whichever activations are kept (fused vs eager trunk: 16-bit noise)
+    if len(_LOSSES) == 4:      # same forward maths whichever activations are kept (fused vs eager trunk: 16-bit noise)
         vals = list(_LOSSES.values())
         assert max(vals) - min(vals) <= 0.02 * abs(vals[0]) + 1e-3, _LOSSES
     # not only consistent but RIGHT: the same epoch in fp32 on the host with the oracle's fused op (the combination the

@@ -36,8 +36,7 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--dtype", default="fp16")
-    ap.add_argument("--waves", type=int, nargs="*", default=[8, 12])
-    ap.add_argument("--rings", type=int, nargs="*", default=[5])
+    ap.add_argument("--waves", type=int, nargs="*", default=[8])      # accepted for old command lines, unused
     ap.add_argument("--only", default=None, help="run only this arm (for rocprofv3): proj | gemm | attn")
     a = ap.parse_args()
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
@@ -55,37 +54,20 @@ def main():
     arms = {"gemm": lambda: torch.nn.functional.linear(y, wq),
             "attn": lambda: ops.xattn_forward(q, packed, mask, coef, scale),
             "gemm+attn": lambda: ops.xattn_forward(torch.nn.functional.linear(y, wq), packed, mask, coef, scale)}
-    for w in a.waves:
-        for ring in (a.rings if w != 12 else [5]):
-            def proj(w=w, ring=ring):
-                lib.set_option(lib.OPT_PROJ_PAIR, 2)
-                lib.set_option(lib.OPT_STAGED_WAVES, w)
-                lib.set_option(lib.OPT_PROJ_RING, ring)
-                r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
-                lib.set_option(lib.OPT_STAGED_WAVES, 0)
-                lib.set_option(lib.OPT_PROJ_RING, 0)
-                lib.set_option(lib.OPT_PROJ_PAIR, 0)
-                return r
-            arms["proj_w%d_r%d" % (w, ring)] = proj
-    for w, ring in ((8, 5), (8, 2)):      # ring 2 = software-pipelined build
-        def pair(w=w, ring=ring):
-            lib.set_option(lib.OPT_STAGED_WAVES, w)
-            lib.set_option(lib.OPT_PROJ_PAIR, 1)
-            lib.set_option(lib.OPT_PROJ_RING, ring)
-            r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
-            lib.set_option(lib.OPT_STAGED_WAVES, 0)
-            lib.set_option(lib.OPT_PROJ_PAIR, 0)
-            lib.set_option(lib.OPT_PROJ_RING, 0)
-            return r
-        arms["pair_w%d_r%d" % (w, ring)] = pair
-    def p3():
-        lib.set_option(lib.OPT_PROJ_PAIR, 3)
+    def proj():
+        lib.set_option(lib.OPT_PROJ_PAIR, 2)
         r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
         lib.set_option(lib.OPT_PROJ_PAIR, 0)
         return r
-    arms["p3"] = p3
+    arms["proj"] = proj                     # one head per workgroup (sta_xattn_proj.hip)
+    def pair():
+        lib.set_option(lib.OPT_PROJ_PAIR, 1)
+        r = ops.xattn_forward_proj(y, wqf, packed_p, mask, coef, scale)
+        lib.set_option(lib.OPT_PROJ_PAIR, 0)
+        return r
+    arms["pair"] = pair                     # a head pair per workgroup (sta_xattn_proj3.hip)
     if a.only:
-        arms = {k_: f for k_, f in arms.items() if any(k_.startswith(o) for o in a.only.split(",")) or (a.only == "proj" and k_.startswith("pair"))}
+        arms = {k_: f for k_, f in arms.items() if any(k_.startswith(o) for o in a.only.split(","))}
     res = {n: [] for n in arms}
     for _ in range(a.rounds):
         for n, f in arms.items():
@@ -95,7 +77,7 @@ def main():
     byts = I * (8.0 * N * C + 4.0 * (K + 2) * M * C + K * N) + 2.0 * C * C
     out = {"N": N, "C": C, "K": K, "imgs": I, "dtype": a.dtype, "us": res, "attn_gflop": f_attn / 1e9, "proj_gflop": f_proj / 1e9, "mbytes": byts / 1e6}
     for n, v_ in res.items():
-        if n.startswith("proj") or n.startswith("pair") or n.startswith("p3"):
+        if n.startswith("proj") or n.startswith("pair"):
             us = min(v_)
             out[n + "_tflops"] = round((f_attn + f_proj) / us / 1e6, 1)
             out[n + "_gbps"] = round(byts / us / 1e3, 1)

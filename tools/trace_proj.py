@@ -21,9 +21,9 @@ subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-
                        "-I", lib.INCLUDE, "-I", lib.CSRC, *lib.SOURCES, "-o", out])
 lib.LIB_PATH = out
 L = lib.load()
-PAIR = len(sys.argv) > 4 and sys.argv[4] == "pair"
-P3 = len(sys.argv) > 4 and sys.argv[4] == "p3"      # 1 image landed | 2 tile 1 begins | 3 projection issued | 4 head A | 5 head B | 8 end | 9-12 after k-steps 1,3,5,7 of tile 1
-set_trace = L.sta_debug_set_trace_p3 if P3 else (L.sta_debug_set_trace_pair if PAIR else L.sta_debug_set_trace_proj)
+P3 = len(sys.argv) > 4 and sys.argv[4] == "pair"    # 1 image landed | 2 item 1 begins | 3 projection issued | 4 head A | 5 head B | 8 end | 9-12 after k-steps 1,3,5,7 of item 1
+PAIR = False
+set_trace = L.sta_debug_set_trace_p3 if P3 else L.sta_debug_set_trace_proj
 set_trace.restype, set_trace.argtypes = ctypes.c_int, [ctypes.c_void_p]
 
 dev = "cuda"
@@ -40,7 +40,7 @@ mask = ops.disc_mask_bits([(0.3, 0.4), (0.7, 0.6)], 64).to(dev).repeat(I, 1)
 coef = torch.full((I, K), 2.5, device=dev)
 packed, wqf = ops.pack_kv_proj(k, v, H, n_img=I), ops.pack_wq(wq, H)
 lib.set_option(lib.OPT_STAGED_WAVES, NW)
-lib.set_option(lib.OPT_PROJ_PAIR, 3 if P3 else (1 if PAIR else 2))
+lib.set_option(lib.OPT_PROJ_PAIR, 1 if P3 else 2)
 for wg in WGS:
     tr = torch.zeros(8 + 16 * 16, dtype=torch.int64, device=dev)
     tr[0] = wg
@@ -51,7 +51,7 @@ for wg in WGS:
     full = tr[8:].cpu().view(16, 16)[:NW]
     wall = (full[:, 14] - full[:, 15]).tolist()
     t = full[:, :14]
-    print("%s N=%d C=%d I=%d waves=%d wg=%d" % ("p3" if P3 else ("pair" if PAIR else "proj"), N, C, I, NW, wg))
+    print("%s N=%d C=%d I=%d waves=%d wg=%d" % ("pair" if P3 else "proj", N, C, I, NW, wg))
     base = min(t[w, 0].item() for w in range(NW))
     for w in range(NW):
         row = t[w].tolist()
