@@ -32,9 +32,16 @@
 #include "sta_xattn_proj3.h"
 
 
+// Ablation builds for tools/lib_ab.py (-DSTA_P3_ABLATE=bits; 0 in the product library): 1 no projection MFMAs, 2 no attention,
+// 4 no output stores, 8 no y refills (the ring is loaded once per wave), 16 no Wq fragment reads. 19 = the load + store skeleton.
+#ifndef STA_P3_ABLATE
+#define STA_P3_ABLATE 0
+#endif
+
 namespace {
 
 using namespace sta_p3;
+constexpr int ABL = STA_P3_ABLATE;
 
 template <typename T> struct M16;           // the k = 16 MFMA of the same type family
 template <> struct M16<_Float16> {
@@ -46,6 +53,15 @@ template <> struct M16<__bf16> {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
   }
 };
+
+// Head dim held by row r of a V^T image (row 40: the ones row, -1). O^T = V^T P^T leaves the MFMAs as lane (g, c) <- rows
+// 16u + 4g + {0..3}: the permutation makes a lane's tile-0 and tile-1 registers 8 CONSECUTIVE dims, i.e. one 16-byte piece of
+// the output row with no cross-lane exchange; head B (hp = 1) is rotated by one lane row so that the pair's 160-byte segment
+// of an output row goes out as three stores: bytes 0..63 = A dims 0..31 (lane rows 0..3), bytes 64..127 = [A dims 32..39 | B
+// dims 0..23] (lane row 0 | 1..3), bytes 128..159 = [B dims 24..31 | B dims 32..39] (lane rows 0 | 1) — see store_pair_rows.
+__host__ __device__ constexpr int vrow_dim(int r, int hp) {
+  return r == D ? -1 : (r >= 32 ? r : 8 * ((((r & 15) >> 2) + 3 * hp) & 3) + 4 * (r >> 4) + (r & 3));
+}
 
 // K, V [n_ctx][M][C] -> [ctx][head][K rows | V^T rows], BLK bytes each (layout: file header, tools/emu_pair3.py)
 template <typename T>
@@ -72,6 +88,7 @@ __global__ __launch_bounds__(256) void pack_kv_p3_kernel(const T* __restrict__ k
     } else {
       const int i2 = i - KBYTES / 2;
       const int r = i2 / (VROW / 2), pos = i2 % (VROW / 2);
+      const int dim = vrow_dim(r, hp);
       int key;
       if (pos < 64) {
         const int s = pos >> 5, g = (pos >> 3) & 3, j = pos & 7;
@@ -80,7 +97,7 @@ __global__ __launch_bounds__(256) void pack_kv_p3_kernel(const T* __restrict__ k
         const int g = (pos - 64) >> 2, j = (pos - 64) & 3;
         key = 64 + 4 * g + j;
       }
-      if (key < M) x = r < D ? vh[(size_t)key * C + r] : (T)1.0f;
+      if (key < M) x = dim >= 0 ? vh[(size_t)key * C + dim] : (T)1.0f;
     }
     blk[i] = x;
   }
@@ -121,6 +138,39 @@ __device__ __forceinline__ float bcast_row2(float x) {
                "v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %1, %0\n\ts_nop 1"
                : "=&v"(t0), "=&v"(t1) : "v"(x));
   return __uint_as_float(t1);
+}
+
+// What a head leaves for the stores of one batch row: `main` = the lane's tile-0 | tile-1 outputs (8 consecutive dims, 16 bytes),
+// `tail` = its tile-2 outputs (dims 32 + 4g .. +3 in lane rows 0 and 1; rows 2, 3 hold the ones row and padding)
+struct OutRow {
+  u32x4 main;
+  unsigned tail[2];
+};
+template <typename T>
+__device__ __forceinline__ OutRow pack_out(const f32x4 (&a)[3]) {
+  typedef __attribute__((ext_vector_type(2))) T T2;
+  OutRow r;
+  r.main = u32x4{__builtin_bit_cast(unsigned, T2{(T)a[0][0], (T)a[0][1]}), __builtin_bit_cast(unsigned, T2{(T)a[0][2], (T)a[0][3]}),
+                 __builtin_bit_cast(unsigned, T2{(T)a[1][0], (T)a[1][1]}), __builtin_bit_cast(unsigned, T2{(T)a[1][2], (T)a[1][3]})};
+  r.tail[0] = __builtin_bit_cast(unsigned, T2{(T)a[2][0], (T)a[2][1]});
+  r.tail[1] = __builtin_bit_cast(unsigned, T2{(T)a[2][2], (T)a[2][3]});
+  return r;
+}
+// Bytes 64..159 of the pair segment of one output row (bytes 0..63 = head A's `main`, stored when head A is done): one
+// v_permlane16_swap per tail dword hands lane row 0 the A tail [own | row 1's] and lane row 1 the B tail; then
+//   bytes  64..127: lane row 0 = A tail, rows 1..3 = B main (B dims 0..23)      address = seg + 64 + 16 g
+//   bytes 128..159: lane row 0 = B main (B dims 24..31), row 1 = B tail          address = seg + 128 + 16 g, rows 2, 3 off
+// `seg` = byte offset of the pair segment of this lane's pixel row in the output buffer; lanes that must not store (pixel
+// >= N: `valid` false; lane rows 2, 3 of the last store) get the offset 0xfffffff0, which the descriptor's bounds check drops.
+__device__ __forceinline__ void store_pair_rest(__amdgpu_buffer_rsrc_t srd, unsigned seg, bool valid, int g, const unsigned (&tailA)[2], const OutRow& b) {
+  auto s0 = __builtin_amdgcn_permlane16_swap(tailA[0], b.tail[0], false, false);
+  auto s1 = __builtin_amdgcn_permlane16_swap(tailA[1], b.tail[1], false, false);
+  const u32x4 tail = {s0[0], s1[0], s0[1], s1[1]};
+  const bool row0 = g == 0;
+  const u32x4 v2 = {row0 ? tail[0] : b.main[0], row0 ? tail[1] : b.main[1], row0 ? tail[2] : b.main[2], row0 ? tail[3] : b.main[3]};
+  const u32x4 v3 = {row0 ? b.main[0] : tail[0], row0 ? b.main[1] : tail[1], row0 ? b.main[2] : tail[2], row0 ? b.main[3] : tail[3]};
+  __builtin_amdgcn_raw_buffer_store_b128(v2, srd, valid ? seg + 64u + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(v3, srd, (valid && g < 2) ? seg + 128u + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
 }
 
 template <typename T>
@@ -194,13 +244,21 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
 }
 
 // Workgroup = 8 waves x 16 pixels, one HEAD PAIR, one image; walks `iters` strided pixel tiles.
-template <typename T, int NKC>
+//
+// y rows (B operands of the projection). The launch is bound by the CU's vector-memory path, which retires about one
+// 128-byte line per 3.8 cycles whatever the hit rate, loads and stores alike (profiles/r03_level0.md: the load + store skeleton
+// of this kernel alone takes 141 of its 155 us). A 16x16x32 B operand wants lane (g, c) to hold 16 bytes of pixel c, so the
+// natural load touches 16 rows x 64 B = 16 half-used lines per instruction. YFULL: an instruction covers 8 rows x one FULL
+// line instead — lane (g, c) fetches row (c & 7), 16-byte slot g + 4 (c >> 3) of the line that holds k-steps 2m and 2m+1; two
+// such loads (rows 0..7, rows 8..15) and one DPP row_ror:8 move per dword hand every lane its own pixel's slots of both
+// k-steps. Same bytes and instruction count, half the lines. The ring then holds the whole row of the NEXT item.
+template <typename T, int NKC, bool YFULL>
 __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NWV = 8, TP = 16 * NWV;
-  constexpr int RING = 5;                         // k-steps of y in flight per batch row
-  static_assert(NKC % RING == 0, "k-steps per tile: a multiple of the ring depth");
+  constexpr int RING = YFULL ? NKC : 5;           // k-steps of y in flight per batch row
+  static_assert(NKC % RING == 0 && (!YFULL || NKC % 2 == 0), "k-steps per tile: a multiple of the ring depth; full-line loads pair them");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -250,27 +308,33 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   unsigned* qcount = (unsigned*)(lds_wq + (size_t)nwq * FRAG);     // behind the Wq fragments
   if (threadIdx.x == 0) *qcount = 2u * NWV;                          // items 0 .. 2 NWV - 1 are handed out statically below
   const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
+  const __amdgpu_buffer_rsrc_t o_srd = make_srd(ob, (unsigned)act);
   const unsigned row1 = (unsigned)N * row_bytes;
   auto px0_of = [&](int q) -> int { return (wt + (q >> 3) * W) * TP + (q & (NWV - 1)) * 16; };
-  // per-lane byte offset of this lane's y loads for item `q`: row c16, 16-byte slot g of a k-step (pixels >= N and items
-  // past the end are pushed out of the descriptor's range: they read as zeros)
-  auto voff_of = [&](int q) -> unsigned {
-    const int px = px0_of(q) + c16;
-    return (q < nitems && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
+  // per-lane byte offset of this lane's y load(s) for item `q` (pixels >= N and items past the end are pushed out of the
+  // descriptor's range: they read as zeros). Half-line shape: row c16, 16-byte slot g of a k-step. Full-line shape: two loads
+  // per line pair — `half` 0: rows 0..7 of the item's 16 pixels, 1: rows 8..15 — lane (g, c) takes row (c & 7), slot g + 4 (c >> 3)
+  auto voff_of = [&](int q, int half = 0) -> unsigned {
+    const int px = px0_of(q) + (YFULL ? (c16 & 7) + 8 * half : c16);
+    const unsigned slot = YFULL ? (unsigned)(g + 4 * (c16 >> 3)) : (unsigned)g;
+    return (q < nitems && px < N) ? (unsigned)px * row_bytes + slot * 16u : 0xfffffff0u;
   };
   auto mask_of = [&](int q) -> unsigned {
     const int px = px0_of(q) + c16;
     return mask[(q < nitems && px < N) ? px : 0];
   };
   int qcur = wv, qnext = NWV + wv;
-  // ring slot j = k-step j (mod RING) of both batch rows
+  // ring slot j: half-line shape = k-step j (mod RING) of both batch rows; full-line shape = (line pair j >> 1, rows-half j & 1)
   V8 yr0[RING], yr1[RING];
   unsigned voff = voff_of(qcur), voffn = voff_of(qnext);
+  unsigned voffh = YFULL ? voff_of(qcur, 1) : 0u, voffhn = YFULL ? voff_of(qnext, 1) : 0u;
   unsigned mb = mask_of(qcur);
 #pragma unroll
   for (int j = 0; j < RING; ++j) {
-    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * (unsigned)j);
-    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * (unsigned)j);
+    const unsigned vo = (YFULL && (j & 1)) ? voffh : voff;
+    const unsigned so = YFULL ? 128u * (unsigned)(j >> 1) : 64u * (unsigned)j;
+    yr0[j] = srd_load16<V8>(y_srd, vo, so);
+    yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
   }
   const f32x4 kb4 = last_tile_bias(g, p.M);
   const float sl2e = p.sl2e;
@@ -300,22 +364,69 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     for (int s = 0; s < NKC; ++s) {
       if (s + 1 < NKC) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) a[(s + 1) & 1][u] = wf[((s + 1) * NT + u) * 64];
+        for (int u = 0; u < NT; ++u) a[(s + 1) & 1][u] = (ABL & 16) ? a[s & 1][u] : wf[((s + 1) * NT + u) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
-      {
-        const int j = s % RING;
+      if constexpr (YFULL) {
+        // slot s & ~1 (rows 0..7): lanes c < 8 hold their own pixel's step-2m slots, lanes c >= 8 pixel c-8's step-2m+1 slots;
+        // slot s | 1 (rows 8..15): lanes c < 8 hold pixel c+8's step-2m slots, lanes c >= 8 their own step-2m+1 slots.
+        // even step: c < 8 keeps A, c >= 8 takes ror8(B);  odd step: c < 8 takes ror8(A), c >= 8 keeps B.
+        const int ja = s & ~1, jb = s | 1;
+        const u32x4 A0 = __builtin_bit_cast(u32x4, yr0[ja]), B0 = __builtin_bit_cast(u32x4, yr0[jb]);
+        const u32x4 A1 = __builtin_bit_cast(u32x4, yr1[ja]), B1 = __builtin_bit_cast(u32x4, yr1[jb]);
+        u32x4 r0, r1;
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          qa0[u] = Tr<T>::mfma(a[s & 1][u], yr0[j], qa0[u]);
-          qa1[u] = Tr<T>::mfma(a[s & 1][u], yr1[j], qa1[u]);
+        for (int q = 0; q < 4; ++q) {
+          if ((s & 1) == 0) {
+            r0[q] = (unsigned)__builtin_amdgcn_update_dpp((int)A0[q], (int)B0[q], 0x128, 0xF, 0xC, false);
+            r1[q] = (unsigned)__builtin_amdgcn_update_dpp((int)A1[q], (int)B1[q], 0x128, 0xF, 0xC, false);
+          } else {
+            r0[q] = (unsigned)__builtin_amdgcn_update_dpp((int)B0[q], (int)A0[q], 0x128, 0xF, 0x3, false);
+            r1[q] = (unsigned)__builtin_amdgcn_update_dpp((int)B1[q], (int)A1[q], 0x128, 0xF, 0x3, false);
+          }
         }
-        // refill this ring slot with k-step s + RING: of this tile, or of the next one (zeros past the last tile)
-        const bool wrap = s + RING >= NKC;              // compile time after unrolling
-        const unsigned vo = wrap ? voffn : voff;
-        const unsigned so = 64u * (unsigned)(wrap ? s + RING - NKC : s + RING);
-        yr0[j] = srd_load16<V8>(y_srd, vo, so);
-        yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+        const V8 b0 = __builtin_bit_cast(V8, r0), b1 = __builtin_bit_cast(V8, r1);
+        if constexpr (ABL & 1) {
+#pragma unroll
+          for (int u = 0; u < NT; ++u) asm volatile("" :: "v"(a[s & 1][u]));
+          asm volatile("" :: "v"(b0), "v"(b1));
+          if (s < NT) { qa0[s] = __builtin_bit_cast(f32x4, b0); qa1[s] = __builtin_bit_cast(f32x4, b1); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            qa0[u] = Tr<T>::mfma(a[s & 1][u], b0, qa0[u]);
+            qa1[u] = Tr<T>::mfma(a[s & 1][u], b1, qa1[u]);
+          }
+        }
+        if ((s & 1) && !(ABL & 8)) {       // the line pair is consumed: request the same pair of the NEXT item into both slots
+          const unsigned so = 128u * (unsigned)(s >> 1);
+          yr0[ja] = srd_load16<V8>(y_srd, voffn, so);
+          yr1[ja] = srd_load16<V8>(y_srd, voffn, row1 + so);
+          yr0[jb] = srd_load16<V8>(y_srd, voffhn, so);
+          yr1[jb] = srd_load16<V8>(y_srd, voffhn, row1 + so);
+        }
+      } else {
+        const int j = s % RING;
+        if constexpr (ABL & 1) {
+#pragma unroll
+          for (int u = 0; u < NT; ++u) asm volatile("" :: "v"(a[s & 1][u]));
+          asm volatile("" :: "v"(yr0[j]), "v"(yr1[j]));
+          if (s < NT) { qa0[s] = __builtin_bit_cast(f32x4, yr0[j]); qa1[s] = __builtin_bit_cast(f32x4, yr1[j]); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            qa0[u] = Tr<T>::mfma(a[s & 1][u], yr0[j], qa0[u]);
+            qa1[u] = Tr<T>::mfma(a[s & 1][u], yr1[j], qa1[u]);
+          }
+        }
+        if constexpr (!(ABL & 8)) {
+          // refill this ring slot with k-step s + RING: of this item, or of the next one (zeros past the last item)
+          const bool wrap = s + RING >= NKC;              // compile time after unrolling
+          const unsigned vo = wrap ? voffn : voff;
+          const unsigned so = 64u * (unsigned)(wrap ? s + RING - NKC : s + RING);
+          yr0[j] = srd_load16<V8>(y_srd, vo, so);
+          yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if ((s & 1) && s < 9) if (it == 1) STA_T(9 + (s >> 1));
@@ -342,11 +453,14 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     const V4 qs0 = cvt4<T>(qa0[2]), qs1 = cvt4<T>(qa1[2]);
 
     // ---- attention + blend, head A then head B ------------------------------------------------------------------
-    auto head = [&](auto hb_tag, const V8& q0, const V8& q1) {
+    // `seg`: byte offset of this lane's pixel row, pair segment (160 bytes at 160 pr), uncond row; + row1 = cond row
+    const unsigned seg = (unsigned)px_own * row_bytes + (unsigned)(2 * pr * D) * (unsigned)sizeof(T);
+    const unsigned seg1 = seg + row1;
+    auto head = [&](auto hb_tag, const V8& q0, const V8& q1, OutRow& ou, OutRow& oc) {
       constexpr int HB = decltype(hb_tag)::value;
       f32x4 au[3], ac[3];
       const char* blk = lds_kv + HB * BLK;                       // (ctx 0, this head); contexts are CTXB apart
-      const char* other = lds_kv + (HB ^ 1) * BLK;               // what follows this head: head B's ctx 0, or head A's of the next tile
+      const char* other = lds_kv + (HB ^ 1) * BLK;               // what follows this head: head B's ctx 0, or head A's of the next item
       // block whose K operands to request during context `cur` (0, 1, or 2 + i): the next needed local context, else `other`
       auto next_of = [&](int first_local) -> const char* {
         const unsigned rest = wneed >> first_local;
@@ -365,27 +479,49 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const char* nx = next_of(i + 1);
         attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sl2e, w, au, ac);
       }
-      if (valid) {
-        T* obase = ob + (size_t)px_own * C + (2 * pr + HB) * D;
-        store_row16<T, 3>(obase, au, g, D);
-        store_row16<T, 3>(obase + (size_t)N * C, ac, g, D);
-      }
+      ou = pack_out<T>(au);
+      oc = pack_out<T>(ac);
     };
-    head(std::integral_constant<int, 0>{}, qA0, qA1);
+    OutRow au_A, ac_A, au_B, ac_B;
+    if constexpr (ABL & 2) {          // no attention: the projected q goes out through the same stores
+      const f32x4 a0[3] = {qa0[0], qa0[1], qa0[2]}, a1[3] = {qa1[0], qa1[1], qa1[2]};
+      const f32x4 b0[3] = {qa0[2], qa0[3], qa0[4]}, b1[3] = {qa1[2], qa1[3], qa1[4]};
+      asm volatile("" :: "v"(kf.big[0]), "v"(kf.sm[4]), "v"(qA0), "v"(qB1), "v"(qs0), "v"(qs1), "v"(qA1), "v"(qB0));
+      au_A = pack_out<T>(a0); ac_A = pack_out<T>(a1); au_B = pack_out<T>(b0); ac_B = pack_out<T>(b1);
+    } else
+    head(std::integral_constant<int, 0>{}, qA0, qA1, au_A, ac_A);
+    // head A's dims 0..31 of both batch rows: bytes 0..63 of the pair segment, 16 bytes per lane, no cross-lane exchange
+    if constexpr (ABL & 4) {
+      asm volatile("" :: "v"(au_A.main), "v"(ac_A.main));
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, valid ? seg + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, valid ? seg1 + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
+    }
     if (it == 1) STA_T(4);
-    head(std::integral_constant<int, 1>{}, qB0, qB1);
+    if constexpr (!(ABL & 2)) head(std::integral_constant<int, 1>{}, qB0, qB1, au_B, ac_B);
+    if constexpr (ABL & 4) {
+      asm volatile("" :: "v"(au_A.tail[0]), "v"(au_A.tail[1]), "v"(ac_A.tail[0]), "v"(ac_A.tail[1]), "v"(au_B.main), "v"(ac_B.main),
+                   "v"(au_B.tail[0]), "v"(au_B.tail[1]), "v"(ac_B.tail[0]), "v"(ac_B.tail[1]));
+    } else {
+      store_pair_rest(o_srd, seg, valid, g, au_A.tail, au_B);
+      store_pair_rest(o_srd, seg1, valid, g, ac_A.tail, ac_B);
+    }
     if (it == 1) STA_T(5);
     mb = mbn;
     qcur = qnext;
     qnext = (int)__builtin_amdgcn_readfirstlane(qtake);
     voff = voffn;
     voffn = voff_of(qnext);
+    if constexpr (YFULL) {
+      voffh = voffhn;
+      voffhn = voff_of(qnext, 1);
+    }
   }
   STA_T(8);
   STA_T_END();
 }
 
-template <typename T, int NKC>
+template <typename T, int NKC, bool YFULL>
 int launch_p3(P3 p, int n_img, hipStream_t st) {
   constexpr int TP = 128;
   const int pairs = p.H / 2;
@@ -398,9 +534,9 @@ int launch_p3(P3 p, int n_img, hipStream_t st) {
   p.W = (p.tiles + p.iters - 1) / p.iters;
   const int lds = lds_bytes(p.C, p.K);
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC>, 160 * 1024))
+  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YFULL>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj p3) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YFULL>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj p3 launch: %s", hipGetErrorString(e));
 }
@@ -430,8 +566,9 @@ int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* m
   P3 p{};
   p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv; p.mask = mask; p.coef = coef; p.out = out;
   p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.sl2e = sl2e;
-  if (dtype == STA_BF16) return C == 320 ? launch_p3<__bf16, 10>(p, n_img, st) : launch_p3<__bf16, 5>(p, n_img, st);
-  return C == 320 ? launch_p3<_Float16, 10>(p, n_img, st) : launch_p3<_Float16, 5>(p, n_img, st);
+  // full-line y loads pair the k-steps: C = 320 (10 steps) takes them, C = 160 (5 steps) keeps the half-line shape
+  if (C == 320) return dtype == STA_BF16 ? launch_p3<__bf16, 10, true>(p, n_img, st) : launch_p3<_Float16, 10, true>(p, n_img, st);
+  return dtype == STA_BF16 ? launch_p3<__bf16, 5, false>(p, n_img, st) : launch_p3<_Float16, 5, false>(p, n_img, st);
 }
 
 }  // namespace sta_p3

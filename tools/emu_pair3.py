@@ -21,6 +21,20 @@ VBYTES = VR * VROW   # 6560
 BLK = KBYTES + VBYTES
 
 
+def vrow_dim(r, hp):
+    """Head dim held by row r of the V^T image (row 40: the ones row, -1). The rows of O^T = V^T P^T come out of the MFMAs
+    as lane (g, c) <- rows 16u + 4g + {0..3}: the permutation makes a lane's tile-0 and tile-1 registers 8 CONSECUTIVE dims
+    (one 16-byte store without a cross-lane exchange); head B is rotated by one lane row so that the pair's second 64-byte
+    store instruction covers bytes 64..127 of the pair segment with [A tail | B dims 0..23] in lane rows 0 | 1, 2, 3."""
+    if r == 40:
+        return -1
+    u, c = r // 16, r % 16
+    g, q = c >> 2, c & 3
+    if u == 2:
+        return 32 + c                       # rows 32..39 (lane rows 0, 1)
+    return 8 * ((g + 3 * hp) & 3) + 4 * u + q
+
+
 def pack_block(k, v, hp, M):
     """k, v: [M, 40] float16 of ONE head; hp = head parity inside its pair. Returns BLK bytes (as uint16 halves)."""
     blk = np.zeros(BLK // 2, dtype=np.float16)
@@ -42,18 +56,55 @@ def pack_block(k, v, hp, M):
     vb = KBYTES // 2
     for r in range(VR):
         row = vb + r * (VROW // 2)
+        dim = vrow_dim(r, hp)
         for s in range(2):
             for g in range(4):
                 for j in range(8):
                     key = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3)
                     if key < M:
-                        blk[row + 32 * s + 8 * g + j] = v[key, r] if r < D else 1.0
+                        blk[row + 32 * s + 8 * g + j] = v[key, dim] if dim >= 0 else 1.0
         for g in range(4):
             for j in range(4):
                 key = 64 + 4 * g + j
                 if key < M:
-                    blk[row + 64 + 4 * g + j] = v[key, r] if r < D else 1.0
+                    blk[row + 64 + 4 * g + j] = v[key, dim] if dim >= 0 else 1.0
     return blk
+
+
+def permlane16_swap(x, y):
+    """v_permlane16_swap vdst=x, src=y on [64 lanes] arrays: odd rows of x <-> even rows of y. Returns (x', y')."""
+    x2, y2 = x.copy(), y.copy()
+    for row in (1, 3):
+        x2[16 * row:16 * row + 16] = y[16 * (row - 1):16 * (row - 1) + 16]
+        y2[16 * (row - 1):16 * (row - 1) + 16] = x[16 * row:16 * row + 16]
+    return x2, y2
+
+
+def store_pair(oA, oB):
+    """oA, oB: per head [3 tiles][64 lanes][4] normalised O^T accumulators of ONE batch row. Returns the pair segment
+    [16 px][80 dims] as the three store instructions of the kernel write it (16-byte pieces = 8 dims per lane)."""
+    seg = np.full((16, 80), np.nan)
+    def put(lane_vals, byte_off_of_lane, active):
+        for lane in range(64):
+            if active(lane):
+                c = lane & 15
+                b = byte_off_of_lane(lane)
+                seg[c, b // 2:b // 2 + 8] = lane_vals[lane]
+    mainA = np.concatenate([oA[0], oA[1]], axis=1)        # [64][8]: lane's tile-0 | tile-1 registers
+    mainB = np.concatenate([oB[0], oB[1]], axis=1)
+    # tails: lane rows 0, 1 hold dims 32..35 / 36..39 of their head in tile 2; one swap per dword pair hands lane row 0 the A
+    # tail (own | row 1's) and lane row 1 the B tail
+    tail = np.zeros((64, 8))
+    for d in range(4):
+        x, y = permlane16_swap(oA[2][:, d], oB[2][:, d])
+        tail[:, d], tail[:, 4 + d] = x, y
+    g_of = lambda lane: lane >> 4
+    put(mainA, lambda l: 16 * g_of(l), lambda l: True)                                    # I1: bytes 0..63
+    v2 = np.where((np.arange(64) >> 4 == 0)[:, None], tail, mainB)
+    put(v2, lambda l: 64 + 16 * g_of(l), lambda l: True)                                  # I2: bytes 64..127
+    v3 = np.where((np.arange(64) >> 4 == 0)[:, None], mainB, tail)
+    put(v3, lambda l: 128 + 16 * g_of(l), lambda l: g_of(l) < 2)                          # I3: bytes 128..159
+    return seg
 
 
 def mfma32(A, B, Cacc):
@@ -118,6 +169,7 @@ def emulate(seed=0, M=77, C=320):
     qsm = q16[2]
     qref = (y.astype(np.float64) @ wq.astype(np.float64).T).astype(np.float16).astype(np.float64)
     worst = 0.0
+    o_norm, refs = [], []
     for hp in range(2):
         h = 2 * pr + hp
         lds = pack_block(k[:, h * D:(h + 1) * D], v[:, h * D:(h + 1) * D], hp, M)
@@ -174,24 +226,22 @@ def emulate(seed=0, M=77, C=320):
                 A[lane] = lds_read(lds, KBYTES + (16 * u + c) * VROW + 128 + 8 * g, 8)
             a = mfma16(A, psm, a)
             o.append(a)
-        OT = np.zeros((48, 16))
-        for u in range(3):
-            for lane in range(64):
-                g, c = lane >> 4, lane & 15
-                OT[16 * u + 4 * g:16 * u + 4 * g + 4, c] = o[u][lane]
-        den = OT[40]                                   # ones row: tile 2, lane row g = 2, register 0
-        assert np.allclose(den, o[2][32:48, 0])
-        out = (OT[:40] / den).T                        # [16 px][40]
+        den = o[2][32:48, 0]                           # ones row 40 = tile 2, row 8: lane row g = 2, register 0
+        inv = np.zeros(64)
+        for lane in range(64):
+            inv[lane] = 1.0 / den[lane & 15]           # broadcast of lane row 2 to all lane rows
+        o_norm.append([o[u] * inv[:, None] for u in range(3)])
         # ---- reference ---------------------------------------------------------------------------------------------
         qh = qref[:, h * D:(h + 1) * D]
         kh = k[:, h * D:(h + 1) * D].astype(np.float64)
         vh = v[:, h * D:(h + 1) * D].astype(np.float64)
         sim = qh @ kh.T * scale
         pr_ = np.exp(sim - sim.max(axis=1, keepdims=True))
-        ref = (pr_ / pr_.sum(axis=1, keepdims=True)) @ vh
-        err = np.abs(out - ref).max()
-        worst = max(worst, err)
-    return worst
+        refs.append((pr_ / pr_.sum(axis=1, keepdims=True)) @ vh)
+    seg = store_pair(o_norm[0], o_norm[1])
+    assert not np.isnan(seg).any(), "a byte of the pair segment was not written"
+    ref = np.concatenate(refs, axis=1)                 # [16 px][80 dims]: head A | head B
+    return np.abs(seg - ref).max()
 
 
 if __name__ == "__main__":
