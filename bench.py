@@ -66,8 +66,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the bounded side measurement after the headline run "
                                                                  "(3-epoch weight optimisation = BASELINE configs[2])")
-    ap.add_argument("--other-dtype", action="store_true", help="also time one step in the other 16-bit type (adds ~2 min of MIOpen "
-                                                                "solver search for its convolutions)")
+    ap.add_argument("--no-other-dtype", action="store_true", help="skip the side leg that times one step in the other 16-bit type "
+                                                                   "(bf16 when the headline runs fp16; its convolution solvers are in the shipped MIOpen find-db)")
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16",
                     help="16-bit type of weights and activations. fp16 is the reference's own compute type (CUDA autocast) and the "
                          "one that meets north_star's 1e-3 attention-map tolerance; bf16 runs at the same MFMA rate but rounding "
@@ -385,7 +385,7 @@ def main():
         # which projection-fused kernel the library dispatches (csrc/sta_xattn_proj.hip): a head pair per workgroup when two
         # heads' compact operand images fit one CU's LDS (d = 40, K <= 2) and the launch has >= 256 pair workgroups
         pair = dom[2] == 320 and K <= 2 and (dom[1] // 128) * 4 * I >= 256
-        kname = {"proj": ("xattn_fwd_proj_pair_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, a head pair per workgroup)" if pair else
+        kname = {"proj": ("xattn_fwd_proj_p3_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, a head pair per workgroup)" if pair else
                           "xattn_fwd_proj_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, one head per workgroup)"),
                  "attn": "xattn_fwd{,_staged}_kernel (QK^T + softmax + disc mask + blend + PV)"}[dom[0]]
         bound = "hbm" if t_hbm >= t_mfma else "mfma"
@@ -407,10 +407,10 @@ def main():
                              "mfma_tflops": all_flops / all_us / 1e6, "mfma_frac": all_flops / all_us / 1e6 / MFMA_PEAK_TFLOPS},
             "per_shape_us": {"%s_N%d_C%d" % k_: round(sum(r["us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])},
             "per_shape_warm_us": {"%s_N%d_C%d" % k_: round(sum(r["warm_us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])}}
-        prof = os.path.join(REPO, "profiles", "r02_bench_kernel_stats.csv")
+        prof = os.path.join(REPO, "profiles", "r03_bench_kernel_stats.csv")
         if os.path.exists(prof):      # rocprofv3 --kernel-trace summary of this command, committed: the cross-check
             import csv
-            want = "xattn_fwd_proj" if dom[0] == "proj" else "xattn_fwd_staged"
+            want = "xattn_fwd_proj" if dom[0] == "proj" else "xattn_fwd_staged"      # xattn_fwd_proj_p3_kernel / xattn_fwd_proj_kernel
             hit = [r for r in csv.DictReader(open(prof)) if want in r["kernel"]]
             if hit:
                 best = max(hit, key=lambda r: float(r["total_ns"]))
@@ -418,7 +418,7 @@ def main():
     _phase("roofline leg done")
     if world == 1 and not a.no_side_runs and a.opt_epochs == 0:
         # reported beside the headline, never part of `value`: the other 16-bit type, and BASELINE configs[2]
-        if a.other_dtype:
+        if not a.no_other_dtype:
             out["other_dtype"] = side_run(dev, "bf16" if a.dtype == "fp16" else "fp16", 0, I, 1, 1, a.res, a.ddim_steps, K)
         # MIOpen's per-shape solver search for the backward convolutions of the UNet and the VAE decoder costs ~10 min on a
         # fresh box; the shipped user find-db (sta/data/miopen_userdb) holds them for fp16 at 512^2, other cases run in
