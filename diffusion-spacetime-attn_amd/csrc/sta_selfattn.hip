@@ -56,6 +56,8 @@ __device__ __forceinline__ float bfly_sum(float x) {
 // PRE (q arrives pre-multiplied by scale*log2(e), p.sl2e == 1 — the host folds the factor into W_q): the running maximum
 // is the INITIAL VALUE of the S^T accumulators, so the MFMAs deliver s - m and the exponent needs no multiply-subtract:
 // 2.5 instead of 3.5 vector instructions per score in a loop whose time is the vector pipe's.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }   // one v_max3_f32
+
 template <typename T, int NKS, int NDT, int QT, bool SUMROW, bool PRE>
 __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
@@ -115,13 +117,34 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       step[i] = __builtin_amdgcn_readfirstlane(KB * (int)sizeof(T));
     }
   }
+  // SUMROW: the lanes that feed row d of the last head-dim tile (the ones row whose PV product is the softmax denominator)
+  // are switched off in the DMA of their V^T fragments; their 16 bytes of every ring slot are written with ones ONCE here.
+  // (Selecting the ones in registers cost 8 v_cndmask per block: 2018-2022 vs 2025-2039 us, B = 64, N = 4096, d = 40.)
+  unsigned keep = ~0u;                     // bit i: this lane takes part in the wave's i-th DMA
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if constexpr (SUMROW) {
+      const int f = wv + 4 * i, f2 = f - NKF;
+      const bool ones_frag = f < NFR && f2 >= 0 && f2 % NDT == NDT - 1;
+      if (ones_frag && 16 * (NDT - 1) + c16 == d) {
+        keep &= ~(1u << i);
+        V8 ones;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+#pragma unroll
+        for (int sl = 0; sl < DEPTH; ++sl) *(V8*)(smem_sa + sl * BB + f * FRAG + lane * 16) = ones;
+      }
+    }
+  }
   const int nfull = N / KB;                // blocks whose 64 keys all exist (the incremental pointers are exact)
-  auto stage = [&](int blk, char* dst) {
+  const int dm8 = d - 8, nm8 = N - 8;
+  auto stage = [&, N, d, dm8, nm8](int blk, char* dst) __attribute__((always_inline)) {   // N, d by value: a by-reference capture ended up in scratch
     if (blk < nfull) {
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                         (__attribute__((address_space(3))) void*)(dst + (wv + 4 * i) * FRAG), 16, 0, 0);
+        if (keep >> i & 1)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                           (__attribute__((address_space(3))) void*)(dst + (wv + 4 * i) * FRAG), 16, 0, 0);
         src[i] += step[i];
       }
       return;
@@ -134,14 +157,15 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       const T* sp;
       if (fs < NKF) {
         const int Tt = fs / NKS, s = fs - Tt * NKS;
-        sp = kb + (size_t)min(k0 + tile_key(Tt, c16), N - 1) * p.ldk + min(32 * s + 8 * g, d - 8);
+        sp = kb + (size_t)min(k0 + tile_key(Tt, c16), N - 1) * p.ldk + min(32 * s + 8 * g, dm8);
       } else {
         const int f2 = fs - NKF;
         const int s2 = f2 / NDT, u = f2 - s2 * NDT;
-        sp = vb + (size_t)min(16 * u + c16, d - 1) * p.vt_rs + min(k0 + 32 * s2 + 8 * g, N - 8);
+        sp = vb + (size_t)min(16 * u + c16, d - 1) * p.vt_rs + min(k0 + 32 * s2 + 8 * g, nm8);
       }
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
-                                       (__attribute__((address_space(3))) void*)(dst + f * FRAG), 16, 0, 0);
+      if (keep >> i & 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sp,
+                                         (__attribute__((address_space(3))) void*)(dst + f * FRAG), 16, 0, 0);
     }
   };
 
@@ -161,15 +185,20 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   const int nblk = (N + KB - 1) / KB;
   stage(0, smem_sa);
   if (nblk > 1) stage(1, smem_sa + BB);
-  for (int blk = 0; blk < nblk; ++blk) {
-    char* cur = smem_sa + (blk % DEPTH) * BB;
+  // The ring slot of a block is a COMPILE-TIME constant: the loop body is instantiated once per slot and the loop walks three
+  // blocks per trip. Every fragment read is then `ds_read_b128 v, lane16 offset:SLOT * BB + f * 1024` — with a run-time slot hipcc
+  // spent two vector adds per fragment read on the address (30 of the ~130 vector instructions of a block in a loop that is
+  // vector-issue bound: profiles/r02_pmc_selfattn.md). Same box, B = 64, N = 4096, d = 40: 2114-2124 -> 2059-2064 us.
+  const char* lane_base = smem_sa + lane * 16;
+  auto body = [&](auto slot_tag, const int blk) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
     if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                      // block `blk` landed for every wave; everyone left block blk-1
-    if (blk + 2 < nblk) stage(blk + 2, smem_sa + ((blk + 2) % DEPTH) * BB);
+    if (blk + 2 < nblk) stage(blk + 2, smem_sa + ((SLOT + 2) % DEPTH) * BB);
     const bool tail = (blk + 1) * KB > N;              // partial last block: mask the missing keys
-    const V8* fr = (const V8*)cur + lane;
+    const V8* fr = (const V8*)(lane_base + SLOT * BB);
     V8 ka[NKF];
 #pragma unroll
     for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
@@ -188,15 +217,6 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
     V8 va[NVF];
 #pragma unroll
     for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
-    if constexpr (SUMROW) {                 // A-operand row of this lane in the last head-dim tile: 16*(NDT-1) + c16
-      V8 ones;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-        if (16 * (NDT - 1) + c16 == d) va[s2 * NDT + NDT - 1] = ones;
-    }
-
     V8 pb[QT][2];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -213,11 +233,15 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
           for (int r = 0; r < 4; ++r)
             if (blk * KB + tile_key(t, 4 * g + r) >= N) st[qt][t][r] = -3.0e38f;
       }
-      float bm = fmaxf(fmaxf(fmaxf(st[qt][0][0], st[qt][0][1]), fmaxf(st[qt][0][2], st[qt][0][3])),
-                       fmaxf(fmaxf(st[qt][1][0], st[qt][1][1]), fmaxf(st[qt][1][2], st[qt][1][3])));
-      bm = fmaxf(bm, fmaxf(fmaxf(fmaxf(st[qt][2][0], st[qt][2][1]), fmaxf(st[qt][2][2], st[qt][2][3])),
-                           fmaxf(fmaxf(st[qt][3][0], st[qt][3][1]), fmaxf(st[qt][3][2], st[qt][3][3]))));
-      bm = bfly_max(bm);
+      // this LANE's maximum over its 16 scores: eight v_max3 / v_max. The reduction over the four lane rows that share a
+      // pixel only runs when a rescale is due: "some lane saw more than the threshold" is the same wave-wide condition as
+      // "some pixel's maximum did" and needs no cross-lane step (2 x (mov, permlane swap, max) per q tile and block):
+      // 2036-2049 -> 2018-2022 us.
+      float bm = fmaxf(max3f(max3f(st[qt][0][0], st[qt][0][1], st[qt][0][2]), max3f(st[qt][0][3], st[qt][1][0], st[qt][1][1]),
+                             max3f(st[qt][1][2], st[qt][1][3], st[qt][2][0])),
+                       max3f(max3f(st[qt][2][1], st[qt][2][2], st[qt][2][3]), max3f(st[qt][3][0], st[qt][3][1], st[qt][3][2]),
+                             st[qt][3][3]));
+      if constexpr (!PRE) bm = bfly_max(bm);
       // Deferred rescale: the running maximum (and with it the O^T accumulators, 12 multiplies + an exp per tile and
       // block) is only moved when some pixel of the wave saw its maximum grow by more than 2^RESCALE_LOG2 since the last
       // move; until then P = exp2(s - stale max) may reach 2^RESCALE_LOG2 = 256, well inside fp16 / bf16, and the
@@ -230,6 +254,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
         // at 0 and O^T, l at 0: nothing to rescale); later blocks only when some pixel's maximum grew by more than 2^RESCALE_LOG2.
         const bool first = blk == 0;
         if (first || __any(bm > RESCALE_LOG2)) {
+          bm = bfly_max(bm);
           const float delta = first ? bm : fmaxf(bm, 0.f);
           mrun[qt] += delta;
           if (!first) {
@@ -286,6 +311,11 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) o[qt][u] = Tr<T>::mfma(va[s2 * NDT + u], pb[qt][s2], o[qt][u]);
     __builtin_amdgcn_s_setprio(0);
+  };
+  for (int blk = 0; blk < nblk; blk += DEPTH) {
+    body(std::integral_constant<int, 0>{}, blk);
+    if (blk + 1 < nblk) body(std::integral_constant<int, 1>{}, blk + 1);
+    if (blk + 2 < nblk) body(std::integral_constant<int, 2>{}, blk + 2);
   }
 
 #pragma unroll
