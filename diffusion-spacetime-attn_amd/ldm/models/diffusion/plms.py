@@ -16,9 +16,11 @@ blocks instead of being compared with 981.
 MI355X-specific: with `opt_epochs=0` (fixed weights; BASELINE config 2) the whole CFG UNet call is
 captured once into a hipGraph and replayed for the 51 calls of a trajectory (sta.graphs).
 """
+import math
 import os
 
 import numpy as np
+
 import torch
 
 from ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
@@ -129,7 +131,10 @@ class PLMSSampler(object):
     def __init__(self, model, schedule="linear", loss_model=None, opt_epochs=3, lr=0.005, weight_init=5.0,
                  local_loss_weight=5.0, use_graph=True, save_images=True, outdir="result_outputs/", loss_scale=None, **kwargs):
         """`loss_scale`: the fidelity loss is multiplied by it before backward and W.grad divided by it before the Adam step.
-        None = 2^12 when the model computes in fp16, 1 otherwise. The backward of a tracked epoch runs through 2 x 51 UNet calls
+        None = 1 for bf16 / fp32 models; for an fp16 model the power of two that brings the scaled loss to [2^15, 2^16)
+        (2^12 for the synthetic CLIP stand-in's loss of ~11; the same gradients whatever the loss model's own scale is:
+        tests/test_modules_gpu.py::test_fp16_small_gradients_survive_with_loss_scaling drives a loss 2^-16 of that one), and
+        a tracked epoch whose W.grad comes back non-finite is re-run at 2^-8 of the scale. The backward of a tracked epoch runs through 2 x 51 UNet calls
         and the VAE decoder in the model's 16-bit type: with a CLIP loss the per-pixel gradients are ~1e-6 and smaller, i.e.
         fp16-subnormal or zero, and W.grad would lose precision or flush to 0 silently (bf16 has fp32's exponent range and needs
         nothing). A power of two scales exactly, so the unscaled W.grad equals the unscaled computation wherever that one is
@@ -256,25 +261,31 @@ class PLMSSampler(object):
             if tuned:
                 torch.cuda.tunable.enable(False)
             try:
-                with torch.set_grad_enabled(track):
-                    # tracked epochs: eager autograd through the 51 calls, or (sta.pipeline.set_recompute mode "call") the
-                    # fixed-weight forward per call + one re-run of the call under autograd in backward
-                    by_call = track and getattr(self.model, "sta_call_recompute", False)
-                    img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
-                                           time_range, W if batched else W[0], block_boxes, text_index,
-                                           graph=self.use_graph and (not track or by_call), call_recompute=by_call)
-                    x_img = None
-                    if self.model.first_stage_model is not None:
-                        x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
-                    if track:
-                        loss = sum(self._fidelity_loss(x_img[i].float(), texts[i], boxes[i], names[i]) for i in range(b))
-                        optimizer.zero_grad()
-                        scale = self._loss_scale()
-                        (loss * scale if scale != 1.0 else loss).backward()
-                        if scale != 1.0:
-                            W.grad.div_(scale)
-                        optimizer.step()
-                        result.setdefault("losses", []).append(float(loss.detach()))
+                scale_backoff = 1.0
+                while True:
+                    with torch.set_grad_enabled(track):
+                        # tracked epochs: eager autograd through the 51 calls, or (sta.pipeline.set_recompute mode "call") the
+                        # fixed-weight forward per call + one re-run of the call under autograd in backward
+                        by_call = track and getattr(self.model, "sta_call_recompute", False)
+                        img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
+                                               time_range, W if batched else W[0], block_boxes, text_index,
+                                               graph=self.use_graph and (not track or by_call), call_recompute=by_call)
+                        x_img = None
+                        if self.model.first_stage_model is not None:
+                            x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
+                        if track:
+                            loss = sum(self._fidelity_loss(x_img[i].float(), texts[i], boxes[i], names[i]) for i in range(b))
+                            optimizer.zero_grad()
+                            scale = self._loss_scale(float(loss.detach())) * scale_backoff
+                            (loss * scale if scale != 1.0 else loss).backward()
+                            if scale != 1.0:
+                                if not bool(torch.isfinite(W.grad).all()) and scale_backoff > 2.0 ** -24:
+                                    scale_backoff /= 256.0         # an fp16 overflow somewhere in the backward: same epoch again, smaller scale
+                                    continue
+                                W.grad.div_(scale)
+                            optimizer.step()
+                            result.setdefault("losses", []).append(float(loss.detach()))
+                    break
             finally:
                 if tuned:            # an exception inside the epoch (OOM, missing CLIP, Ctrl-C) must not leave the process-wide switch off
                     torch.cuda.tunable.enable(True)
@@ -287,10 +298,12 @@ class PLMSSampler(object):
         self.last_result = result
         return None
 
-    def _loss_scale(self):
+    def _loss_scale(self, loss_value):
         if self.loss_scale is not None:
             return float(self.loss_scale)
-        return 4096.0 if next(self.model.model.parameters()).dtype == torch.float16 else 1.0
+        if next(self.model.model.parameters()).dtype != torch.float16 or not (0.0 < abs(loss_value) < float("inf")):
+            return 1.0
+        return float(2.0 ** min(max(math.floor(math.log2(65536.0 / abs(loss_value))), 0), 60))
 
     def _fidelity_loss(self, image, curr_text, bboxs_curr, object_names):
         if self.clip_loss_model is None:

@@ -418,6 +418,69 @@ def _weight_optimisation_reference():
     return _WOPT_REF
 
 
+class _TinyLoss:
+    """A loss model whose values (and so every upstream gradient) are 2^-16 of DCLIPLoss's: the regime a real CLIP loss puts
+    the backward in (per-pixel gradients of 1e-6 and below)."""
+
+    def __init__(self, inner, factor):
+        self.inner, self.factor = inner, factor
+
+    def forward_2(self, image, text):
+        return self.inner.forward_2(image, text) * self.factor
+
+    def forward_3(self, image, text):
+        return self.inner.forward_3(image, text) * self.factor
+
+
+def test_fp16_small_gradients_survive_with_loss_scaling():
+    """fp16 tracked epoch with upstream gradients 2^-16 of the usual ones (what a real CLIP loss produces): with the
+    sampler's default fp16 loss scale (the power of two that brings the loss to [2^15, 2^16), PLMSSampler._loss_scale) dLoss/dW keeps the direction of the fp32 host chain
+    (the oracle-backed reference of test_weight_optimisation_on_gpu: scaling a loss by a positive constant does not change
+    a gradient's sign); the un-scaled run is reported beside it and must not be better."""
+    from ldm.models.autoencoder import AutoencoderKL
+    from ldm.models.diffusion.ddpm import LatentDiffusion
+    from ldm.models.diffusion.plms import DCLIPLoss, PLMSSampler
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from sta.pipeline import set_recompute
+    from sta.synth import SyntheticCLIP
+    meta = json.load(open(os.path.join(G, "unet_state_dict_keys.json")))
+    unet = UNetModel(**dict(meta["cfg"], use_checkpoint=True)).eval()
+    seeded_fill_(unet, 21)
+    vae = AutoencoderKL(ddconfig=dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=32,
+                                      ch_mult=[1, 2, 4, 4], num_res_blocks=1, attn_resolutions=[], dropout=0.0))
+    seeded_fill_(vae, 3)
+    model = LatentDiffusion(unet_config=unet.to(torch.float16), first_stage_config=vae.to(torch.float16)).cuda()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    set_recompute(model, "none")
+    c, local_ctx, x_T = gi.unet_inputs(2, 6)
+    ref = _weight_optimisation_reference()
+    ref_sign = torch.sign(ref["W"] - 2.5)
+    strong = ref["grad"].abs() > 0.05 * ref["grad"].abs().max()
+    agree = {}
+    for name, scale in (("default", None), ("no scaling", 1.0)):
+        grads = []
+        orig_step = torch.optim.Adam.step
+        torch.optim.Adam.step = lambda self, *a, **k: (grads.append(self.param_groups[0]["params"][0].grad.clone()), orig_step(self, *a, **k))[1]
+        try:
+            sampler = PLMSSampler(model, loss_model=_TinyLoss(DCLIPLoss(SyntheticCLIP().cuda()), 2.0 ** -16), opt_epochs=2,
+                                  save_images=False, loss_scale=scale)
+            sampler.sample(S=6, conditioning=c.cuda(), batch_size=1, shape=[4, 32, 32], verbose=False, unconditional_guidance_scale=7.5,
+                           unconditional_conditioning=gi.load_uncond().cuda(), x_T=x_T.cuda(), text_index=0, curr_text="two things",
+                           bboxs_curr=[[0.3, 0.4], [0.7, 0.6]], seed=1, prompt_idx=0, object_names=["The cat", "dog"],
+                           local_conditionings=[l.cuda() for l in local_ctx])
+        finally:
+            torch.optim.Adam.step = orig_step
+        g = grads[0][0].cpu()
+        assert torch.isfinite(g).all()
+        agree[name] = ((torch.sign(g)[strong] == -ref_sign[strong]).float().mean().item(), (g != 0).float().mean().item(),
+                       (g.abs().max() / (ref["grad"].abs().max() * 2.0 ** -16)).item())
+    print("fp16, loss x 2^-16: (sign agreement on strong entries, non-zero fraction, max|dW| / expected) =", agree)
+    a, nz, mag = agree["default"]
+    assert a >= 0.95 and nz == 1.0 and 0.5 < mag < 2.0, agree
+    assert agree["no scaling"][0] <= a + 1e-6, agree
+
+
 def test_entry_point_script_end_to_end(tmp_path):
     """scripts/txt2img-mscoco.py on a 4-prompt dataset with a layout JSON: synthetic SD-v1 weights, fixed blend
     weights, 3 PLMS steps; one prompt alone + batches grouped by object count; PNGs named like the reference's

@@ -19,7 +19,7 @@ if os.environ.get("STA_FA_LIB"):
     torch.backends.cuda.preferred_rocm_fa_library(os.environ["STA_FA_LIB"])
     print("rocm fa library:", torch.backends.cuda.preferred_rocm_fa_library())
 I = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1
-dev, dt, K = torch.device("cuda", 0), torch.bfloat16, 2
+dev, dt, K = torch.device("cuda", 0), (torch.float16 if os.environ.get('DT', 'fp16') == 'fp16' else torch.bfloat16), 2
 model = build_sd_v1(dev, dt, with_vae=False, init_weights=True, seed=0, use_checkpoint=True)
 set_recompute(model, "none")
 uc, c, local_c = conditionings(model, "a photo of a cat and a dog", ["cat", "dog"], dt)
@@ -48,9 +48,12 @@ for _ in range(5):
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / 5
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=bool(os.environ.get('STACK'))) as prof:
     for _ in range(3):
         call()
     torch.cuda.synchronize()
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=50))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=40, max_shapes_column_width=70))
+if os.environ.get("STACK"):
+    print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=40))
 print("wall per fwd+bwd call (un-profiled): %.1f ms" % (wall * 1e3))
