@@ -73,8 +73,9 @@ int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, l
  *   scale[r] = max_c |x[r, c]| / 448 (1 if the row is all zero);  xq[r, c] = e4m3( x[r, c] / scale[r] )
  *   x [rows][C] dtype, xq [rows][C] bytes, scale [rows] fp32;  C % 8 == 0, C <= 5120.
  * Stands in front of the nn.Linear layers of the transformer blocks (reference attention.py:50,69,164-171) when their
- * weights are stored as e4m3 with one fp32 scale per output channel: the GEMM then runs e4m3 x e4m3 -> fp32 on the
- * fp8 MFMA path (hipBLASLt) and the two scale vectors are applied to its fp32 accumulators.
+ * weights are stored as e4m3 with one fp32 scale per output channel: the GEMM is then hipBLASLt's row-scaled e4m3 GEMM (a
+ * library call; non-block-scaled fp8 runs at the 16-bit MFMA rate on gfx950, so this is a weight-memory option, not a
+ * rate option: DESIGN.md section 5) and the two scale vectors are applied to its fp32 accumulators.
  */
 int sta_quant_rows_fp8(const void* x, void* xq, float* scale, long rows, int C, int dtype, void* stream);
 

@@ -133,7 +133,8 @@ int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const 
  * Supported when sta_xattn_fwd_proj_supported(C, heads, M, K) != 0: d <= 96, C % 160 == 0, 64 < M <= 80 and the head's
  * Wq slice plus all K+2 contexts fit the 160 KiB LDS of a CU (SD-v1 level 0, C = 320: K <= 4). Other shapes take
  * the GEMM + sta_xattn_fwd. At d = 40 with K <= 2 and an even head count a workgroup serves a head PAIR from one read
- * of the y rows (compact per-(ctx, head) images, packed alongside by the same two pack calls).
+ * of the y rows (64 < M <= 77; per-(ctx, head) operand images of 13952 bytes in which one 16- or 8-byte LDS read is one
+ * MFMA operand, packed alongside by the same two pack calls; csrc/sta_xattn_proj3.h holds the layout).
  */
 int sta_xattn_fwd_proj_supported(int C, int heads, int M, int K);
 size_t sta_xattn_packed_wq_bytes(int C, int heads);

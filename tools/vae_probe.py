@@ -8,7 +8,8 @@ for _k in ("FWD", "BWD", "WRW"):
 import torch
 from sta.pipeline import build_sd_v1
 I = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-for dt in (torch.float16, torch.bfloat16):
+torch.backends.cudnn.benchmark = os.environ.get("FIND", "1") == "1"      # MIOpen measures its solvers per shape (immediate mode otherwise)
+for dt in [getattr(torch, t) for t in os.environ.get("DT", "float16,bfloat16").split(",")]:
     model = build_sd_v1("cuda", dt, with_vae=True, channels_last=True)
     z = torch.randn(I, 4, 64, 64, device="cuda", dtype=dt)
     for cl in (False, True):
