@@ -13,7 +13,9 @@ sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd"))
 for k in ("FWD", "BWD", "WRW"):
     os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + k, "0")
 from sta import prompt_state  # noqa: E402
-from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, set_recompute  # noqa: E402
+from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, set_recompute, use_shipped_miopen_db  # noqa: E402
+
+use_shipped_miopen_db(0)
 
 if os.environ.get("STA_FA_LIB"):
     torch.backends.cuda.preferred_rocm_fa_library(os.environ["STA_FA_LIB"])
@@ -55,5 +57,11 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
 print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=50))
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=40, max_shapes_column_width=70))
 if os.environ.get("STACK"):
-    print(prof.key_averages(group_by_stack_n=6).table(sort_by="self_cuda_time_total", row_limit=40, max_name_column_width=40))
+    rows = [e for e in prof.key_averages(group_by_stack_n=8) if e.key in ("aten::copy_", "aten::add_", "aten::add", "aten::cat", "aten::mul")]
+    rows.sort(key=lambda e: -e.self_device_time_total)
+    for e in rows[:40]:
+        print("%-12s %8.2f ms %4d calls" % (e.key, e.self_device_time_total / 1e3, e.count))
+        for fr in e.stack[:8]:
+            if "site-packages/torch" not in fr and "dist-packages/torch" not in fr:
+                print("      ", fr[-150:])
 print("wall per fwd+bwd call (un-profiled): %.1f ms" % (wall * 1e3))
