@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from ldm.modules.diffusionmodules.util import make_ddim_sampling_parameters, make_ddim_timesteps
+from sta import fused as _fused
 from sta import prompt_state as _ps
 
 mode = _ps.MODE
@@ -262,11 +263,12 @@ class PLMSSampler(object):
                 torch.cuda.tunable.enable(False)
             try:
                 scale_backoff = 1.0
+                by_call = track and getattr(self.model, "sta_call_recompute", False)
                 while True:
-                    with torch.set_grad_enabled(track):
-                        # tracked epochs: eager autograd through the 51 calls, or (sta.pipeline.set_recompute mode "call") the
-                        # fixed-weight forward per call + one re-run of the call under autograd in backward
-                        by_call = track and getattr(self.model, "sta_call_recompute", False)
+                    # tracked epochs: eager autograd through the 51 calls, or (sta.pipeline.set_recompute mode "call") the
+                    # fixed-weight forward per call + one re-run of the call under autograd in backward, with the glue passes of
+                    # the trunk as autograd Functions over the HIP kernels (sta.fused.tracked)
+                    with torch.set_grad_enabled(track), _fused.tracked(by_call):
                         img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
                                                time_range, W if batched else W[0], block_boxes, text_index,
                                                graph=self.use_graph and (not track or by_call), call_recompute=by_call)

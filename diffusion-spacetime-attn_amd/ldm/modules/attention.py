@@ -39,6 +39,8 @@ class GEGLU(nn.Module):
         h = self.proj(x)
         if _fused.usable(h):
             return _fused.geglu(h)                     # chunk + gelu + mul in one pass (csrc/sta_unet.hip)
+        if _fused.tracked_usable(h):
+            return _fused.geglu_tracked(h)             # the same pass under autograd, HIP input gradient
         a, gate = h.chunk(2, dim=-1)
         return a * F.gelu(gate)
 
@@ -261,6 +263,17 @@ class BasicTransformerBlock(nn.Module):
                 blended = _ops.xattn_blend(q, c, cache.packed, cache.mask, self.attn2.scale)
             x, y = _fused.add_layernorm(x, self.attn2.to_out(blended), None, n3.weight, n3.bias, n3.eps)
             return self.ff(y) + x
+        if _fused.tracked_usable(x):
+            # tracked epochs (opt-in, fused.TRACKED): the residual adds run inside the LayerNorm passes as above, each pass an
+            # autograd Function whose backward is one HIP input-gradient kernel (parameters are frozen)
+            n1, n2, n3 = self.norm1, self.norm2, self.norm3
+            x, y = _fused.add_layernorm_tracked(x, None, in_bias, n1.weight, n1.bias, n1.eps)
+            x, y = _fused.add_layernorm_tracked(x, self.attn1(y), None, n2.weight, n2.bias, n2.eps)
+            q = self.attn2.to_q(y)
+            self._keep_maps(q, c, cache)
+            blended = _ops.xattn_blend(q, c, cache.packed, cache.mask, self.attn2.scale)
+            x, y = _fused.add_layernorm_tracked(x, self.attn2.to_out(blended), None, n3.weight, n3.bias, n3.eps)
+            return self.ff(y) + x
         if in_bias is not None:
             x = x + in_bias
         x = self.attn1(self.norm1(x)) + x
@@ -303,7 +316,11 @@ class SpatialTransformer(nn.Module):
         b, c, h, w = x.shape
         if _fused.usable(x) and (_fused.is_nhwc(x) or b <= 32):     # NCHW path uses weight-broadcast bmm: see _self_attention_hip
             return self._forward_fused(x, context, time, text_index, coef, bboxs_curr)
-        t = self.proj_in(self.norm(x))
+        if _fused.tracked_usable(x):
+            xn = _fused.groupnorm_silu_tracked(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, silu=False)
+        else:
+            xn = self.norm(x)
+        t = self.proj_in(xn)
         # 'b c h w -> b (h w) c': a free view when the activation is channels_last (NHWC in memory)
         t = t.permute(0, 2, 3, 1).reshape(b, h * w, -1)
         for blk in self.transformer_blocks:

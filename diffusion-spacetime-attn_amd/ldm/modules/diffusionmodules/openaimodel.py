@@ -90,9 +90,28 @@ class ResBlock(TimestepBlock):
     def _forward(self, x, emb):
         if _fused.usable(x):
             return self._forward_fused(x, emb)
+        if _fused.tracked_usable(x):
+            return self._forward_tracked(x, emb)
         h = self.in_layers(x)
         h = h + self.emb_layers(emb).type(h.dtype)[:, :, None, None]
         return self.skip_connection(x) + self.out_layers(h)
+
+    def _forward_tracked(self, x, emb):
+        """Tracked epochs on an NHWC trunk (opt-in, sta.fused.TRACKED): the op structure of _forward_fused with every glue pass an
+        autograd Function whose backward is one HIP input-gradient kernel (csrc/sta_unet_bwd.hip); convolutions through MIOpen."""
+        gn1, _, conv1 = self.in_layers
+        gn2, _, _, conv2 = self.out_layers
+        h = _fused.groupnorm_silu_tracked(x, gn1.weight, gn1.bias, gn1.num_groups, gn1.eps)
+        h = F.conv2d(h, conv1.weight, None, conv1.stride, conv1.padding)
+        add = (self.emb_layers(emb).float() + conv1.bias.float()).detach()            # no path from the blend weights to the embedding
+        h = _fused.groupnorm_silu_tracked(h, gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, add=add)
+        h = F.conv2d(h, conv2.weight, None, conv2.stride, conv2.padding)
+        skip, bias = x, conv2.bias
+        if not isinstance(self.skip_connection, nn.Identity):
+            sc = self.skip_connection
+            skip = F.conv2d(x, sc.weight, None, sc.stride, sc.padding)
+            bias = conv2.bias + sc.bias
+        return _fused.add_bias_tracked(skip, h, bias)
 
     def _forward_fused(self, x, emb):
         """Inference: GroupNorm+SiLU are one pass each; the timestep-embedding add AND conv1's bias ride into the
@@ -196,6 +215,10 @@ class UNetModel(nn.Module):
             gn, _, conv = self.out
             h = _fused.groupnorm_silu(h, gn.weight, gn.bias, gn.num_groups, gn.eps)
             return conv(h).to(x.dtype).contiguous()
+        if _fused.tracked_usable(h):
+            gn, _, conv = self.out
+            h = _fused.groupnorm_silu_tracked(h, gn.weight, gn.bias, gn.num_groups, gn.eps)
+            return conv(h).to(x.dtype)
         return self.out(h).to(x.dtype)
 
     def transformer_blocks(self):

@@ -1,9 +1,13 @@
 """Python face of include/sta_unet.h: one-pass HIP kernels for the elementwise / normalisation chains of the
 UNet trunk around the cross-attention path (ResBlock, SpatialTransformer, BasicTransformerBlock, GEGLU).
 
-They are inference kernels: `usable()` is False whenever autograd is recording, and the modules then run the
-reference's eager sequence (which is also what the CPU tests exercise). `fused.ENABLED = False` (tools/, tests) switches
-them off."""
+The forward kernels are used for inference: `usable()` is False whenever autograd is recording, and the modules then run
+the reference's eager sequence (which is also what the CPU tests exercise). `fused.ENABLED = False` (tools/, tests) switches
+them off. For the tracked (weight-optimisation) epochs the same forward kernels are wrapped in autograd Functions whose
+backward is a HIP input-gradient kernel (csrc/sta_unet_bwd.hip: parameters are frozen, only d(input) exists): `tracked_usable()`,
+`GroupNormSiLUFn`, `GegluFn`, `AddLayerNormFn`, `AddBiasFn`. They are opt-in (`with fused.tracked():`, entered by PLMSSampler
+around a tracked epoch under the per-call recomputation policy of sta.pipeline.set_recompute) so that the other policies keep
+the eager chain the goldens pin."""
 
 import torch
 
@@ -12,6 +16,7 @@ from . import lib
 _DT = {torch.bfloat16: lib.STA_BF16, torch.float16: lib.STA_F16}
 ENABLED = True          # A/B switch for tools/ and tests; nothing reads the environment
 _hold = 0               # > 0 inside `held()`: the forward of a block that will be re-run under autograd
+TRACKED = False         # differentiable fused glue ops while autograd records (see module docstring)
 
 
 class held:
@@ -26,6 +31,22 @@ class held:
     def __exit__(self, *exc):
         global _hold
         _hold -= 1
+
+
+class tracked:
+    """Context in which the differentiable fused glue ops are used while autograd records (tracked epochs)."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global TRACKED
+        self.prev, TRACKED = TRACKED, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global TRACKED
+        TRACKED = self.prev
 
 
 def is_nhwc(x):
@@ -121,3 +142,129 @@ def add_bias_nchw(a, b=None, bias=None):
     lib.check(lib.load().sta_add_bias_nchw(a.data_ptr(), _ptr(b), _ptr(bias), y.data_ptr(), B, C, HW, _DT[a.dtype], _stream()),
               "sta_add_bias_nchw")
     return y
+
+
+# -- differentiable forms for the tracked epochs ----------------------------------------------------------------------
+def tracked_usable(x):
+    """The differentiable fused glue ops apply while autograd records, on dense 16-bit CUDA activations (4-D ones in NHWC)."""
+    return (TRACKED and ENABLED and x.is_cuda and x.dtype in _DT and torch.is_grad_enabled()
+            and (is_nhwc(x) if x.dim() == 4 else x.is_contiguous()))
+
+
+class GroupNormSiLUFn(torch.autograd.Function):
+    """act(GroupNorm(x + add[:, :, None, None])) on an NHWC activation; backward = sta_groupnorm_silu_nhwc_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, add, weight, bias, groups, eps, silu):
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        L = lib.load()
+        add = None if add is None else add.float().contiguous()
+        y = torch.empty_like(x)
+        ws = torch.empty(L.sta_groupnorm_nhwc_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)
+        lib.check(L.sta_groupnorm_silu_nhwc(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(), ws.data_ptr(),
+                                            B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()), "sta_groupnorm_silu_nhwc")
+        ctx.save_for_backward(x, add, weight, bias, ws)
+        ctx.cfg = (B, C, HW, groups, float(eps), int(bool(silu)))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, add, weight, bias, ws = ctx.saved_tensors
+        B, C, HW, groups, eps, silu = ctx.cfg
+        if not is_nhwc(dy):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x)
+        wsb = torch.empty_like(ws)
+        lib.check(lib.load().sta_groupnorm_silu_nhwc_bwd(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), dy.data_ptr(),
+                                                         dx.data_ptr(), ws.data_ptr(), wsb.data_ptr(), B, C, HW, groups, eps, silu,
+                                                         _DT[x.dtype], _stream()), "sta_groupnorm_silu_nhwc_bwd")
+        return dx, None, None, None, None, None, None
+
+
+def groupnorm_silu_tracked(x, weight, bias, groups, eps, add=None, silu=True):
+    """Differentiable GroupNorm(+pre-add)(+SiLU) for NHWC activations (eager chain outside the kernel's limits)."""
+    C = x.shape[1]
+    if add is not None and add.requires_grad:
+        raise RuntimeError("the pre-add of the fused GroupNorm carries no gradient (timestep embedding)")
+    if not is_nhwc(x) or C % 8 or C // groups < 8 or C > 4096 or groups > 64:
+        h = x if add is None else x + add.to(x.dtype)[:, :, None, None]
+        h = torch.nn.functional.group_norm(h, groups, weight, bias, eps)
+        return torch.nn.functional.silu(h) if silu else h
+    return GroupNormSiLUFn.apply(x, add, weight, bias, groups, eps, silu)
+
+
+class GegluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return geglu(h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        D = h.shape[-1] // 2
+        dy = dy.contiguous()
+        dh = torch.empty_like(h)
+        lib.check(lib.load().sta_geglu_bwd(h.data_ptr(), dy.data_ptr(), dh.data_ptr(), h.numel() // (2 * D), D, _DT[h.dtype], _stream()),
+                  "sta_geglu_bwd")
+        return dh
+
+
+def geglu_tracked(h):
+    if (h.shape[-1] // 2) % 8 or not h.is_contiguous():
+        a, gate = h.chunk(2, dim=-1)
+        return a * torch.nn.functional.gelu(gate)
+    return GegluFn.apply(h)
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """(s, y) = (x + f + bias, LayerNorm(s)); backward: ds_total = ds + dLayerNorm(dy), handed to x and f alike."""
+
+    @staticmethod
+    def forward(ctx, x, f, bias, ln_weight, ln_bias, eps):
+        s, y = add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True)
+        ctx.save_for_backward(s, ln_weight)
+        ctx.eps, ctx.has_f = float(eps), f is not None
+        return s, y
+
+    @staticmethod
+    def backward(ctx, ds, dy):
+        s, ln_weight = ctx.saved_tensors
+        C = s.shape[-1]
+        dy = dy.contiguous()
+        ds = None if ds is None else ds.contiguous()
+        g = torch.empty_like(s)
+        lib.check(lib.load().sta_layernorm_bwd(s.data_ptr(), ln_weight.data_ptr(), dy.data_ptr(), _ptr(ds), g.data_ptr(), s.numel() // C, C,
+                                               ctx.eps, _DT[s.dtype], _stream()), "sta_layernorm_bwd")
+        return g, (g if ctx.has_f else None), None, None, None, None
+
+
+def add_layernorm_tracked(x, f, bias, ln_weight, ln_bias, eps):
+    """Differentiable (x + f + bias, LayerNorm(x + f + bias)); x, f [.., C] contiguous."""
+    C = x.shape[-1]
+    if C % 8 or C > 2048 or not x.is_contiguous() or (f is not None and not f.is_contiguous()):
+        t = x if f is None else x + f
+        t = t if bias is None else t + bias
+        return t, torch.nn.functional.layer_norm(t, (C,), ln_weight, ln_bias, eps)
+    return AddLayerNormFn.apply(x, f, bias, ln_weight, ln_bias, eps)
+
+
+class AddBiasFn(torch.autograd.Function):
+    """a + b + bias[None, :, None, None] (NHWC); backward hands dy to a and b."""
+
+    @staticmethod
+    def forward(ctx, a, b, bias):
+        ctx.has_b = b is not None
+        return add_bias_nchw(a, b, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, (dy if ctx.has_b else None), None
+
+
+def add_bias_tracked(a, b=None, bias=None):
+    if not is_nhwc(a) or a.shape[1] % 8 or (b is not None and not is_nhwc(b)):
+        t = a if b is None else a + b
+        return t if bias is None else t + bias[None, :, None, None]
+    return AddBiasFn.apply(a, b, bias)

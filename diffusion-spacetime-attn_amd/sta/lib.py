@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj3.hip", "sta_selfattn.hip", "sta_selfattn_bwd.hip", "sta_unet.hip", "sta_fp8.hip")]
+SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj3.hip", "sta_selfattn.hip", "sta_selfattn_bwd.hip", "sta_unet.hip", "sta_unet_bwd.hip", "sta_fp8.hip")]
 
 # Self-attention keeps its MFMA accumulators in VGPRs: hipcc otherwise parks them in AGPRs and brackets the
 # online-softmax rescale with v_accvgpr_read/write pairs (120 extra VALU instructions per key block in a kernel
@@ -63,6 +63,9 @@ SYMBOLS = {
     "sta_groupnorm_silu_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "sta_add_bias_rows": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _vp]),
     "sta_quant_rows_fp8": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "sta_groupnorm_silu_nhwc_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "sta_geglu_bwd": (_i, [_vp, _vp, _vp, _l, _i, _i, _vp]),
+    "sta_layernorm_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
 }
 
 

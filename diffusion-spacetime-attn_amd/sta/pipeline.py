@@ -158,6 +158,11 @@ def set_recompute(model, mode="auto", prompts_per_step=1):
         mode = "none" if prompts_per_step <= 2 else "call"
     model.sta_call_recompute = mode == "call"
     unet = model.model.diffusion_model
+    if mode == "call" and next(unet.parameters()).is_cuda:
+        # per-call recomputation re-runs a call under autograd with the differentiable fused glue ops (sta.fused.tracked),
+        # whose GroupNorm works on NHWC activations: MIOpen's NHWC convolutions need no layout transposes in either
+        # direction and 'b c h w -> b (h w) c' is a view
+        unet.to(memory_format=torch.channels_last)
     from ldm.modules.diffusionmodules.openaimodel import ResBlock
     for m in unet.modules():
         if isinstance(m, ResBlock):

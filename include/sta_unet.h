@@ -79,6 +79,25 @@ int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, l
  */
 int sta_quant_rows_fp8(const void* x, void* xq, float* scale, long rows, int C, int dtype, void* stream);
 
+/*
+ * Input gradients of the glue kernels, for the tracked (weight-optimisation) epochs (plms.py:220-277): the blend weights
+ * are the only leaf and every model parameter is frozen, so each op needs d(input) only. csrc/sta_unet_bwd.hip.
+ *
+ * sta_groupnorm_silu_nhwc_bwd: dx of y = act(GroupNorm_G(x + add) * gamma + beta) on NHWC activations. fwd_workspace is the
+ *   workspace the FORWARD call filled for the same x (its per-chunk moments; mean / rstd are rebuilt from it), bwd_workspace
+ *   another sta_groupnorm_nhwc_workspace_bytes(B, HW, G) bytes. Same limits as the forward. (add gets no gradient: the
+ *   timestep embedding does not depend on the blend weights.)
+ * sta_geglu_bwd: dx [R][2D] of y = x[:, :D] * gelu(x[:, D:]) given dy [R][D].
+ * sta_layernorm_bwd: ds = dLayerNorm(s)^T dy + dres for y = LayerNorm(s) * gamma + beta; s, dy, dres (may be NULL: the
+ *   gradient reaching s through the residual connection), ds [R][C]; C % 8 == 0, C <= 2048.
+ */
+int sta_groupnorm_silu_nhwc_bwd(const void* x, const float* add, const void* gamma, const void* beta, const void* dy, void* dx,
+                                const void* fwd_workspace, void* bwd_workspace, int B, int C, int HW, int G, float eps, int silu,
+                                int dtype, void* stream);
+int sta_geglu_bwd(const void* x, const void* dy, void* dx, long R, int D, int dtype, void* stream);
+int sta_layernorm_bwd(const void* s, const void* gamma, const void* dy, const void* dres, void* ds, long R, int C, float eps,
+                      int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,3 +158,100 @@ def test_fused_error_convention():
     rc = lib.load().sta_groupnorm_silu(x.data_ptr(), 0, w.data_ptr(), w.data_ptr(), x.data_ptr(), 2, 30, 25, 3, 1e-5, 1, 0, 0)
     assert rc == -1 and b"groupnorm" in lib.load().sta_last_error()            # the C-ABI rejects it; the wrapper never calls it
     assert not fused.usable(torch.randn(4, 8))                                  # CPU tensors never take the fused path
+
+
+# ---- input gradients for the tracked epochs (csrc/sta_unet_bwd.hip) vs fp32 autograd of the reference's op chain --------
+def _grad_close(got, ref, dtype, k=4.0):
+    """Gradient of a 16-bit chain: the error scales with the gradient's magnitude over the tensor (sums of many products)."""
+    err = (got.float().cpu() - ref).abs()
+    tol = k * EPS[dtype] * (ref.abs() + ref.abs().mean() + 1e-6)
+    assert (err <= tol).all(), "max err %.4g at tol %.4g (ref max %.4g)" % (err.max().item(), tol[err.argmax()].item() if err.numel() else 0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,C,H,G", [(2, 320, 64, 32), (3, 640, 32, 32), (2, 1280, 16, 32), (2, 2560, 8, 32), (2, 64, 12, 8), (2, 960, 64, 32)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_add,silu", [(False, True), (True, True), (False, False)])
+def test_groupnorm_silu_tracked_gradient(B, C, H, G, dtype, with_add, silu):
+    from sta import fused
+    g = torch.Generator().manual_seed(B * C + H + 1)
+    x = (torch.randn(B, C, H, H, generator=g) * 1.7 + 0.3).to(dtype)
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    add = torch.randn(B, C, generator=g) if with_add else None
+    dy = torch.randn(B, C, H, H, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    ref = F.group_norm(xr + (add[:, :, None, None] if with_add else 0.0), G, w.float(), b.float(), 1e-5)
+    ref = F.silu(ref) if silu else ref
+    ref.backward(dy.float())
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with fused.tracked():
+        assert fused.tracked_usable(xg)
+        y = fused.groupnorm_silu_tracked(xg, w.cuda(), b.cuda(), G, 1e-5, add=None if add is None else add.cuda(), silu=silu)
+    assert fused.is_nhwc(y) and y.grad_fn is not None and "GroupNormSiLUFn" in type(y.grad_fn).__name__
+    y.backward(dy.cuda().contiguous(memory_format=torch.channels_last))
+    torch.cuda.synchronize()
+    _close(y.detach(), ref.detach(), dtype)
+    _grad_close(xg.grad, xr.grad, dtype)
+
+
+@pytest.mark.parametrize("R,D", [(4096, 1280), (1000, 2560), (64, 5120), (7, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_geglu_tracked_gradient(R, D, dtype):
+    from sta import fused
+    g = torch.Generator().manual_seed(R + D + 1)
+    h = (torch.randn(R, 2 * D, generator=g) * 2).to(dtype)
+    dy = torch.randn(R, D, generator=g).to(dtype)
+    hr = h.float().requires_grad_(True)
+    a, gate = hr.chunk(2, dim=-1)
+    (a * F.gelu(gate)).backward(dy.float())
+    hg = h.cuda().requires_grad_(True)
+    with fused.tracked():
+        y = fused.geglu_tracked(hg)
+    assert "GegluFn" in type(y.grad_fn).__name__
+    y.backward(dy.cuda())
+    torch.cuda.synchronize()
+    _close(hg.grad, hr.grad, dtype)
+
+
+@pytest.mark.parametrize("R,C", [(8192, 320), (2048, 640), (513, 1280), (3, 2048), (5, 64)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_f", [True, False])
+def test_add_layernorm_tracked_gradient(R, C, dtype, with_f):
+    """(s, y) = (x + f + bias, LN(s)) with BOTH outputs used downstream, as in the transformer block."""
+    from sta import fused
+    g = torch.Generator().manual_seed(R + C + 1)
+    x = torch.randn(R, C, generator=g).to(dtype)
+    f = torch.randn(R, C, generator=g).to(dtype) if with_f else None
+    bias = (0.1 * torch.randn(C, generator=g)).to(dtype)
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    ds, dy = torch.randn(R, C, generator=g).to(dtype), torch.randn(R, C, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    fr = f.float().requires_grad_(True) if with_f else None
+    sr = ((xr + fr) if with_f else xr) + bias.float()
+    yr = F.layer_norm(sr, (C,), w.float(), b.float(), 1e-5)
+    torch.autograd.backward([sr, yr], [ds.float(), dy.float()])
+    xg = x.cuda().requires_grad_(True)
+    fg = f.cuda().requires_grad_(True) if with_f else None
+    with fused.tracked():
+        s, y = fused.add_layernorm_tracked(xg, fg, bias.cuda(), w.cuda(), b.cuda(), 1e-5)
+    torch.autograd.backward([s, y], [ds.cuda(), dy.cuda()])
+    torch.cuda.synchronize()
+    _close(y.detach(), yr.detach(), dtype, k=4.0)
+    _grad_close(xg.grad, xr.grad, dtype)
+    if with_f:
+        assert torch.equal(fg.grad, xg.grad)
+
+
+def test_add_bias_tracked_gradient():
+    from sta import fused
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(2, 64, 8, 8, generator=g).half().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    b = torch.randn(2, 64, 8, 8, generator=g).half().cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bias = torch.randn(64, generator=g).half().cuda()
+    dy = torch.randn(2, 64, 8, 8, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    with fused.tracked():
+        y = fused.add_bias_tracked(a, b, bias)
+    y.backward(dy)
+    _close(y.detach(), (a.float() + b.float() + bias.float()[None, :, None, None]).detach().cpu(), torch.float16)
+    assert torch.equal(a.grad, dy) and torch.equal(b.grad, dy)

@@ -45,6 +45,8 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert L.sta_add_bias_nchw(0, 0, 0, 0, 2, 4, 64, 0, 0) == -1 and L.sta_add_bias_rows(0, 0, 0, 0, 8, 64, 0, 0) == -1
     assert L.sta_groupnorm_nhwc_workspace_bytes(16, 4096, 32) == 16 * 32 * 2 * 32 * 4
     assert L.sta_groupnorm_silu_nhwc(0, 0, 0, 0, 0, 0, 2, 320, 4096, 32, 1e-5, 1, 0, 0) == -1
+    assert L.sta_groupnorm_silu_nhwc_bwd(0, 0, 0, 0, 0, 0, 0, 0, 2, 320, 4096, 32, 1e-5, 1, 0, 0) == -1 and b"null" in L.sta_last_error()
+    assert L.sta_geglu_bwd(0, 0, 0, 4, 64, 0, 0) == -1 and L.sta_layernorm_bwd(0, 0, 0, 0, 0, 4, 64, 1e-5, 0, 0) == -1
     assert L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2) >= 2 * 256 * 8 * 4
     assert L.sta_xattn_bwd_workspace_bytes(3, 4096, 8, 2) == 3 * L.sta_xattn_bwd_workspace_bytes(1, 4096, 8, 2)
 
