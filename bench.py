@@ -232,6 +232,9 @@ def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps
         moved = float((r["W"] - w0).abs().max()) if K else 0.0
         assert K == 0 or opt_epochs < 2 or moved > 0.0, "the tracked epochs did not move the blend weights (zero gradient)"
         out.update(W_moved=moved, decoder_calibration={"mean_before": calib[0], "std_before": calib[1], "std_after": 0.25} if calib else None)
+        if mode == "call":
+            out.update(kept_calls=getattr(sampler, "last_kept_calls", None),
+                       call_activation_gib_per_image=round(getattr(sampler, "_call_bytes_per_image", 0) / 2 ** 30, 2))
         out.update(opt_epochs=opt_epochs, recompute=mode, miopen_find=bool(find), loss="CLIP stand-in (sta.synth.SyntheticCLIP): real front-end, VAE decode "
                    "and backward through 2 x 51 UNet calls; the third epoch runs the fixed-weight path", losses=r.get("losses"))
     del sampler, model

@@ -130,7 +130,8 @@ class _CallRecompute(torch.autograd.Function):
 
 class PLMSSampler(object):
     def __init__(self, model, schedule="linear", loss_model=None, opt_epochs=3, lr=0.005, weight_init=5.0,
-                 local_loss_weight=5.0, use_graph=True, save_images=True, outdir="result_outputs/", loss_scale=None, **kwargs):
+                 local_loss_weight=5.0, use_graph=True, save_images=True, outdir="result_outputs/", loss_scale=None, keep_calls=None,
+                 **kwargs):
         """`loss_scale`: the fidelity loss is multiplied by it before backward and W.grad divided by it before the Adam step.
         None = 1 for bf16 / fp32 models; for an fp16 model the power of two that brings the scaled loss to [2^15, 2^16)
         (2^12 for the synthetic CLIP stand-in's loss of ~11; the same gradients whatever the loss model's own scale is:
@@ -142,6 +143,7 @@ class PLMSSampler(object):
         representable (the reference relies on CUDA autocast with fp32 parameters and no scaler, scripts/txt2img-gpt.py:301)."""
         super().__init__()
         self.loss_scale = loss_scale
+        self.keep_calls = keep_calls      # per-call recomputation: how many trailing calls keep their activations (None = sized to HBM)
         self.model = model
         self.ddpm_num_timesteps = model.num_timesteps
         self.schedule = schedule
@@ -329,7 +331,10 @@ class PLMSSampler(object):
     def _trajectory(self, img, cond, uncond, scale, time_range, W, bboxs_curr, text_index, graph=False, call_recompute=False):
         """W: [K, S] for one image or [I, K, S] for a batch; column i of every image is used at step i."""
         S, b, device = len(time_range), img.shape[0], img.device
-        eps_fn = self._make_eps_fn(cond, uncond, scale, bboxs_curr, text_index, graph, img, call_recompute)
+        keep = self._calls_to_keep(S + 1, b) if call_recompute and torch.is_grad_enabled() else 0
+        if call_recompute and torch.is_grad_enabled():
+            self.last_kept_calls = keep
+        eps_fn = self._make_eps_fn(cond, uncond, scale, bboxs_curr, text_index, graph, img, call_recompute, keep_last=keep, n_calls=S + 1)
         old_eps = []
         for i, step in enumerate(time_range):
             index = S - i - 1
@@ -341,7 +346,24 @@ class PLMSSampler(object):
                 old_eps.pop(0)
         return img
 
-    def _make_eps_fn(self, cond, uncond, scale, bboxs_curr, text_index, graph, img, call_recompute=False):
+    def _calls_to_keep(self, n_calls, batch):
+        """Per-call recomputation re-runs every call's forward in backward; the LAST calls of a trajectory are differentiated
+        first and freed first, so as many of them as HBM holds simply keep their activations (no re-run). The size of one call's
+        saved activations is measured on the first kept call (none is assumed before that: the first tracked epoch of a
+        sampler keeps one call); four calls' worth + 24 GiB stay free for the calls that are recomputed and the VAE backward."""
+        if not torch.cuda.is_available() or self.keep_calls == 0:
+            return 0
+        if self.keep_calls is not None:
+            return min(int(self.keep_calls), n_calls)
+        per_image = getattr(self, "_call_bytes_per_image", None)
+        if per_image is None:
+            return 1
+        est = per_image * batch
+        free, _ = torch.cuda.mem_get_info()
+        free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+        return int(max(0, min(n_calls, (free - 4 * est - (24 << 30)) // max(est, 1))))
+
+    def _make_eps_fn(self, cond, uncond, scale, bboxs_curr, text_index, graph, img, call_recompute=False, keep_last=0, n_calls=0):
         """eps(x, t, coef) with classifier-free guidance. The UNet batch is [uncond_0, cond_0, uncond_1, cond_1, ...]:
         for one image this is the reference's `cat([uc, c])` (:304-308); for a batch the pairs stay adjacent,
         which is the layout the fused kernel indexes (image-major, row 0 = uncond, row 1 = cond)."""
@@ -362,8 +384,18 @@ class PLMSSampler(object):
         def unet(fn, x, t, coef):
             return fn(pair(x, x), text_index, pair(t, t), c_in, coef=coef, bboxs_curr=bboxs_curr)
 
+        calls = [0]
+
         def eps(x, t, coef):
-            if call_recompute and torch.is_grad_enabled():
+            k = calls[0]
+            calls[0] += 1
+            if call_recompute and torch.is_grad_enabled() and k >= n_calls - keep_last:
+                # one of the last calls: plain autograd, its activations stay until backward reaches it (_calls_to_keep)
+                before = torch.cuda.memory_allocated() if x.is_cuda else 0
+                out = unet(self.model.apply_model_extra, x, t, coef)
+                if x.is_cuda and k == n_calls - 1:
+                    self._call_bytes_per_image = max(torch.cuda.memory_allocated() - before, 1) // b
+            elif call_recompute and torch.is_grad_enabled():
                 out = _CallRecompute.apply(lambda x_, t_, c_: unet(apply_fn, x_, t_, c_),
                                            lambda x_, t_, c_: unet(self.model.apply_model_extra, x_, t_, c_), t, x, coef)
             else:

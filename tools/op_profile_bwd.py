@@ -23,7 +23,8 @@ if os.environ.get("STA_FA_LIB"):
 I = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1
 dev, dt, K = torch.device("cuda", 0), (torch.float16 if os.environ.get('DT', 'fp16') == 'fp16' else torch.bfloat16), 2
 model = build_sd_v1(dev, dt, with_vae=False, init_weights=True, seed=0, use_checkpoint=True)
-set_recompute(model, "none")
+set_recompute(model, os.environ.get("POLICY", "none"))       # POLICY=call: NHWC trunk + differentiable fused glue ops
+from sta import fused  # noqa: E402
 uc, c, local_c = conditionings(model, "a photo of a cat and a dog", ["cat", "dog"], dt)
 pair = lambda u, v: torch.stack([u, v], dim=1).reshape(2 * I, *u.shape[1:])
 c_in = pair(uc.expand(I, -1, -1), c.expand(I, -1, -1)).contiguous()
@@ -36,8 +37,9 @@ prompt_state.begin_prompt([local_c] * I if I > 1 else local_c, first_timestep=98
 def call():
     x = torch.randn(I, 4, 64, 64, device=dev, requires_grad=True)
     coef = (torch.full((I, K), 2.5, device=dev) if I > 1 else torch.full((K,), 2.5, device=dev)).requires_grad_(True)
-    out = model.apply_model_extra(pair(x, x), 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
-    out.float().square().mean().backward()
+    with fused.tracked(os.environ.get("POLICY") == "call"):
+        out = model.apply_model_extra(pair(x, x), 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
+        out.float().square().mean().backward()
     return x.grad, coef.grad
 
 
