@@ -176,7 +176,7 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_stats_kernel(const T* __restric
         q[e] += t * t;
       }
     }
-    // fold the 8 channels into their (at most two, Cg >= 8) groups, then one LDS atomic per group and moment
+    // fold the 8 channels into their (at most two: Cg >= 8 or Cg == 4) groups, then one LDS atomic per group and moment
     const int g0 = (col * 8) / Cg, g1 = (col * 8 + 7) / Cg;
     float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
 #pragma unroll
@@ -515,8 +515,8 @@ int sta_groupnorm_silu_nhwc(const void* x, const float* add, const void* gamma, 
                             void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!x || !gamma || !beta || !y || !workspace) return sta_fail(STA_E_ARG, "null pointer");
-  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || G > GN_MAXG || C % G || C % 8 || C / G < 8 || C / 8 > GN_NT)
-    return sta_fail(STA_E_ARG, "groupnorm nhwc: B=%d C=%d HW=%d G=%d (need C %% 8 == 0, 8 <= C/G, C <= %d, G <= %d)", B, C, HW,
+  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || G > GN_MAXG || C % G || C % 8 || (C / G < 8 && C / G != 4) || C / 8 > GN_NT)
+    return sta_fail(STA_E_ARG, "groupnorm nhwc: B=%d C=%d HW=%d G=%d (need C %% 8 == 0, C/G >= 8 or == 4, C <= %d, G <= %d)", B, C, HW,
                     G, 8 * GN_NT, GN_MAXG);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   const int nchunk = gn_nhwc_chunks(HW), chunk_px = (HW + nchunk - 1) / nchunk;

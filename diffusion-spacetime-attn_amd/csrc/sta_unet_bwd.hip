@@ -276,8 +276,8 @@ int sta_groupnorm_silu_nhwc_bwd(const void* x, const float* add, const void* gam
                                 int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!x || !gamma || !beta || !dy || !dx || !fwd_workspace || !bwd_workspace) return sta_fail(STA_E_ARG, "null pointer");
-  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || G > GN_MAXG || C % G || C % 8 || C / G < 8 || C / 8 > GN_NT)
-    return sta_fail(STA_E_ARG, "groupnorm nhwc bwd: B=%d C=%d HW=%d G=%d (need C %% 8 == 0, 8 <= C/G, C <= %d, G <= %d)", B, C, HW,
+  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || G > GN_MAXG || C % G || C % 8 || (C / G < 8 && C / G != 4) || C / 8 > GN_NT)
+    return sta_fail(STA_E_ARG, "groupnorm nhwc bwd: B=%d C=%d HW=%d G=%d (need C %% 8 == 0, C/G >= 8 or == 4, C <= %d, G <= %d)", B, C, HW,
                     G, 8 * GN_NT, GN_MAXG);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;

@@ -16,6 +16,8 @@ def _norm_silu(norm, x):
     sampling and of the last epoch), the eager pair otherwise (the loss path of the tracked epochs)."""
     if _fused.usable(x):
         return _fused.groupnorm_silu(x, norm.weight, norm.bias, norm.num_groups, norm.eps)
+    if _fused.tracked_usable(x):      # NHWC decoder under autograd (tracked epochs, sta.fused.tracked): HIP input gradient
+        return _fused.groupnorm_silu_tracked(x, norm.weight, norm.bias, norm.num_groups, norm.eps)
     return F.silu(norm(x))
 
 
@@ -49,7 +51,10 @@ class AttnBlock(nn.Module):
 
     def forward(self, x):
         b, c, h, w = x.shape
-        n = self.norm(x)
+        if _fused.tracked_usable(x):
+            n = _fused.groupnorm_silu_tracked(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, silu=False)
+        else:
+            n = self.norm(x)
         q, k, v = (m(n).flatten(2).transpose(1, 2).unsqueeze(1) for m in (self.q, self.k, self.v))   # [b,1,hw,c]
         o = F.scaled_dot_product_attention(q, k, v, scale=c ** -0.5)
         return x + self.proj_out(o.squeeze(1).transpose(1, 2).reshape(b, c, h, w))
@@ -117,4 +122,7 @@ class AutoencoderKL(nn.Module):
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
 
     def decode(self, z):
+        w = self.decoder.conv_in.weight
+        if z.is_cuda and not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last):
+            z = z.contiguous(memory_format=torch.channels_last)       # NHWC decoder (sta.pipeline.set_recompute, per-call policy)
         return self.decoder(self.post_quant_conv(z))

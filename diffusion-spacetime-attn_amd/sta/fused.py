@@ -82,7 +82,7 @@ def groupnorm_silu(x, weight, bias, groups, eps, add=None, silu=True):
     y = torch.empty_like(x)                     # keeps the memory format
     if is_nhwc(x):
         L = lib.load()
-        if C % 8 or C // groups < 8 or C > 4096 or groups > 64:
+        if C % 8 or (C // groups < 8 and C // groups != 4) or C > 4096 or groups > 64:
             return eager()
         ws = torch.empty(L.sta_groupnorm_nhwc_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)
         lib.check(L.sta_groupnorm_silu_nhwc(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
@@ -187,7 +187,7 @@ def groupnorm_silu_tracked(x, weight, bias, groups, eps, add=None, silu=True):
     C = x.shape[1]
     if add is not None and add.requires_grad:
         raise RuntimeError("the pre-add of the fused GroupNorm carries no gradient (timestep embedding)")
-    if not is_nhwc(x) or C % 8 or C // groups < 8 or C > 4096 or groups > 64:
+    if not is_nhwc(x) or C % 8 or (C // groups < 8 and C // groups != 4) or C > 4096 or groups > 64:
         h = x if add is None else x + add.to(x.dtype)[:, :, None, None]
         h = torch.nn.functional.group_norm(h, groups, weight, bias, eps)
         return torch.nn.functional.silu(h) if silu else h

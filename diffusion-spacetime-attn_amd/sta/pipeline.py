@@ -163,6 +163,7 @@ def set_recompute(model, mode="auto", prompts_per_step=1):
         # whose GroupNorm works on NHWC activations: MIOpen's NHWC convolutions need no layout transposes in either
         # direction and 'b c h w -> b (h w) c' is a view
         unet.to(memory_format=torch.channels_last)
+        # (the VAE decoder stays NCHW: converted as well it measured 0.80 vs 0.83-0.84 images/s at 16 prompts per step)
     from ldm.modules.diffusionmodules.openaimodel import ResBlock
     for m in unet.modules():
         if isinstance(m, ResBlock):

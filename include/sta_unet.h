@@ -57,7 +57,7 @@ int sta_add_bias_nchw(const void* a, const void* b, const void* bias, void* y, i
 /*
  * NHWC ("channels_last") variants: x, y [B][HW][C]. GroupNorm needs a caller-owned workspace of
  * sta_groupnorm_nhwc_workspace_bytes(B, HW, G) bytes (per-chunk partial moments; written then read inside the
- * call, no initialisation needed). Limits: C % 8 == 0, 8 <= C / G, C <= 4096, G <= 64.
+ * call, no initialisation needed). Limits: C % 8 == 0, C / G >= 8 or == 4 (an 8-channel column spans at most two groups), C <= 4096, G <= 64.
  * MIOpen's bf16 convolutions are NHWC kernels; keeping the UNet trunk in NHWC removes the two layout transposes
  * MIOpen wraps around every NCHW convolution and makes 'b c h w -> b (h w) c' (attention.py:338) a view.
  */

@@ -168,7 +168,7 @@ def _grad_close(got, ref, dtype, k=4.0):
     assert (err <= tol).all(), "max err %.4g at tol %.4g (ref max %.4g)" % (err.max().item(), tol[err.argmax()].item() if err.numel() else 0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("B,C,H,G", [(2, 320, 64, 32), (3, 640, 32, 32), (2, 1280, 16, 32), (2, 2560, 8, 32), (2, 64, 12, 8), (2, 960, 64, 32)])
+@pytest.mark.parametrize("B,C,H,G", [(2, 320, 64, 32), (3, 640, 32, 32), (2, 1280, 16, 32), (2, 2560, 8, 32), (2, 64, 12, 8), (2, 960, 64, 32), (2, 128, 64, 32)])   # last: VAE decoder, 4 channels per group
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("with_add,silu", [(False, True), (True, True), (False, False)])
 def test_groupnorm_silu_tracked_gradient(B, C, H, G, dtype, with_add, silu):
