@@ -88,7 +88,14 @@ class CrossAttention(nn.Module):
         q = self.to_q(x).view(b, n, h, -1).transpose(1, 2)
         k = self.to_k(context).view(b, context.shape[1], h, -1).transpose(1, 2)
         v = self.to_v(context).view(b, context.shape[1], h, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
+        if q.is_cuda:
+            # shapes the HIP kernels refuse (N < 64, N % 8, head dims above 160): the reference's own formulation,
+            # einsum - softmax - einsum (attention.py:181-196), as plain library GEMMs with an fp32 softmax — no Triton-backed SDPA
+            # kernel in the product. No BASELINE config reaches this on the GPU.
+            p = torch.softmax(torch.matmul(q, k.transpose(-1, -2)).float() * self.scale, dim=-1).to(q.dtype)
+            o = torch.matmul(p, v)
+        else:
+            o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
         return self.to_out(o.transpose(1, 2).reshape(b, n, -1))
 
     def _self_attention_tracked(self, x):

@@ -31,7 +31,7 @@ dev = "cuda"
 I = int(sys.argv[1]) if len(sys.argv) > 1 else 1           # images per launch
 WGS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 37]
 NW = 8
-for (N, C) in [(4096, 320), (1024, 640)]:
+for (N, C) in [tuple(int(v) for v in t.split('x')) for t in os.environ.get('SHAPES', '4096x320,1024x640').split(',')]:
     K, H, M = 2, 8, 77
     g = torch.Generator().manual_seed(0)
     q = torch.randn(2 * I, N, C, generator=g).bfloat16().to(dev)
