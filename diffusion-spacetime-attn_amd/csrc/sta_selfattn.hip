@@ -349,6 +349,11 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   }
 }
 
+
+#ifdef STA_EXPERIMENT_SELFATTN32
+#include "../../tools/experiments/selfattn_fwd32.inc"     // 32x32x16-MFMA variant: measured slower in wall time (lower clocks), tools-only
+#endif
+
 template <typename T, int NKS, int NDT, bool SUMROW, bool PRE>
 int launch_sa_cfg(const SParams& p, hipStream_t st) {
   constexpr int QT = NDT > 6 ? 1 : 2;     // d > 96: one query tile per wave keeps the 4*NDT accumulator + 8*NDT V^T registers under 256
@@ -369,6 +374,9 @@ int launch_sa(const SParams& p, hipStream_t st) {
 
 template <typename T>
 int dispatch_sa(const SParams& p, hipStream_t st) {
+#ifdef STA_EXPERIMENT_SELFATTN32
+  if (p.d > 32 && p.d <= 48 && (p.d & 15) && p.N % 64 == 0 && p.sl2e == 1.0f && g_sta_opt[STA_OPT_SELFATTN_32] != 2) return launch_sa32<T>(p, st);
+#endif
   switch ((p.d + 15) / 16) {
     case 1: return launch_sa<T, 1, 1>(p, st);
     case 2: return launch_sa<T, 1, 2>(p, st);

@@ -66,7 +66,7 @@ enum {
   STA_OPT_STAGED_QT = 3,    /* 2: two 16-pixel sub-tiles per wave */
   STA_OPT_HEAD_MAJOR = 4,   /* 1: block b -> head b % heads; 2: XCD-contiguous tile ranges */
   STA_OPT_SPLIT_QT = 5,     /* sub-tiles per wave of the split kernel: 1, 2, 4 */
-  STA_OPT_PROJ_RING = 6,    /* reserved (round-2 experiment variants, removed); ignored */
+  STA_OPT_SELFATTN_32 = 6,  /* experiment builds only (-DSTA_EXPERIMENT_SELFATTN32): 2 = keep the 16x16x32-MFMA self-attention kernel at d = 40 */
   STA_OPT_PROJ_PAIR = 7,    /* sta_xattn_fwd_proj: 1 = head-pair kernel whenever the shape allows, 2 = one head per workgroup */
   STA_OPT_COUNT = 8
 };

@@ -22,6 +22,10 @@ for B, N, C, h in ((64, 4096, 320, 8), (64, 1024, 640, 8)):
     d = C // h
     qk = torch.randn(B, N, 2 * C, device="cuda", dtype=torch.float16)
     vt = torch.randn(B, C, N, device="cuda", dtype=torch.float16)
+    from sta import lib
     a = timed(lambda: ops.self_attention(qk[..., :C], qk[..., C:], vt, h, d ** -0.5))
     b = timed(lambda: ops.self_attention(qk[..., :C], qk[..., C:], vt, h, ops.LN2))
-    print(json.dumps({"B": B, "N": N, "d": d, "scaled_us": round(a, 1), "log2_us": round(b, 1)}))
+    lib.load().sta_set_option(lib.OPT_SELFATTN_32, 2)          # the 16x16x32-MFMA kernel where the 32x32x16 one is the default (d = 40)
+    c = timed(lambda: ops.self_attention(qk[..., :C], qk[..., C:], vt, h, ops.LN2))
+    lib.load().sta_set_option(lib.OPT_SELFATTN_32, 0)
+    print(json.dumps({"B": B, "N": N, "d": d, "scaled_us": round(a, 1), "log2_us": round(b, 1), "log2_16x16x32_us": round(c, 1)}))
