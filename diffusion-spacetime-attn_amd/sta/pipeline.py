@@ -152,7 +152,9 @@ def set_recompute(model, mode="auto", prompts_per_step=1):
       all  — the reference's policy
       call — recompute at UNet-CALL granularity (ldm.models.diffusion.plms._CallRecompute): the forward of a tracked epoch
              is the fixed-weight path (inference kernels, hipGraph) and keeps 16 KB per call and image; backward re-runs one
-             call under autograd at a time (1.6 GiB per prompt) — what lets 16-32 prompts share a step
+             call under autograd at a time (1.1 GiB per prompt) — what lets 16-32 prompts share a step. The re-run uses an
+             NHWC trunk with the differentiable fused glue ops (sta.fused.tracked, csrc/sta_unet_bwd.hip), and the last calls of a
+             trajectory keep their activations instead, as many as HBM holds (PLMSSampler._calls_to_keep)
     auto = none for <= 2 prompts per step, call above. Returns the mode applied."""
     if mode == "auto":
         mode = "none" if prompts_per_step <= 2 else "call"
