@@ -421,14 +421,20 @@ def main():
     _phase("roofline leg done")
     if world == 1 and not a.no_side_runs and a.opt_epochs == 0:
         # reported beside the headline, never part of `value`: the other 16-bit type, and BASELINE configs[2]
+        def guarded(fn):      # a side leg that fails (e.g. out of memory on a smaller box) is reported, it does not take the headline line with it
+            try:
+                return fn()
+            except Exception as e:          # noqa: BLE001
+                torch.cuda.empty_cache()
+                return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if not a.no_other_dtype:
-            out["other_dtype"] = side_run(dev, "bf16" if a.dtype == "fp16" else "fp16", 0, I, 1, 1, a.res, a.ddim_steps, K)
+            out["other_dtype"] = guarded(lambda: side_run(dev, "bf16" if a.dtype == "fp16" else "fp16", 0, I, 1, 1, a.res, a.ddim_steps, K))
         # MIOpen's per-shape solver search for the backward convolutions of the UNet and the VAE decoder costs ~10 min on a
         # fresh box; the shipped user find-db (sta/data/miopen_userdb) holds them for fp16 at 512^2, other cases run in
         # immediate mode (no search, slower solvers)
         find = a.dtype == "fp16" and a.res == 512
         torch.backends.cudnn.benchmark = find
-        out["weight_optimisation"] = side_run(dev, a.dtype, 3, 16 if a.res <= 512 else 2, 1, 1, a.res, a.ddim_steps, K, find=find)
+        out["weight_optimisation"] = guarded(lambda: side_run(dev, a.dtype, 3, 16 if a.res <= 512 else 2, 1, 1, a.res, a.ddim_steps, K, find=find))
         out["weight_optimisation"]["config"] = "BASELINE configs[2]: %dx%d, %d PLMS steps, %d objects, 3 epochs of per-step blend-weight optimisation" % (
             a.res, a.res, a.ddim_steps, K)
     _phase("side runs done")
