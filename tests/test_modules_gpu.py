@@ -494,6 +494,41 @@ def test_fp16_small_gradients_survive_with_loss_scaling():
     assert agree["no scaling"][0] <= a + 1e-6, agree
 
 
+def test_bench_step_images_match_single_prompt():
+    """The default bench step at FULL size (SD-v1-4-shaped UNet, fp16, NHWC trunk, 32 prompts per step through sample_batch + hipGraph:
+    the level-0 launches take the projection-fused head-pair kernel at 256 workgroups x 16 tiles, levels 1-2 / mid the LDS-resident
+    kernel with 8 / 8 / 4 waves) against the SAME prompts sampled one at a time (one image per launch: other kernel instantiations,
+    other GEMM / convolution algorithms). Images 0 and 31 after 4 PLMS steps (5 CFG UNet calls); stated tolerance: 2 % of max |x0|
+    per element, 1 % on average (measured 0.4 % / 0.35 %: 16-bit trunk, independent roundings in the two paths)."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, use_shipped_miopen_db
+    use_shipped_miopen_db(0)
+    dev, dt, I, K, S = torch.device("cuda", 0), torch.float16, 32, 2, 4
+    model = build_sd_v1(dev, dt, with_vae=False, init_weights=True, seed=0, channels_last=True)
+    sampler = PLMSSampler(model, opt_epochs=0, use_graph=True, save_images=False)
+    recs = load_prompts(64)[:I]
+    names = [(r["objects"] + ["object"] * K)[:K] for r in recs]
+    conds = [conditionings(model, r["prompt"], nm, dt) for r, nm in zip(recs, names)]
+    centres = [list(c) for c in DEFAULT_CENTRES[:K]]
+    x_T = torch.randn([1, 4, 64, 64], generator=torch.Generator(device=dev).manual_seed(1), device=dev)
+    sampler.sample_batch(S=S, shape=[4, 64, 64], conditionings=[c[1] for c in conds], unconditional_conditionings=[c[0] for c in conds],
+                         bboxs=[centres] * I, object_names=names, local_conditionings=[c[2] for c in conds],
+                         curr_texts=[r["prompt"] for r in recs], x_T=x_T.expand(I, -1, -1, -1), unconditional_guidance_scale=7.5, seed=1)
+    xb = sampler.last_result["x0"].float()
+    assert xb.shape == (I, 4, 64, 64) and torch.isfinite(xb).all()
+    for i in (0, I - 1):
+        uc, c, loc = conds[i]
+        sampler.sample(S=S, conditioning=c, batch_size=1, shape=[4, 64, 64], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=uc, eta=0.0, x_T=x_T, text_index=0, curr_text=recs[i]["prompt"], bboxs_curr=centres,
+                       seed=1, prompt_idx=i, object_names=names[i], local_conditionings=loc)
+        x1 = sampler.last_result["x0"].float()[0]
+        e_max = ((xb[i] - x1).abs().max() / x1.abs().max()).item()
+        e_mean = ((xb[i] - x1).abs().mean() / x1.abs().mean()).item()
+        print("image %d of the 32-prompt step vs the prompt alone: max %.4f mean %.4f (relative)" % (i, e_max, e_mean))
+        assert e_max < 0.02 and e_mean < 0.01, (i, e_max, e_mean)
+    assert (xb[0] - xb[I - 1]).abs().max() > 1e-3        # different prompts give different images
+
+
 def test_entry_point_script_end_to_end(tmp_path):
     """scripts/txt2img-mscoco.py on a 4-prompt dataset with a layout JSON: synthetic SD-v1 weights, fixed blend
     weights, 3 PLMS steps; one prompt alone + batches grouped by object count; PNGs named like the reference's
