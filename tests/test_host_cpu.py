@@ -406,3 +406,46 @@ def test_config1_trajectory_matches_reference():
     x0 = sampler.last_result["x0"].numpy()
     err = np.abs(x0 - g["x0"]).max() / np.abs(g["x0"]).max()
     assert err < 2e-3, err
+
+
+def test_calls_to_keep_is_sized_to_free_memory(monkeypatch):
+    """Per-call recomputation keeps the activations of as many trailing UNet calls as HBM holds (PLMSSampler._calls_to_keep):
+    none before the per-call size is known (then one, to measure it), afterwards (free - 4 calls - 24 GiB) / size, clamped."""
+    from ldm.models.diffusion.plms import PLMSSampler
+    s = PLMSSampler.__new__(PLMSSampler)
+    s.keep_calls = None
+    gib = 1 << 30
+    assert s._calls_to_keep(51, 16) == 0                                   # no GPU: nothing to size against
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda: (200 * gib, 288 * gib))
+    monkeypatch.setattr(torch.cuda, "memory_reserved", lambda: 30 * gib)
+    monkeypatch.setattr(torch.cuda, "memory_allocated", lambda: 10 * gib)
+    assert s._calls_to_keep(51, 16) == 1                                   # first tracked epoch: one call, to measure its size
+    s._call_bytes_per_image = gib                                          # 16 GiB per call at 16 prompts
+    assert s._calls_to_keep(51, 16) == (220 - 4 * 16 - 24) // 16           # free = 200 + cached 20 GiB
+    assert s._calls_to_keep(51, 1) == 51                                   # one prompt: everything fits -> no recomputation at all
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda: (40 * gib, 288 * gib))
+    assert s._calls_to_keep(51, 16) == 0
+    s.keep_calls = 5
+    assert s._calls_to_keep(51, 16) == 5 and s._calls_to_keep(3, 16) == 3
+    s.keep_calls = 0
+    assert s._calls_to_keep(51, 16) == 0
+
+
+def test_fp16_loss_scale_follows_the_loss_value():
+    """PLMSSampler._loss_scale: fp16 models scale the loss to [2^15, 2^16) with a power of two, other types do not scale; an explicit
+    loss_scale wins."""
+    import types
+    from ldm.models.diffusion.plms import PLMSSampler
+    s = PLMSSampler.__new__(PLMSSampler)
+    s.loss_scale = None
+    s.model = types.SimpleNamespace(model=torch.nn.Linear(2, 2).half())
+    for loss in (11.18, 174.9, 1.7e-4, 0.7):
+        sc = s._loss_scale(loss)
+        assert sc == 2.0 ** round(np.log2(sc)) and 2.0 ** 15 <= loss * sc < 2.0 ** 16, (loss, sc)
+    assert s._loss_scale(11.18) == 4096.0
+    assert s._loss_scale(0.0) == 1.0 and s._loss_scale(float("inf")) == 1.0 and s._loss_scale(1e9) == 1.0
+    s.model = types.SimpleNamespace(model=torch.nn.Linear(2, 2).bfloat16())
+    assert s._loss_scale(11.18) == 1.0
+    s.loss_scale = 128.0
+    assert s._loss_scale(11.18) == 128.0
