@@ -77,6 +77,10 @@ def parse():
                     help="weak (default): every rank samples --images-per-step prompts per step, whatever the world size. strong: a step "
                          "is the 64-prompt batch of BASELINE configs[3] split 64/world per rank (8 prompts per GPU per UNet call at 8 GPUs)")
     ap.add_argument("--cpu-calls", type=int, default=2, help="timed CPU UNet calls of the baseline sample")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="start the ranks, form the process group (RCCL on GPUs, gloo without), broadcast the frozen weights, check every "
+                         "rank holds rank 0's bytes, and stop BEFORE the first kernel of the sampler: the multi-rank plumbing of --gpus N, "
+                         "runnable on a CPU-only host (a reduced-width UNet there)")
     ap.add_argument("--opt-epochs", type=int, default=0,
                     help="weight-optimisation epochs (0 = fixed weights = BASELINE configs[1], the headline; 3 = configs[2] "
                          "with a CLIP stand-in loss, reported as a side measurement)")
@@ -250,14 +254,81 @@ def _phase(name):
     print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, name), file=sys.stderr, flush=True)
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a torch.distributed environment: start the N ranks here, one process per GPU, exactly as
+    the documented launch line does (torch.distributed.run, rendezvous on 127.0.0.1, a free port). The ranks inherit stdout, so the
+    ONE JSON line of rank 0 is this process's output; the exit code is non-zero if any rank failed (torchrun tears the others down)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver stack
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n_ranks)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_launch(a, rank, world, local):
+    """--dry-launch: everything a multi-rank run does before its first sampler kernel — process group, model skeleton on every rank,
+    weights on rank 0 only, the bucketed scatter + all-gather transfer, a checksum of what arrived, barrier, max-over-ranks — then
+    the JSON line and out. On a GPU box it moves the real SD-v1 weights over RCCL; without GPUs (the CPU test suite) a
+    reduced-width UNet over gloo."""
+    import torch.distributed as dist
+    from sta import parallel
+    from sta.pipeline import build_sd_v1
+    on_gpu = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    dt = (torch.float16 if a.dtype == "fp16" else torch.bfloat16) if on_gpu else torch.float32
+    over = None if on_gpu else dict(model_channels=32, num_heads=2, context_dim=64)
+    model = build_sd_v1(dev, dt, with_vae=on_gpu, init_weights=(rank == 0), seed=0, unet_overrides=over,
+                        channels_last=on_gpu and not a.nchw)
+    if rank != 0:                                   # whatever to_empty left behind: make "nothing arrived" visible
+        for t in model.state_dict().values():
+            if torch.is_tensor(t) and t.is_floating_point():
+                t.fill_(-7.0)
+    t0 = time.perf_counter()
+    nbytes = parallel.broadcast_module_(model, bucket_bytes=(512 << 20) if on_gpu else (1 << 20))
+    if on_gpu:
+        torch.cuda.synchronize()
+    t_bcast = time.perf_counter() - t0
+    # every rank must hold rank 0's bytes: compare a checksum of the whole state with rank 0's
+    cks = torch.stack([t.double().sum() for _, t in sorted(model.state_dict().items()) if torch.is_tensor(t)]).sum().reshape(1).to(dev)
+    mine = cks.clone()
+    if world > 1:
+        dist.broadcast(cks, src=0)
+    ok = bool(torch.isfinite(mine).all()) and bool((mine == cks).all())
+    oks = torch.tensor([1.0 if ok else 0.0], device=dev)
+    if world > 1:
+        dist.all_reduce(oks, op=dist.ReduceOp.MIN)
+    parallel.barrier()
+    el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    I = a.images_per_step
+    shard = [((0 * world + r) * I + i) % 64 for r in range(world) for i in range(min(I, 2))]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None, "scaling": a.scaling,
+                          "images_per_step": I, "global_batch": world * I, "weights_identical_on_every_rank": bool(oks.item() == 1.0),
+                          "weight_broadcast_bytes": nbytes, "weight_broadcast_s": round(t_bcast, 3), "elapsed_max_over_ranks_s": round(el, 3),
+                          "first_prompts_of_step0": shard, "device": str(dev.type)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not bool(oks.item() == 1.0):
+        raise SystemExit("dry launch: a rank does not hold rank 0's weights after the broadcast")
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(a.gpus))
     from sta import parallel
     rank, world, local = parallel.init_from_env()
     if world != a.gpus:
-        if a.gpus != 1 or world != 1:
-            raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)"
-                             % (a.gpus, world, a.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus %d`, which starts its own ranks, or "
+                         "torch.distributed.run --nproc-per-node %d)" % (a.gpus, world, a.gpus, a.gpus))
+    if a.dry_launch:
+        return dry_launch(a, rank, world, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)

@@ -95,3 +95,36 @@ def test_entry_point_cli_surface():
     a = p.parse_args(["--plms", "--ddim_steps", "50", "--prompt", "", "--scale", "7.5", "--H", "512", "--W", "512",
                       "--n_samples", "1", "--seed", "42", "--process_id", "3", "--precision", "autocast", "--fixed_code"])
     assert a.plms and a.ddim_steps == 50 and a.C == 4 and a.f == 8 and a.opt_epochs == 3 and a.dataset == "x.txt"
+
+
+def _run_bench(*flags):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+def test_bench_starts_its_own_ranks_dry_launch():
+    """`python bench.py --gpus 2` (the way the driver calls it: no torch.distributed environment) starts two ranks itself; with
+    --dry-launch they form the group (gloo here, RCCL on GPUs), move rank 0's weights to rank 1 in scatter + all-gather buckets,
+    verify them and stop before the first sampler kernel. ONE JSON line, rc 0."""
+    r, lines = _run_bench("--gpus", "2", "--dry-launch")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["n_gpus"] == 2 and out["backend"] == "gloo"
+    assert out["weights_identical_on_every_rank"] and out["weight_broadcast_bytes"] > 0
+    assert out["global_batch"] == 64 and out["first_prompts_of_step0"] == [0, 1, 32, 33]      # disjoint prompt slices per rank
+
+
+def test_bench_strong_scaling_split_and_world_mismatch():
+    r, lines = _run_bench("--gpus", "2", "--dry-launch", "--scaling", "strong")
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["scaling"] == "strong" and out["images_per_step"] == 32 and out["global_batch"] == 64      # 64 prompts / 2 ranks
+    # a torch.distributed environment that disagrees with --gpus is refused (non-zero rc, no JSON line)
+    import subprocess
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-launch"], env=env, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=1" in bad.stderr and not [ln for ln in bad.stdout.splitlines() if ln.startswith("{")]

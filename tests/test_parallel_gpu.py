@@ -82,3 +82,33 @@ def test_rccl_broadcast_two_ranks(tmp_path):
         pytest.skip("RCCL does not form a 2-rank communicator on one GPU here: %s" % [r.get("error") for r in res])
     assert all(r["ok"] for r in res), res
     assert all(r["ok"] for r in res) and res[0]["nbytes"] == res[1]["nbytes"] > 0 and res[0]["max"] == res[1]["max"] == 2.0
+
+
+def _bench(*flags, timeout=900):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), *flags], env=env, capture_output=True, text=True, timeout=timeout)
+    return r, [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_dry_launch_on_the_gpu():
+    """`python bench.py --gpus N --dry-launch` with the REAL SD-v1 weights: N = 2 over RCCL when the box has two GPUs (bench.py
+    starts its own ranks), N = 1 otherwise (the same code path minus the collectives)."""
+    n = 2 if torch.cuda.device_count() >= 2 else 1
+    r, lines = _bench("--gpus", str(n), "--dry-launch")
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["dry_launch"] and out["n_gpus"] == n and out["device"] == "cuda" and out["weights_identical_on_every_rank"]
+    if n == 2:
+        assert out["backend"] == "nccl" and out["weight_broadcast_bytes"] > 1.5e9      # UNet + VAE in 16 bit
+
+
+def test_bench_two_ranks_end_to_end():
+    """The whole N = 2 bench (weights over RCCL, per-rank MIOpen db copies, hipGraph capture in two processes, barrier + max over
+    ranks) at a small size; needs two GPUs."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (one rank per GPU)")
+    r, lines = _bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--images-per-step", "2", "--ddim_steps", "4", timeout=1500)
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["weight_broadcast_bytes"] > 1.5e9
