@@ -379,6 +379,94 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict_
 }
 
 // --------------------------------------------------------------------------------------------------
+// The same pass with y written in QUERY-FRAGMENT order — the layout sta_xattn_fwd_proj_qfrag consumes. y = norm2(x) at
+// SD-v1 level 0 has exactly one consumer, the projection-fused cross-attention kernel, whose MFMA B operand wants lane
+// (g, c) of a wave to hold 16 bytes of pixel c: read from row-major [R][C] that is 16 half-used 128-byte lines per load
+// instruction (the shape profiles/r03_vmem_shapes.txt prices at 1.5x the adjacent-lane one). Here the 16 rows of a pixel
+// group leave as C/32 fragments of 1 KiB: fragment s holds, at byte (16 g + c) * 16, channels 32 s + 8 g .. + 7 of row c —
+// a transpose of [16 rows][C/8 chunks] to [C/8 chunks][16 rows] in 16-byte units, (R/16) * (C/32) KiB in all (the same
+// bytes as row-major). One workgroup = one group of 16 rows, a wave takes 4 of them (same per-row arithmetic and lane
+// assignment as add_layernorm_kernel: bit-identical values); the chunks cross LDS (272-byte chunk stride: conflict-free
+// 16-byte writes and reads) so that the stores are 1-KiB contiguous per wave instruction.
+// --------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_qfrag_kernel(const T* __restrict__ x, const T* __restrict__ f,
+                                                                const T* __restrict__ bias, const T* __restrict__ gamma,
+                                                                const T* __restrict__ beta, T* s_out, T* __restrict__ y,
+                                                                long R, int C, float eps) {
+  using V8 = typename V8T<T>::type;
+  constexpr int CHUNK = 272;                              // LDS bytes per chunk: 16 rows x 16 B + 16 B of padding
+  __shared__ __attribute__((aligned(16))) char tile[64 * CHUNK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nvec = C >> 3;
+  const long row0 = (long)blockIdx.x * 16 + 4 * wv;
+  const bool on = lane < nvec;
+  float v[4][8];
+  float sum[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {                           // every load of the wave's four rows is issued before the first use
+    const long row = row0 + r;
+    V8 a = {}, b = {};
+    if (on) {
+      a = ((const V8*)(x + row * C))[lane];
+      if (f) b = ((const V8*)(f + row * C))[lane];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[r][e] = (float)a[e];
+    if (f) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[r][e] += (float)b[e];
+    }
+  }
+  V8 bs = {}, gm = {}, bt = {};
+  if (on) {
+    if (bias) bs = ((const V8*)bias)[lane];
+    gm = ((const V8*)gamma)[lane];
+    bt = ((const V8*)beta)[lane];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long row = row0 + r;
+    if (bias) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[r][e] += (float)bs[e];
+    }
+    if (s_out) {
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (T)v[r][e];
+        v[r][e] = (float)o[e];
+      }
+      if (on) ((V8*)(s_out + row * C))[lane] = o;
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t += v[r][e];
+    sum[r] = on ? t : 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float mean = wave_sum(sum[r]) / (float)C;
+    float q = 0.f;
+    if (on) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float dlt = v[r][e] - mean;
+        q += dlt * dlt;
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    V8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)((v[r][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+    if (on) *(V8*)(tile + lane * CHUNK + (4 * wv + r) * 16) = o;
+  }
+  __syncthreads();
+  V8* yo = (V8*)y + (size_t)blockIdx.x * nvec * 16;
+  for (int t = threadIdx.x; t < nvec * 16; t += 256) yo[t] = *(const V8*)(tile + (t >> 4) * CHUNK + (t & 15) * 16);
+}
+
+// --------------------------------------------------------------------------------------------------
 // y = a + b + bias[c] over [B][C][HW]
 // --------------------------------------------------------------------------------------------------
 template <typename T>
@@ -478,6 +566,24 @@ int sta_add_layernorm(const void* x, const void* f, const void* bias, const void
     hipLaunchKernelGGL(add_layernorm_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)f,
                        (const _Float16*)bias, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)s, (_Float16*)y, R, C, eps);
   return launched("add_layernorm");
+}
+
+int sta_add_layernorm_qfrag(const void* x, const void* f, const void* bias, const void* gamma, const void* beta, void* s,
+                            void* y, long R, int C, float eps, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!x || !gamma || !beta || !y) return sta_fail(STA_E_ARG, "null pointer");
+  if (R <= 0 || R % 16 || C <= 0 || C % 32 || C > 512)
+    return sta_fail(STA_E_ARG, "add_layernorm_qfrag: R=%ld C=%d (need R %% 16 == 0, C %% 32 == 0, C <= 512)", R, C);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const unsigned blocks = (unsigned)(R / 16);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(add_layernorm_qfrag_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)f,
+                       (const __bf16*)bias, (const __bf16*)gamma, (const __bf16*)beta, (__bf16*)s, (__bf16*)y, R, C, eps);
+  else
+    hipLaunchKernelGGL(add_layernorm_qfrag_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)f,
+                       (const _Float16*)bias, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)s, (_Float16*)y, R, C, eps);
+  return launched("add_layernorm_qfrag");
 }
 
 int sta_add_bias_nchw(const void* a, const void* b, const void* bias, void* y, int B, int C, int HW, int dtype,

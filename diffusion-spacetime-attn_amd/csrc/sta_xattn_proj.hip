@@ -388,9 +388,39 @@ int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed, int n_ctx
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_kv_proj launch: %s", hipGetErrorString(e));
 }
 
+// does a launch of this shape take the head-pair kernel (sta_xattn_proj3.hip)?
+static bool takes_pair_kernel(int n_img, int N, int C, int heads, int M, int K) {
+  const long pair_wgs = (long)((N + 127) / 128) * (heads / 2) * n_img;
+  return sta_p3::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2 && (pair_wgs >= 256 || g_sta_opt[STA_OPT_PROJ_PAIR] == 1);
+}
+
+static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                         const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
+                         int dtype, void* stream, bool qfrag);
+
+int sta_xattn_fwd_proj_qfrag_supported(int n_img, int N, int C, int heads, int M, int K) {
+  const int rc = n_img < 1 ? STA_E_ARG : check_proj_shape(N, C, heads, M, K);
+  g_sta_err[0] = 0;
+  return rc == STA_OK && N % 16 == 0 && takes_pair_kernel(n_img, N, C, heads, M, K);
+}
+
+int sta_xattn_fwd_proj_qfrag(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                             const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
+                             int dtype, void* stream) {
+  return fwd_proj_impl(y, packed_wq, packed_kv, mask, coef, out, n_img, N, C, heads, M, K, scale, dtype, stream, true);
+}
+
 int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                        const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
                        int dtype, void* stream) {
+  return fwd_proj_impl(y, packed_wq, packed_kv, mask, coef, out, n_img, N, C, heads, M, K, scale, dtype, stream, false);
+}
+
+}  // extern "C"
+
+static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                         const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
+                         int dtype, void* stream, bool qfrag) {
   g_sta_err[0] = 0;
   if (!y || !packed_wq || !packed_kv || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (n_img < 1 || n_img > 65535) return sta_fail(STA_E_ARG, "n_img=%d", n_img);
@@ -411,14 +441,12 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
   // Head pairs share one read of y where both heads' operands fit a CU (d = 40, C = 160 / 320, K <= 2: sta_xattn_proj3.hip)
   // and the launch still fills the chip with one pair workgroup per CU (level 0 at 32 / 16 images: 147 / 72 us against
   // 156 / 92 us one head per workgroup; a one-image launch has 128 pair workgroups and takes the one-head kernel).
-  const long pair_wgs = (long)((N + 127) / 128) * (heads / 2) * n_img;
-  if (sta_p3::eligible(C, heads, M, K) && g_sta_opt[STA_OPT_PROJ_PAIR] != 2 && (pair_wgs >= 256 || g_sta_opt[STA_OPT_PROJ_PAIR] == 1)) {
+  if (takes_pair_kernel(n_img, N, C, heads, M, K)) {
     const int ndt = (p.d + 15) / 16;
     const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
     const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
-    return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st);
+    return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st, qfrag);
   }
+  if (qfrag) return sta_fail(STA_E_UNSUP, "query-fragment order is read by the head-pair kernel only (sta_xattn_fwd_proj_qfrag_supported)");
   return dtype == STA_BF16 ? dispatch_proj<__bf16>(p, n_img, lds, st) : dispatch_proj<_Float16>(p, n_img, lds, st);
 }
-
-}  // extern "C"

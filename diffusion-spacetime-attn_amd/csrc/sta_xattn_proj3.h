@@ -30,6 +30,6 @@ inline size_t kv_bytes(int n_ctx, int heads) { return (size_t)n_ctx * heads * BL
 
 int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype, hipStream_t st);
 int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* mask, const float* coef, void* out, int n_img,
-            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st);
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag = false);
 }  // namespace sta_p3
 #endif

@@ -252,12 +252,20 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
 // line instead — lane (g, c) fetches row (c & 7), 16-byte slot g + 4 (c >> 3) of the line that holds k-steps 2m and 2m+1; two
 // such loads (rows 0..7, rows 8..15) and one DPP row_ror:8 move per dword hand every lane its own pixel's slots of both
 // k-steps. Same bytes and instruction count, half the lines. The ring then holds the whole row of the NEXT item.
-template <typename T, int NKC, bool YFULL>
+//
+// YL = 2 (query-fragment order, sta_xattn_fwd_proj_qfrag): y is not row-major at all. Its producer — the add + LayerNorm pass
+// of the same block (sta_add_layernorm_qfrag), whose only consumer at this level is this kernel — writes every 16-pixel group
+// as C/32 fragments of 1 KiB in B-operand lane order, so a load instruction is one fully coalesced KiB (8 whole lines, adjacent
+// lanes on adjacent bytes), there is no cross-lane hand-over, and an item's 2 x NKC fragments start at the row-major byte
+// offset of its first pixel. N % 16 == 0.
+template <typename T, int NKC, int YL>
 __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NWV = 8, TP = 16 * NWV;
-  constexpr int RING = YFULL ? NKC : 5;           // k-steps of y in flight per batch row
+  constexpr bool YFULL = YL == 1, YFRAG = YL == 2;
+  constexpr int RING = (YFULL || YFRAG) ? NKC : 5;           // k-steps of y in flight per batch row
+  constexpr unsigned YSTEP = YFRAG ? 1024u : 64u;            // bytes between consecutive k-steps of a lane's loads
   static_assert(NKC % RING == 0 && (!YFULL || NKC % 2 == 0), "k-steps per tile: a multiple of the ring depth; full-line loads pair them");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -315,6 +323,10 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   // descriptor's range: they read as zeros). Half-line shape: row c16, 16-byte slot g of a k-step. Full-line shape: two loads
   // per line pair — `half` 0: rows 0..7 of the item's 16 pixels, 1: rows 8..15 — lane (g, c) takes row (c & 7), slot g + 4 (c >> 3)
   auto voff_of = [&](int q, int half = 0) -> unsigned {
+    if constexpr (YFRAG) {      // fragment s of the item's group: byte offset of its first pixel's row + 1024 s + 16 lane
+      const int px0 = px0_of(q);
+      return (q < nitems && px0 < N) ? (unsigned)px0 * row_bytes + (unsigned)lane * 16u : 0xfffffff0u;
+    }
     const int px = px0_of(q) + (YFULL ? (c16 & 7) + 8 * half : c16);
     const unsigned slot = YFULL ? (unsigned)(g + 4 * (c16 >> 3)) : (unsigned)g;
     return (q < nitems && px < N) ? (unsigned)px * row_bytes + slot * 16u : 0xfffffff0u;
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
 #pragma unroll
   for (int j = 0; j < RING; ++j) {
     const unsigned vo = (YFULL && (j & 1)) ? voffh : voff;
-    const unsigned so = YFULL ? 128u * (unsigned)(j >> 1) : 64u * (unsigned)j;
+    const unsigned so = YFULL ? 128u * (unsigned)(j >> 1) : YSTEP * (unsigned)j;
     yr0[j] = srd_load16<V8>(y_srd, vo, so);
     yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
   }
@@ -423,7 +435,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
           // refill this ring slot with k-step s + RING: of this item, or of the next one (zeros past the last item)
           const bool wrap = s + RING >= NKC;              // compile time after unrolling
           const unsigned vo = wrap ? voffn : voff;
-          const unsigned so = 64u * (unsigned)(wrap ? s + RING - NKC : s + RING);
+          const unsigned so = YSTEP * (unsigned)(wrap ? s + RING - NKC : s + RING);
           yr0[j] = srd_load16<V8>(y_srd, vo, so);
           yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
         }
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   STA_T_END();
 }
 
-template <typename T, int NKC, bool YFULL>
+template <typename T, int NKC, int YL>
 int launch_p3(P3 p, int n_img, hipStream_t st) {
   constexpr int TP = 128;
   const int pairs = p.H / 2;
@@ -534,9 +546,9 @@ int launch_p3(P3 p, int n_img, hipStream_t st) {
   p.W = (p.tiles + p.iters - 1) / p.iters;
   const int lds = lds_bytes(p.C, p.K);
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YFULL>, 160 * 1024))
+  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YL>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj p3) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YFULL>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YL>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj p3 launch: %s", hipGetErrorString(e));
 }
@@ -562,13 +574,18 @@ int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C,
 }
 
 int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* mask, const float* coef, void* out, int n_img,
-            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st) {
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag) {
   P3 p{};
   p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv; p.mask = mask; p.coef = coef; p.out = out;
   p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.sl2e = sl2e;
-  // full-line y loads pair the k-steps: C = 320 (10 steps) takes them, C = 160 (5 steps) keeps the half-line shape
-  if (C == 320) return dtype == STA_BF16 ? launch_p3<__bf16, 10, true>(p, n_img, st) : launch_p3<_Float16, 10, true>(p, n_img, st);
-  return dtype == STA_BF16 ? launch_p3<__bf16, 5, false>(p, n_img, st) : launch_p3<_Float16, 5, false>(p, n_img, st);
+  if (qfrag) {      // y in query-fragment order (sta_add_layernorm_qfrag): 1-KiB coalesced loads, no hand-over
+    if (N % 16) return sta_fail(STA_E_UNSUP, "query-fragment order needs N %% 16 == 0 (N=%d)", N);
+    if (C == 320) return dtype == STA_BF16 ? launch_p3<__bf16, 10, 2>(p, n_img, st) : launch_p3<_Float16, 10, 2>(p, n_img, st);
+    return dtype == STA_BF16 ? launch_p3<__bf16, 5, 2>(p, n_img, st) : launch_p3<_Float16, 5, 2>(p, n_img, st);
+  }
+  // row-major y. Full-line loads pair the k-steps: C = 320 (10 steps) takes them, C = 160 (5 steps) keeps the half-line shape
+  if (C == 320) return dtype == STA_BF16 ? launch_p3<__bf16, 10, 1>(p, n_img, st) : launch_p3<_Float16, 10, 1>(p, n_img, st);
+  return dtype == STA_BF16 ? launch_p3<__bf16, 5, 0>(p, n_img, st) : launch_p3<_Float16, 5, 0>(p, n_img, st);
 }
 
 }  // namespace sta_p3

@@ -156,12 +156,13 @@ class _PromptCache:
     """What a block keeps per prompt for one (N, K) shape: the packed K/V image of the K+2 contexts
     and the disc masks. Buffers are allocated once per shape and refilled in place for later prompts,
     so a captured hipGraph that holds their addresses stays valid across prompts."""
-    __slots__ = ("version", "packed", "packed_proj", "mask", "centres")
+    __slots__ = ("version", "packed", "packed_proj", "qfrag", "mask", "centres")
 
     def __init__(self):
         self.version = -1
         self.packed = None
         self.packed_proj = None      # forward-only image for the projection-fused kernel (None: shape not taken)
+        self.qfrag = False           # that kernel reads norm2's output in query-fragment order (head-pair launches)
         self.mask = None
         self.centres = None
 
@@ -229,8 +230,9 @@ class BasicTransformerBlock(nn.Module):
             cache.packed = _ops.pack_kv(k, v, self.attn2.heads, out=cache.packed, n_img=n_img)
             if k.is_cuda and _ops.proj_supported(k.shape[2], self.attn2.heads, k.shape[1], K, N=n, n_img=n_img):
                 cache.packed_proj = _ops.pack_kv_proj(k, v, self.attn2.heads, out=cache.packed_proj, n_img=n_img)
+                cache.qfrag = _ops.proj_qfrag_supported(k.shape[2], self.attn2.heads, k.shape[1], K, n, n_img)
             else:
-                cache.packed_proj = None
+                cache.packed_proj, cache.qfrag = None, False
             if K:
                 m = torch.stack([_ops.disc_mask_bits(c, dim) for c in centres]).to(context.device)   # [I, N]
                 if cache.mask is None:
@@ -264,10 +266,14 @@ class BasicTransformerBlock(nn.Module):
             n1, n2, n3 = self.norm1, self.norm2, self.norm3
             s, y = _fused.add_layernorm(x, None, in_bias, n1.weight, n1.bias, n1.eps, store_sum=in_bias is not None)
             x = x if s is None else s
-            x, y = _fused.add_layernorm(x, self.attn1(y), None, n2.weight, n2.bias, n2.eps)
-            if cache.packed_proj is not None and not self.keep_maps:
+            fused_q = cache.packed_proj is not None and not self.keep_maps
+            # norm2's output has ONE consumer when to_q runs inside the attention kernel: the pass then writes it in the MFMA
+            # operand order that kernel loads (query-fragment order, 1-KiB coalesced loads) instead of row-major
+            qfrag = fused_q and cache.qfrag
+            x, y = _fused.add_layernorm(x, self.attn1(y), None, n2.weight, n2.bias, n2.eps, qfrag=qfrag)
+            if fused_q:
                 # to_q runs INSIDE the attention kernel: no [2I, N, C] query round trip through HBM
-                blended = _ops.xattn_forward_proj(y, self._wq_fragments(), cache.packed_proj, cache.mask, c, self.attn2.scale)
+                blended = _ops.xattn_forward_proj(y, self._wq_fragments(), cache.packed_proj, cache.mask, c, self.attn2.scale, qfrag=qfrag)
             else:
                 q = self.attn2.to_q(y)
                 self._keep_maps(q, c, cache)

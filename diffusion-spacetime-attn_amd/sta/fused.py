@@ -108,9 +108,20 @@ def geglu(h):
     return y
 
 
-def add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True):
-    """s = x + f + bias; returns (s, LayerNorm(s)); f / bias may be None; s is None if store_sum is False."""
+def add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True, qfrag=False):
+    """s = x + f + bias; returns (s, LayerNorm(s)); f / bias may be None; s is None if store_sum is False.
+    `qfrag`: y comes back in QUERY-FRAGMENT order (sta_add_layernorm_qfrag: same shape and bytes, 16-row groups as 1-KiB MFMA
+    operand fragments) for sta.ops.xattn_forward_proj(..., qfrag=True), its only legal consumer."""
     C = x.shape[-1]
+    if qfrag:
+        if C % 32 or C > 512 or (x.numel() // C) % 16:
+            raise ValueError("query-fragment order needs C %% 32 == 0, C <= 512 and a multiple of 16 rows, got %s" % (tuple(x.shape),))
+        s = torch.empty_like(x) if store_sum else None
+        y = torch.empty_like(x)
+        lib.check(lib.load().sta_add_layernorm_qfrag(x.data_ptr(), _ptr(f), _ptr(bias), ln_weight.data_ptr(), ln_bias.data_ptr(),
+                                                     _ptr(s), y.data_ptr(), x.numel() // C, C, float(eps), _DT[x.dtype], _stream()),
+                  "sta_add_layernorm_qfrag")
+        return s, y
     if C % 8 or C > 2048:
         t = x if f is None else x + f
         t = t if bias is None else t + bias

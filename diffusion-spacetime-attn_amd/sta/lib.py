@@ -50,6 +50,8 @@ SYMBOLS = {
     "sta_xattn_packed_kv_proj_bytes": (_sz, [_i, _i, _i]),
     "sta_xattn_pack_kv_proj": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sta_xattn_fwd_proj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "sta_xattn_fwd_proj_qfrag_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sta_xattn_fwd_proj_qfrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
@@ -58,6 +60,7 @@ SYMBOLS = {
     "sta_groupnorm_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "sta_geglu": (_i, [_vp, _vp, _l, _i, _i, _vp]),
     "sta_add_layernorm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
+    "sta_add_layernorm_qfrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     "sta_add_bias_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sta_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sta_groupnorm_silu_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),

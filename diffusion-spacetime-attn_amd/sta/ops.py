@@ -231,19 +231,45 @@ def pack_kv_proj(k, v, heads, out=None, n_img=1):
     return PackedKV(buf, n_ctx, heads, M, C, k.dtype, n_img)
 
 
-def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale):
+def proj_qfrag_supported(C, heads, M, K, N, n_img):
+    """Launches whose y the head-pair kernel reads in query-fragment order (sta_xattn_fwd_proj_qfrag_supported)."""
+    return bool(_lib.load().sta_xattn_fwd_proj_qfrag_supported(n_img, N, C, heads, M, K))
+
+
+def to_qfrag(y):
+    """Row-major [..., N, C] -> query-fragment order (same shape container): groups of 16 rows as C/32 fragments of 1 KiB, lane
+    16 g + c of fragment s = y[16 P + c, 32 s + 8 g .. + 7]. Host-side restatement of sta_add_layernorm_qfrag's layout for tests
+    and tools; the product gets the layout from the LayerNorm pass itself."""
+    C = y.shape[-1]
+    rows = y.numel() // C
+    if C % 32 or rows % 16:
+        raise ValueError("need C %% 32 == 0 and a multiple of 16 rows, got %s" % (tuple(y.shape),))
+    t = y.reshape(rows // 16, 16, C // 32, 4, 8)                 # [P, c, s, g, e]
+    return t.permute(0, 2, 3, 1, 4).contiguous().view(y.shape)    # [P, s, g, c, e]
+
+
+def from_qfrag(yf):
+    """Inverse of to_qfrag."""
+    C = yf.shape[-1]
+    rows = yf.numel() // C
+    t = yf.reshape(rows // 16, C // 32, 4, 16, 8)                # [P, s, g, c, e]
+    return t.permute(0, 3, 1, 2, 4).contiguous().view(yf.shape)
+
+
+def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False):
     """y [2I, N, C] = norm2(hidden) -> blended pre-projection output [2I, N, C]; the query projection happens inside
-    the attention kernel (no autograd). `packed` comes from pack_kv_proj, `wq_packed` from pack_wq."""
+    the attention kernel (no autograd). `packed` comes from pack_kv_proj, `wq_packed` from pack_wq. `qfrag`: y is in
+    query-fragment order (fused.add_layernorm(..., qfrag=True) / to_qfrag); only where proj_qfrag_supported."""
     I, N, C, K = _check_inputs(y, packed, mask, coef)
     L = _lib.load()
     y = y.contiguous()
     coef32 = coef.detach().to(torch.float32).contiguous() if K else None
     maskc = mask.contiguous() if K else None
     out = torch.empty_like(y)
+    fn, name = (L.sta_xattn_fwd_proj_qfrag, "sta_xattn_fwd_proj_qfrag") if qfrag else (L.sta_xattn_fwd_proj, "sta_xattn_fwd_proj")
     def launch():
-        _lib.check(L.sta_xattn_fwd_proj(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
-                                        out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y),
-                                        _stream(y)), "sta_xattn_fwd_proj")
+        _lib.check(fn(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
+                      out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y), _stream(y)), name)
     _logged("proj", I, N, C, K, launch)
     return out
 

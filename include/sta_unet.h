@@ -47,6 +47,17 @@ int sta_add_layernorm(const void* x, const void* f, const void* bias, const void
                       void* s, void* y, long R, int C, float eps, int dtype, void* stream);
 
 /*
+ * sta_add_layernorm with y in QUERY-FRAGMENT order, the private layout between norm2 and the projection-fused
+ * cross-attention (attention.py:279-281 -> :178): rows are taken in groups of 16 consecutive rows; group P, fragment
+ * s (C/32 per group, 1 KiB each) holds at byte offset (P * C/32 + s) * 1024 + (16 g + c) * 16 the 8 values
+ * y[16 P + c][32 s + 8 g .. + 7] — one fragment is one MFMA B operand of sta_xattn_fwd_proj_qfrag (lane = 16 g + c),
+ * fetched by one fully coalesced 1-KiB load. Same bytes in total as row-major. s (if not NULL) stays row-major.
+ * R % 16 == 0, C % 32 == 0, C <= 512. Values are bit-identical to sta_add_layernorm's.
+ */
+int sta_add_layernorm_qfrag(const void* x, const void* f, const void* bias, const void* gamma, const void* beta,
+                            void* s, void* y, long R, int C, float eps, int dtype, void* stream);
+
+/*
  * y = a + b + bias[c]  over NCHW tensors [B][C][HW] (HW % 8 == 0); b and/or bias may be NULL.
  * Replaces a convolution's separate bias pass plus the residual add that follows it
  * (`skip_connection(x) + out_layers(h)`, openaimodel.py ResBlock._forward; `proj_out(x) + x_in`, attention.py:346).

@@ -146,6 +146,21 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
                        const float* coef, void* out,
                        int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
 
+/*
+ * sta_xattn_fwd_proj reading y in QUERY-FRAGMENT order (include/sta_unet.h: sta_add_layernorm_qfrag writes it): y = norm2(hidden)
+ * has one consumer at SD-v1 level 0 — this launch (attention.py:279-281 feed :178) — so its layout is private to the pair
+ * of kernels, like the packed K / V / Wq images. Per 16-pixel group and batch row C/32 fragments of 1 KiB, fragment s holding
+ * at byte (16 g + c) * 16 the values y[16 P + c][32 s + 8 g .. + 7]: one load instruction of a wave is one coalesced KiB
+ * and IS the MFMA B operand (row-major y costs 16 half-used 128-byte lines per instruction, or a DPP hand-over).
+ * Results are bit-identical to sta_xattn_fwd_proj on the same values. Taken by the head-pair kernel only:
+ * sta_xattn_fwd_proj_qfrag_supported(n_img, N, C, heads, M, K) != 0 iff d = 40, C in {160, 320}, K <= 2, 64 < M <= 77,
+ * N % 16 == 0 and the launch has >= 256 pair workgroups.
+ */
+int sta_xattn_fwd_proj_qfrag_supported(int n_img, int N, int C, int heads, int M, int K);
+int sta_xattn_fwd_proj_qfrag(const void* y_frag, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                             const float* coef, void* out,
+                             int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+
 /* Bytes of fp32 workspace sta_xattn_bwd needs for the given shape (deterministic dcoef reduce). */
 size_t sta_xattn_bwd_workspace_bytes(int n_img, int N, int heads, int K);
 

@@ -77,6 +77,36 @@ def test_add_layernorm(R, C, dtype, with_f, with_bias):
     _close(y2, F.layer_norm(s_ref, (C,), w.float(), b.float(), 1e-5), dtype)
 
 
+@pytest.mark.parametrize("R,C", [(8192, 320), (4096, 160), (16, 512), (48, 32)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_f,with_bias,store", [(True, True, True), (True, False, True), (False, False, False)])
+def test_add_layernorm_query_fragment_order(R, C, dtype, with_f, with_bias, store):
+    """sta_add_layernorm_qfrag = sta_add_layernorm with y laid out as the projection-fused attention kernel's MFMA B operands
+    (16-row groups -> C/32 fragments of 1 KiB): bit-identical values at permuted addresses, s untouched; shapes outside its
+    limits are refused by the C-ABI."""
+    from sta import fused, lib, ops
+    g = torch.Generator().manual_seed(R + C)
+    x = torch.randn(R, C, generator=g).to(dtype).cuda()
+    f = (torch.randn(R, C, generator=g) * 0.5).to(dtype).cuda() if with_f else None
+    bias = (torch.randn(C, generator=g) * 0.3).to(dtype).cuda() if with_bias else None
+    w = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype).cuda()
+    b = (0.2 * torch.randn(C, generator=g)).to(dtype).cuda()
+    s0, y0 = fused.add_layernorm(x, f, bias, w, b, 1e-5, store_sum=store)
+    s1, y1 = fused.add_layernorm(x, f, bias, w, b, 1e-5, store_sum=store, qfrag=True)
+    torch.cuda.synchronize()
+    assert (s0 is None and s1 is None) or torch.equal(s0, s1)
+    assert torch.equal(ops.from_qfrag(y1), y0) and torch.equal(ops.to_qfrag(y0), y1)
+    # the layout, spelled out: group P, fragment s, lane 16 g + c holds y[16 P + c, 32 s + 8 g .. + 7]
+    flat = y1.reshape(-1)
+    for (P, sfr, gl, c) in [(0, 0, 0, 0), (R // 16 - 1, C // 32 - 1, 3, 15), (R // 32, 0, 2, 7)]:
+        off = ((P * (C // 32) + sfr) * 64 + 16 * gl + c) * 8
+        assert torch.equal(flat[off:off + 8], y0[16 * P + c, 32 * sfr + 8 * gl:32 * sfr + 8 * gl + 8])
+    L = lib.load()
+    for (r_bad, c_bad) in [(R + 8, C), (R, 16), (R, 544)]:
+        rc = L.sta_add_layernorm_qfrag(x.data_ptr(), 0, 0, w.data_ptr(), b.data_ptr(), 0, y1.data_ptr(), r_bad, c_bad, 1e-5, lib.STA_F16, 0)
+        assert rc == -1 and "qfrag" in lib.last_error()
+
+
 @pytest.mark.parametrize("B,C,H", [(2, 320, 64), (3, 1280, 8), (2, 64, 12)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_add_bias_nchw(B, C, H, dtype):

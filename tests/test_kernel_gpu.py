@@ -611,6 +611,7 @@ PAIR_SHAPES = [
     (4096, 320, 8, 0, 2, None, 77),       # no objects
     (1000, 160, 4, 2, 2, 3, 77),          # ragged N, C = 160 (5 k-steps), 2 head pairs, forced tile count
     (1000, 160, 4, 2, 2, 3, 66),          # fewer keys than rows stored: rows 66 .. 76 are zero, the bias masks them
+    (1008, 160, 4, 1, 2, 3, 77),          # N % 16 == 0 but not % 128: a partial last tile in query-fragment order, C = 160
     (9216, 320, 8, 2, 2, None, 77),       # 768^2 with 2 objects
 ]
 
@@ -635,7 +636,17 @@ def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
     if tiles is not None:
         lib.set_option(lib.OPT_STAGED_TILES, tiles)
     lib.set_option(lib.OPT_PROJ_PAIR, 1)
-    out = ops.xattn_forward_proj(y, ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I), mb, coef, scale)
+    wqf, kvp = ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I)
+    out = ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale)
+    # the same launch reading y in QUERY-FRAGMENT order (what sta_add_layernorm_qfrag writes for it): same MFMAs on the same
+    # values in the same order => bit-identical; N % 16 != 0 is refused
+    assert ops.proj_qfrag_supported(C, heads, M, K, N, I) == (N % 16 == 0)
+    if N % 16 == 0:
+        out_f = ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True)
+        assert torch.equal(out_f, out)
+    else:
+        with pytest.raises(RuntimeError, match="N % 16"):
+            ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale, qfrag=True)
     torch.cuda.synchronize()
     lib.set_option(lib.OPT_STAGED_TILES, 0)
     lib.set_option(lib.OPT_PROJ_PAIR, 0)

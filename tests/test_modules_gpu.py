@@ -50,13 +50,18 @@ def test_block_vs_reference_golden(name, dtype):
         assert rel.max() < (0.05 if dtype == torch.bfloat16 else 0.01), (coef.grad, g["dcoef"])
 
 
+@pytest.mark.parametrize("pair", [False, True])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_block_projection_fused_path_vs_reference_golden(dtype, monkeypatch):
+def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatch):
     """The inference block with to_q INSIDE the attention kernel (sta_xattn_fwd_proj; normally taken from 256 workgroup
-    tiles per launch, forced here) against the reference's fp32 block output, same tolerance as the unfused block."""
+    tiles per launch, forced here) against the reference's fp32 block output, same tolerance as the unfused block.
+    `pair`: the head-pair kernel forced as well — the block then hands norm2's output over in query-fragment order
+    (sta_add_layernorm_qfrag -> sta_xattn_fwd_proj_qfrag), the path of the bench's level-0 launches."""
     from ldm.modules.attention import BasicTransformerBlock
-    from sta import ops, prompt_state
+    from sta import lib, ops, prompt_state
     monkeypatch.setattr(ops, "PROJ_MIN_WORKGROUPS", 0)
+    if pair:
+        lib.set_option(lib.OPT_PROJ_PAIR, 1)          # reset after the test by conftest
     g = _load("block_d40.npz")
     dim, C, heads, K, seed = (int(g[k]) for k in ("dim", "C", "heads", "K", "seed"))
     x, context, local_ctx = gi.block_inputs(dim, C, K, seed, gi.load_uncond())
@@ -65,12 +70,13 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, monkeypatch):
     blk = blk.to("cuda", dtype)
     calls = []
     real = ops.xattn_forward_proj
-    monkeypatch.setattr(ops, "xattn_forward_proj", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    monkeypatch.setattr(ops, "xattn_forward_proj", lambda *a, **k: (calls.append(k), real(*a, **k))[1])
     prompt_state.begin_prompt([c.cuda() for c in local_ctx], first_timestep=981)
     with torch.no_grad():
         out = blk(x.cuda().to(dtype), context=context.cuda().to(dtype), time=torch.tensor(981),
                   coef=torch.from_numpy(g["coef"]).cuda(), bboxs_curr=[list(c) for c in g["centres"]])
     assert calls, "the projection-fused kernel was not taken"
+    assert [kw.get("qfrag", False) for kw in calls] == [pair], "query-fragment order is taken exactly by the head-pair launches"
     ref = g["out"]
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     err = np.abs(out.float().cpu().numpy() - ref)

@@ -66,6 +66,19 @@ def main():
         lib.set_option(lib.OPT_PROJ_PAIR, 0)
         return r
     arms["pair"] = pair                     # a head pair per workgroup (sta_xattn_proj3.hip)
+    if N % 16 == 0:
+        yq = ops.to_qfrag(y)
+        def pairq():
+            lib.set_option(lib.OPT_PROJ_PAIR, 1)
+            r = ops.xattn_forward_proj(yq, wqf, packed_p, mask, coef, scale, qfrag=True)
+            lib.set_option(lib.OPT_PROJ_PAIR, 0)
+            return r
+        arms["pairq"] = pairq               # the same kernel reading y in query-fragment order
+        from sta import fused
+        xs, fs = torch.randn_like(y), torch.randn_like(y)
+        lw, lb = torch.ones(C, device=dev, dtype=dt), torch.zeros(C, device=dev, dtype=dt)
+        arms["ln"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5)                     # the producer pass, row-major y
+        arms["lnq"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5, qfrag=True)        # ... query-fragment order
     if a.only:
         arms = {k_: f for k_, f in arms.items() if any(k_.startswith(o) for o in a.only.split(","))}
     res = {n: [] for n in arms}
