@@ -503,6 +503,11 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     } else
     head(std::integral_constant<int, 0>{}, qA0, qA1, au_A, ac_A);
     // head A's dims 0..31 of both batch rows: bytes 0..63 of the pair segment, 16 bytes per lane, no cross-lane exchange
+    if constexpr (ABL & 32) {      // EXPERIMENT: fragment-order store addresses (1-KiB contiguous per instruction)
+      const unsigned fb = (unsigned)px0_of(qcur) * row_bytes + (unsigned)lane * 16u;
+      __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, valid ? fb + 2048u * pr : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, valid ? fb + row1 + 2048u * pr : 0xfffffff0u, 0, 0);
+    } else
     if constexpr (ABL & 4) {
       asm volatile("" :: "v"(au_A.main), "v"(ac_A.main));
     } else {
@@ -511,6 +516,15 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     }
     if (it == 1) STA_T(4);
     if constexpr (!(ABL & 2)) head(std::integral_constant<int, 1>{}, qB0, qB1, au_B, ac_B);
+    if constexpr (ABL & 32) {
+      const unsigned fb = (unsigned)px0_of(qcur) * row_bytes + (unsigned)lane * 16u;
+      __builtin_amdgcn_raw_buffer_store_b128(au_B.main, o_srd, valid ? fb + 2048u * pr + 1024u : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_B.main, o_srd, valid ? fb + row1 + 2048u * pr + 1024u : 0xfffffff0u, 0, 0);
+      const u32x4 zu = {au_A.tail[0], au_A.tail[1], au_B.tail[0], au_B.tail[1]}, zc = {ac_A.tail[0], ac_A.tail[1], ac_B.tail[0], ac_B.tail[1]};
+      const unsigned zo = 8192u + 1024u * (pr >> 1) + 512u * (pr & 1);
+      __builtin_amdgcn_raw_buffer_store_b128(zu, o_srd, (valid && g < 2) ? fb + zo : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(zc, o_srd, (valid && g < 2) ? fb + row1 + zo : 0xfffffff0u, 0, 0);
+    } else
     if constexpr (ABL & 4) {
       asm volatile("" :: "v"(au_A.tail[0]), "v"(au_A.tail[1]), "v"(ac_A.tail[0]), "v"(ac_A.tail[1]), "v"(au_B.main), "v"(ac_B.main),
                    "v"(au_B.tail[0]), "v"(au_B.tail[1]), "v"(ac_B.tail[0]), "v"(ac_B.tail[1]));

@@ -55,10 +55,30 @@ class AttnBlock(nn.Module):
             n = _fused.groupnorm_silu_tracked(x, self.norm.weight, self.norm.bias, self.norm.num_groups, self.norm.eps, silu=False)
         else:
             n = self.norm(x)
-        q, k, v = (m(n).flatten(2).transpose(1, 2).unsqueeze(1) for m in (self.q, self.k, self.v))   # [b,1,hw,c]
-        # (PyTorch's SDPA here: the explicit batched matmul - softmax - matmul form faults inside the GEMM library at 32 images in bf16)
-        o = F.scaled_dot_product_attention(q, k, v, scale=c ** -0.5)
-        return x + self.proj_out(o.squeeze(1).transpose(1, 2).reshape(b, c, h, w))
+        q, k, v = (m(n).flatten(2).transpose(1, 2) for m in (self.q, self.k, self.v))   # [b, hw, c]
+        if not x.is_cuda:
+            o = F.scaled_dot_product_attention(q.unsqueeze(1), k.unsqueeze(1), v.unsqueeze(1), scale=c ** -0.5).squeeze(1)
+        else:
+            o = _attention_chunked(q, k, v, c ** -0.5)
+        return x + self.proj_out(o.transpose(1, 2).reshape(b, c, h, w))
+
+
+ATTN_CHUNK = 8      # images per batched GEMM of the decoder's attention
+
+
+def _attention_chunked(q, k, v, scale):
+    """softmax(scale q k^T) v for the decoder's one single-head attention (hw = 4096, c = 512; reference
+    ldm/modules/diffusionmodules/model.py AttnBlock: bmm - softmax - bmm) as plain library GEMMs with an fp32 softmax, a few
+    images at a time: no Triton-built SDPA kernel in the product path, and the batched GEMMs stay far below the size at which
+    the library faulted (one bmm over 32 images in bf16: tools/repro_bmm_fault.py). The scale rides on q so that the 16-bit
+    scores stay small; runs once per image, under autograd in the tracked epochs (P of a chunk is what backward keeps)."""
+    q = q * scale
+    outs = []
+    for i in range(0, q.shape[0], ATTN_CHUNK):
+        s = torch.bmm(q[i:i + ATTN_CHUNK], k[i:i + ATTN_CHUNK].transpose(1, 2))
+        p = torch.softmax(s.float(), dim=-1).to(q.dtype)
+        outs.append(torch.bmm(p, v[i:i + ATTN_CHUNK]))
+    return outs[0] if len(outs) == 1 else torch.cat(outs)
 
 
 class _Up(nn.Module):

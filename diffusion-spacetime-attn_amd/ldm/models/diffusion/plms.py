@@ -119,11 +119,17 @@ class _CallRecompute(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         x, coef = ctx.saved_tensors
-        x_ = x.detach().requires_grad_(True)
-        c_ = coef.detach().requires_grad_(True)
+        need_x, need_c = ctx.needs_input_grad[3], ctx.needs_input_grad[4]
+        x_ = x.detach().requires_grad_(need_x)          # the first call of a trajectory starts from x_T: no dx chain through conv_in
+        c_ = coef.detach().requires_grad_(need_c)
+        gx = gc = None
         with torch.enable_grad():
             out = ctx.slow_fn(x_, ctx.t, c_)
-            gx, gc = torch.autograd.grad(out, (x_, c_), grad_out.to(out.dtype), allow_unused=True)
+            wrt = [t for t, need in ((x_, need_x), (c_, need_c)) if need]
+            if wrt:
+                grads = list(torch.autograd.grad(out, wrt, grad_out.to(out.dtype), allow_unused=True))
+                gx = grads.pop(0) if need_x else None
+                gc = grads.pop(0) if need_c else None
         ctx.slow_fn = None
         return None, None, None, gx, gc
 
@@ -282,10 +288,14 @@ class PLMSSampler(object):
                             optimizer.zero_grad()
                             scale = self._loss_scale(float(loss.detach())) * scale_backoff
                             (loss * scale if scale != 1.0 else loss).backward()
-                            if scale != 1.0:
-                                if not bool(torch.isfinite(W.grad).all()) and scale_backoff > 2.0 ** -24:
+                            # checked whatever the scale (a backoff can land on exactly 1.0): Adam must never see a non-finite gradient
+                            if not bool(torch.isfinite(W.grad).all()):
+                                if scale_backoff > 2.0 ** -24:
                                     scale_backoff /= 256.0         # an fp16 overflow somewhere in the backward: same epoch again, smaller scale
                                     continue
+                                raise FloatingPointError("the gradient of the blend weights is not finite even with the loss scale backed "
+                                                         "off to %g: refusing to step the optimizer on it" % scale)
+                            if scale != 1.0:
                                 W.grad.div_(scale)
                             optimizer.step()
                             result.setdefault("losses", []).append(float(loss.detach()))
@@ -331,6 +341,7 @@ class PLMSSampler(object):
     def _trajectory(self, img, cond, uncond, scale, time_range, W, bboxs_curr, text_index, graph=False, call_recompute=False):
         """W: [K, S] for one image or [I, K, S] for a batch; column i of every image is used at step i."""
         S, b, device = len(time_range), img.shape[0], img.device
+        self._call_key = (tuple(img.shape[1:]), int(W.shape[-2]))     # what one call's saved activations depend on, per image
         keep = self._calls_to_keep(S + 1, b) if call_recompute and torch.is_grad_enabled() else 0
         if call_recompute and torch.is_grad_enabled():
             self.last_kept_calls = keep
@@ -356,8 +367,8 @@ class PLMSSampler(object):
         if self.keep_calls is not None:
             return min(int(self.keep_calls), n_calls)
         per_image = getattr(self, "_call_bytes_per_image", None)
-        if per_image is None:
-            return 1
+        if per_image is None or getattr(self, "_call_bytes_key", None) != self._call_key:
+            return 1                          # nothing measured for this (latent shape, object count) yet: keep one call and measure it
         est = per_image * batch
         free, _ = torch.cuda.mem_get_info()
         free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
@@ -395,6 +406,7 @@ class PLMSSampler(object):
                 out = unet(self.model.apply_model_extra, x, t, coef)
                 if x.is_cuda and k == n_calls - 1:
                     self._call_bytes_per_image = max(torch.cuda.memory_allocated() - before, 1) // b
+                    self._call_bytes_key = self._call_key
             elif call_recompute and torch.is_grad_enabled():
                 out = _CallRecompute.apply(lambda x_, t_, c_: unet(apply_fn, x_, t_, c_),
                                            lambda x_, t_, c_: unet(self.model.apply_model_extra, x_, t_, c_), t, x, coef)

@@ -92,8 +92,13 @@ class CrossAttention(nn.Module):
             # shapes the HIP kernels refuse (N < 64, N % 8, head dims above 160): the reference's own formulation,
             # einsum - softmax - einsum (attention.py:181-196), as plain library GEMMs with an fp32 softmax — no Triton-backed SDPA
             # kernel in the product. No BASELINE config reaches this on the GPU.
-            p = torch.softmax(torch.matmul(q, k.transpose(-1, -2)).float() * self.scale, dim=-1).to(q.dtype)
-            o = torch.matmul(p, v)
+            # The [rows, N, M] scores exist in fp32 for one slice of query rows at a time (<= 1 GiB), so memory does not grow as
+            # O(N^2) per (batch, head) beyond that slice; under autograd the 16-bit P of every slice is what backward keeps.
+            m = k.shape[2]
+            rows = max(1, min(n, (1 << 28) // max(1, b * h * m)))
+            o = torch.cat([torch.matmul(torch.softmax(torch.matmul(q[:, :, i:i + rows], k.transpose(-1, -2)).float() * self.scale, dim=-1).to(q.dtype), v)
+                           for i in range(0, n, rows)], dim=2) if rows < n else \
+                torch.matmul(torch.softmax(torch.matmul(q, k.transpose(-1, -2)).float() * self.scale, dim=-1).to(q.dtype), v)
         else:
             o = F.scaled_dot_product_attention(q, k, v, scale=self.scale)
         return self.to_out(o.transpose(1, 2).reshape(b, n, -1))

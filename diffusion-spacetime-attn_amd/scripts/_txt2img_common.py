@@ -60,8 +60,10 @@ def build_parser(default_dataset):
                         "encode_image/encode_text or (model, tokenize)), a CLIP .pt path, or 'synthetic' (frozen stand-in, for "
                         "timing the gradient path). Default: clip.load('ViT-B/32') as the reference (plms.py:24)")
     p.add_argument("--fp8", action="store_true",
-                   help="store the Linear weights of the transformer blocks as OCP e4m3 with per-channel scales and run their GEMMs "
-                        "on the fp8 MFMA path (BASELINE configs[4]); fixed blend weights only (--opt_epochs 0)")
+                   help="store the Linear weights of the transformer blocks as OCP e4m3 with per-channel scales (BASELINE configs[4]): half "
+                        "the weight memory; their GEMMs become hipBLASLt's row-scaled e4m3 GEMMs behind a per-row activation quantiser, "
+                        "which measures SLOWER than 16 bit here (a memory option, not a rate option: DESIGN.md section 5); fixed blend "
+                        "weights only (--opt_epochs 0)")
     p.add_argument("--clip_tokenizer", type=str, default=None, help="directory with the CLIP tokenizer files (with --ckpt)")
     p.add_argument("--synthetic", action="store_true", help="synthetic weights/text embeddings when no checkpoint is available")
     p.add_argument("--batch_prompts", type=int, default=1,

@@ -34,12 +34,17 @@ def use_shipped_miopen_db(rank=None):
     import shutil
     if rank is None:
         rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dst = os.path.join(os.path.expanduser(os.environ.get("XDG_CACHE_HOME", "~/.cache")), "sta", "miopen", "rank%d" % rank)
+    import socket
+    # one live copy per (host, local rank): ranks of different nodes sharing $HOME never append to the same files
+    dst = os.path.join(os.path.expanduser(os.environ.get("XDG_CACHE_HOME", "~/.cache")), "sta", "miopen",
+                       "%s-rank%d" % (socket.gethostname() or "host", rank))
     try:
         os.makedirs(dst, exist_ok=True)
         for name in os.listdir(USER_DB):
             if not os.path.exists(os.path.join(dst, name)):
-                shutil.copy(os.path.join(USER_DB, name), os.path.join(dst, name))
+                tmp = os.path.join(dst, ".%s.%d.tmp" % (name, os.getpid()))
+                shutil.copy(os.path.join(USER_DB, name), tmp)
+                os.replace(tmp, os.path.join(dst, name))          # atomic: a half-copied file never passes the exists() check
     except OSError:
         return None                      # read-only home: MIOpen searches as on a fresh box
     os.environ["MIOPEN_USER_DB_PATH"] = dst
