@@ -158,6 +158,7 @@ class PLMSSampler(object):
         self.use_graph, self.save_images, self.outdir = use_graph, save_images, outdir
         self.last_result = None
         self._graphs = None
+        self._call_key = None             # (latent shape, object count) of the trajectory being sampled: keys the measured activation size
 
     def register_buffer(self, name, attr):
         if isinstance(attr, np.ndarray):

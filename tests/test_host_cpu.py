@@ -413,7 +413,7 @@ def test_calls_to_keep_is_sized_to_free_memory(monkeypatch):
     none before the per-call size is known (then one, to measure it), afterwards (free - 4 calls - 24 GiB) / size, clamped."""
     from ldm.models.diffusion.plms import PLMSSampler
     s = PLMSSampler.__new__(PLMSSampler)
-    s.keep_calls = None
+    s.keep_calls, s._call_key = None, None
     gib = 1 << 30
     assert s._calls_to_keep(51, 16) == 0                                   # no GPU: nothing to size against
     monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
@@ -422,6 +422,9 @@ def test_calls_to_keep_is_sized_to_free_memory(monkeypatch):
     monkeypatch.setattr(torch.cuda, "memory_allocated", lambda: 10 * gib)
     assert s._calls_to_keep(51, 16) == 1                                   # first tracked epoch: one call, to measure its size
     s._call_bytes_per_image = gib                                          # 16 GiB per call at 16 prompts
+    s._call_key = ((4, 64, 64), 2)
+    assert s._calls_to_keep(51, 16) == 1                                   # measured for ANOTHER (latent shape, K): measure again
+    s._call_bytes_key = s._call_key
     assert s._calls_to_keep(51, 16) == (220 - 4 * 16 - 24) // 16           # free = 200 + cached 20 GiB
     assert s._calls_to_keep(51, 1) == 51                                   # one prompt: everything fits -> no recomputation at all
     monkeypatch.setattr(torch.cuda, "mem_get_info", lambda: (40 * gib, 288 * gib))
