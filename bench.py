@@ -76,7 +76,7 @@ def parse():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak (default): every rank samples --images-per-step prompts per step, whatever the world size. strong: a step "
                          "is the 64-prompt batch of BASELINE configs[3] split 64/world per rank (8 prompts per GPU per UNet call at 8 GPUs)")
-    ap.add_argument("--cpu-calls", type=int, default=2, help="timed CPU UNet calls of the baseline sample")
+    ap.add_argument("--cpu-calls", type=int, default=3, help="timed full-width CPU UNet calls of the baseline sample (median)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="start the ranks, form the process group (RCCL on GPUs, gloo without), broadcast the frozen weights, check every "
                          "rank holds rank 0's bytes, and stop BEFORE the first kernel of the sampler: the multi-rank plumbing of --gpus N, "
@@ -144,14 +144,58 @@ def measure_xattn(run_eager_call, n_calls=4, reps=20):
     return rows
 
 
+LEVELS = [("L0", 4096, 320), ("L1", 1024, 640), ("L2", 256, 1280), ("mid", 64, 1280)]      # SD-v1 at 512^2: (N, C) per UNet level, 8 heads
+
+
 def cpu_baseline(res, ddim_steps, K, n_calls):
-    """The reference's CPU path restated: fp32 torch modules with the ORACLE's fused op (oracle/ is the
-    checker; here it is the thing timed, as the contract allows). Sample: `n_calls` CFG UNet calls + one
-    VAE decode of the same 512x512 workload; images/s extrapolated to 51 calls + 1 decode."""
+    """The reference's CPU path restated ("Timing the reference CPU path"): fp32 torch modules with the
+    ORACLE's fused op on this box's host cores (oracle/ is the checker; here it is the thing timed, as the contract allows).
+      per_level_us  the fused op alone (K + 2 attentions + disc masks + blend, oracle.fused_xattn) at the four (N, C) level shapes
+                    of a 512x512 UNet call, one image: median of 5 runs after 1 warm-up — the CPU figure beside `roofline`'s kernel;
+      config1_s     BASELINE configs[0] END TO END, really run: one prompt, 64x64 latent, S = 10 PLMS steps (11 CFG UNet calls),
+                    K = 1 object, fixed weights, + the VAE decode, through the product's own sampler with the oracle op — on the
+                    REDUCED-WIDTH UNet of the golden fixtures (model_channels 64, same topology; the full-width run is ~2 min);
+      value         images/s of the bench workload (512x512, 50 steps, K objects, FULL width), EXTRAPOLATED from the median of
+                    `n_calls` full-width CFG UNet calls and one VAE decode to 51 calls + 1 decode."""
+    import statistics
+    from ldm.models.diffusion.plms import PLMSSampler
+    from oracle import xattn_oracle as orc
     from sta import prompt_state
     from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings
     from tests.cpu_backend import oracle_ops
     torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    # (1) the fused op per level
+    per_level, runs = {}, 5
+    with torch.no_grad():
+        for name, N, C in LEVELS:
+            dim = int(N ** 0.5)
+            q = torch.randn(2, N, C)
+            k, v = torch.randn(K + 2, M_KEYS, C) * 0.78, torch.randn(K + 2, M_KEYS, C)
+            mask = orc.disc_masks([list(cc) for cc in DEFAULT_CENTRES[:K]], dim).reshape(K, N) if K else torch.zeros(0, N, dtype=torch.bool)
+            coef = torch.full((K,), 5.0 / max(K, 1))
+            ts = []
+            for r in range(runs + 1):
+                t0 = time.perf_counter()
+                orc.fused_xattn(q, k, v, mask, coef, 8, (C // 8) ** -0.5)
+                ts.append(time.perf_counter() - t0)
+            per_level["%s_N%d_C%d" % (name, N, C)] = round(statistics.median(ts[1:]) * 1e6, 1)
+    # (2) configs[0] end to end on the reduced-width UNet
+    small = build_sd_v1("cpu", torch.float32, with_vae=True, init_weights=False, unet_overrides=dict(model_channels=64))
+    for p in small.parameters():
+        torch.nn.init.normal_(p, std=0.02)
+    uc, c, local = conditionings(small, "a bench prompt", ["obj0"])
+    x_T = torch.randn(1, 4, 64, 64)
+    sampler = PLMSSampler(small, opt_epochs=0, use_graph=False, save_images=False)
+    with oracle_ops(), torch.no_grad():
+        t0 = time.perf_counter()
+        sampler.sample(S=10, conditioning=c, batch_size=1, shape=[4, 64, 64], verbose=False, unconditional_guidance_scale=7.5,
+                       unconditional_conditioning=uc, eta=0.0, x_T=x_T, text_index=0, curr_text="a bench prompt",
+                       bboxs_curr=[list(DEFAULT_CENTRES[0])], seed=1, prompt_idx=0, object_names=["obj0"], local_conditionings=local)
+        config1_s = time.perf_counter() - t0
+    assert torch.isfinite(sampler.last_result["x0"]).all()
+    del small, sampler
+    # (3) the bench workload at full width: a bounded sample, extrapolated
     model = build_sd_v1("cpu", torch.float32, with_vae=True, init_weights=False)
     for p in model.parameters():          # cheap init (values do not change the timing)
         torch.nn.init.normal_(p, std=0.02)
@@ -165,20 +209,117 @@ def cpu_baseline(res, ddim_steps, K, n_calls):
         prompt_state.begin_prompt(local, first_timestep=981)
         c_in = torch.cat([uc, c])
         model.apply_model_extra(x, 0, t, c_in, coef=coef, bboxs_curr=centres)           # warm-up (allocator, oneDNN)
-        t0 = time.perf_counter()
+        calls = []
         for _ in range(n_calls):
+            t0 = time.perf_counter()
             model.apply_model_extra(x, 0, t, c_in, coef=coef, bboxs_curr=centres)
-        t_call = (time.perf_counter() - t0) / n_calls
+            calls.append(time.perf_counter() - t0)
+        t_call = statistics.median(calls)
         t0 = time.perf_counter()
         model.decode_first_stage(x[:1])
         t_dec = time.perf_counter() - t0
     n_unet = ddim_steps + 1
-    return dict(value=1.0 / (n_unet * t_call + t_dec), unit="images/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d CFG UNet calls (%.2f s each) + 1 VAE decode (%.2f s) at %dx%d, fp32 torch + oracle op; "
-                       "extrapolated to %d calls + 1 decode per image" % (n_calls, t_call, t_dec, res, res, n_unet))
+    return dict(value=1.0 / (n_unet * t_call + t_dec), unit="images/s", cores=cores, kind="port", extrapolated=True,
+                sample="median of %d full-width CFG UNet calls (%.2f s) + 1 VAE decode (%.2f s) at %dx%d, fp32 torch + oracle op, after 1 "
+                       "warm-up call; EXTRAPOLATED to %d calls + 1 decode per image" % (n_calls, t_call, t_dec, res, res, n_unet),
+                unet_call_s=[round(x_, 3) for x_ in calls], vae_decode_s=round(t_dec, 3),
+                per_level_us=per_level, per_level_what="oracle fused op (K = %d: %d attentions + disc masks + blend), one image, fp32, median of %d "
+                                                       "runs after 1 warm-up" % (K, K + 2, runs), runs=runs,
+                config1_s=round(config1_s, 2),
+                config1_what="BASELINE configs[0] end to end, really run: 1 prompt, 64x64 latent, S = 10 PLMS steps (11 CFG UNet calls), K = 1, "
+                             "fixed weights, + full VAE decode; REDUCED-width UNet (model_channels 64, the golden fixtures' topology), fp32")
 
 
-def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps, K, checkpoint="auto", find=True):
+def source_sha(names=("sta_xattn_proj3.hip", "sta_xattn_proj3.h", "sta_xattn_dev.h", "sta_xattn_proj.hip", "sta_xattn.hip")):
+    """sha256 over the kernel sources a committed counter measurement belongs to (profiles/xattn_fwd_hbm_traffic.json keeps the
+    hash it was taken at; a measurement of an older kernel is refused instead of being reported as this one's)."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(PKG, "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def roofline_leg(model, dev, dt, dtype_name, I, K, lat, rec, centres):
+    """`roofline` of the JSON line: per-launch times of the cross-attention forward kernels on the tensors of real CFG UNet
+    calls of `model` (measure_xattn), the dominant launch against the HBM and MFMA peaks, the 16-launch aggregate beside it."""
+    from sta import prompt_state
+    from sta.pipeline import conditionings
+    names = (rec["objects"] + ["object"] * K)[:K]
+    uc, c, local_c = conditionings(model, rec["prompt"], names, dt)
+    pair = lambda u, v: torch.stack([u, v], dim=1).reshape(2 * I, *u.shape[1:])
+    c_in = pair(uc.expand(I, -1, -1), c.expand(I, -1, -1)).contiguous()
+    x_in = torch.randn(2 * I, 4, lat, lat, device=dev)
+    t_in = torch.full((2 * I,), 981, device=dev, dtype=torch.long)
+    coef = torch.full((I, K), 5.0 / max(K, 1), device=dev) if I > 1 else torch.full((K,), 5.0 / max(K, 1), device=dev)
+    boxes = [centres] * I if I > 1 else centres
+    prompt_state.begin_prompt([local_c] * I if I > 1 else local_c, first_timestep=981)
+
+    def run_eager_call():
+        with torch.no_grad():
+            model.apply_model_extra(x_in, 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
+
+    rows = measure_xattn(run_eager_call)
+    by_shape = {}
+    for r in rows:
+        by_shape.setdefault((r["kind"], r["N"], r["C"]), []).append(r)
+    # the dominant kernel = the launch shape with the largest share of the cross-attention time of a UNet call
+    dom = max(by_shape, key=lambda k_: sum(r["us"] for r in by_shape[k_]))
+    d_us = sum(r["us"] for r in by_shape[dom]) / len(by_shape[dom])
+    d_flops, d_bytes = by_shape[dom][0]["flops"], by_shape[dom][0]["bytes"]
+    t_hbm, t_mfma = d_bytes / (HBM_PEAK_GBS * 1e3), d_flops / (MFMA_PEAK_TFLOPS * 1e6)      # us at either peak
+    all_us, all_bytes, all_flops = (sum(r[k_] for r in rows) for k_ in ("us", "bytes", "flops"))
+    # which projection-fused kernel the library dispatches (csrc/sta_xattn_proj.hip): a head pair per workgroup when two
+    # heads' compact operand images fit one CU's LDS (d = 40, K <= 2) and the launch has >= 256 pair workgroups; it then reads
+    # norm2's output in query-fragment order (sta_add_layernorm_qfrag -> sta_xattn_fwd_proj_qfrag)
+    pair_k = dom[2] == 320 and K <= 2 and (dom[1] // 128) * 4 * I >= 256
+    # HBM-side traffic: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/pmc_traffic_kernel.py), committed per kernel, shape,
+    # images per launch AND the hash of the kernel sources they were taken at — a measurement of an older kernel is not reported
+    traffic, traffic_note = None, "no committed PMC measurement for this launch"
+    pmc = os.path.join(REPO, "profiles", "xattn_fwd_hbm_traffic.json")
+    if os.path.exists(pmc):
+        ent = json.load(open(pmc)).get("by_kernel", {}).get("%s_N%d_C%d_I%d" % (dom + (I,)) + ("" if dtype_name == "fp16" else "_" + dtype_name))
+        if ent and ent.get("source_sha") == source_sha() and ent.get("dtype", "fp16") == dtype_name:
+            traffic, traffic_note = ent["bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, kernel sources %s" % ent["source_sha"]
+        elif ent:
+            traffic_note = "the committed PMC measurement belongs to other kernel sources / dtype (%s, %s): refused as stale" % (ent.get("source_sha"), ent.get("dtype", "fp16"))
+    kname = {"proj": ("xattn_fwd_proj_p3_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, a head pair per workgroup, y in query-fragment order)" if pair_k else
+                      "xattn_fwd_proj_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, one head per workgroup)"),
+             "attn": "xattn_fwd{,_staged}_kernel (QK^T + softmax + disc mask + blend + PV)"}[dom[0]]
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    roof = {
+        "bound": bound,
+        "achieved": d_bytes / d_us / 1e3 if bound == "hbm" else d_flops / d_us / 1e6,
+        "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+        "frac": max(t_hbm, t_mfma) / d_us, "traffic": traffic, "traffic_note": traffic_note, "dtype": dtype_name,
+        "kernel": "%s, N=%d C=%d, %d image(s) per launch, %d of the %d launches of a UNet call (%.0f %% of their time)"
+                  % (kname, dom[1], dom[2], I, len(by_shape[dom]), len(rows), 100.0 * d_us * len(by_shape[dom]) / all_us),
+        "bytes_per_launch": d_bytes, "flops_per_launch": d_flops, "avg_launch_us": d_us,
+        "flop_per_byte": d_flops / d_bytes, "ridge_flop_per_byte": MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS,
+        "hbm_gbps": d_bytes / d_us / 1e3, "hbm_frac": t_hbm / d_us, "mfma_tflops": d_flops / d_us / 1e6, "mfma_frac": t_mfma / d_us,
+        "how": "in situ: 4 real eager CFG UNet calls, one HIP-event pair per launch on the launch stream, RAW event times "
+               "(an empty pair measures ~4.6 us here; nothing subtracted)",
+        "warm_launch_us": sum(r["warm_us"] for r in by_shape[dom]) / len(by_shape[dom]),
+        "warm_how": "the same launches re-issued 20x back to back between one event pair. NOT comparable with `in situ` below level 0: a level-1 "
+                    "launch touches 168 MB (q + out), which stays resident in the 256 MiB Infinity Cache between repetitions, so warm times are "
+                    "cache-resident times; in situ the same bytes come from HBM behind the to_q GEMM (profiles/r04_insitu_vs_warm.md)",
+        "all_launches": {"n": len(rows), "sum_us": all_us, "hbm_gbps": all_bytes / all_us / 1e3, "hbm_frac": all_bytes / all_us / 1e3 / HBM_PEAK_GBS,
+                         "mfma_tflops": all_flops / all_us / 1e6, "mfma_frac": all_flops / all_us / 1e6 / MFMA_PEAK_TFLOPS},
+        "per_shape_us": {"%s_N%d_C%d" % k_: round(sum(r["us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])},
+        "per_shape_warm_us": {"%s_N%d_C%d" % k_: round(sum(r["warm_us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])}}
+    prof = os.path.join(REPO, "profiles", "r04_bench_kernel_stats.csv")
+    if os.path.exists(prof) and dtype_name == "fp16":      # rocprofv3 --kernel-trace summary of this command, committed: the cross-check
+        import csv
+        want = "xattn_fwd_proj" if dom[0] == "proj" else "xattn_fwd_staged"      # xattn_fwd_proj_p3_kernel / xattn_fwd_proj_kernel
+        hit = [r for r in csv.DictReader(open(prof)) if want in r["kernel"]]
+        if hit:
+            best = max(hit, key=lambda r: float(r["total_ns"]))
+            roof["rocprof_avg_us_committed"] = float(best["avg_ns"]) / 1e3
+    return roof
+
+
+def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps, K, checkpoint="auto", find=True, roofline=False):
     """A bounded side measurement on rank 0 after the headline run: the same workload with another 16-bit type, or
     BASELINE configs[2] (3 weight-optimisation epochs: two tracked trajectories with backward + one fixed-weight one).
     Builds its own model, reports images/s over `steps` timed steps after `warmup` untimed ones."""
@@ -231,6 +372,8 @@ def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps
     assert torch.isfinite(r["x0"]).all()
     out = {"value": steps * images / el, "unit": "images/s", "dtype": dtype_name, "images_per_step": images, "steps": steps,
            "warmup": warmup, "ms_per_step": 1e3 * el / steps}
+    if roofline:
+        out["roofline"] = roofline_leg(model, dev, dt, dtype_name, images, K, lat, prompts[0], centres)
     if opt_epochs:
         w0 = sampler.weight_init / max(K, 1)
         moved = float((r["W"] - w0).abs().max()) if K else 0.0
@@ -425,70 +568,7 @@ def main():
                    "peak_hbm_gib": round(peak_gb, 1), **({"recompute": ckpt_mode} if a.opt_epochs > 1 else {})},
     }
     if not a.no_roofline:
-        # per-launch times of the cross-attention forward kernels on the tensors of a real CFG UNet call
-        from sta import prompt_state
-        rec = prompts[mine(0)[0]]
-        names = (rec["objects"] + ["object"] * K)[:K]
-        uc, c, local_c = conditionings(model, rec["prompt"], names, dt)
-        pair = lambda u, v: torch.stack([u, v], dim=1).reshape(2 * I, *u.shape[1:])
-        c_in = pair(uc.expand(I, -1, -1), c.expand(I, -1, -1)).contiguous()
-        x_in = torch.randn(2 * I, 4, lat, lat, device=dev)
-        t_in = torch.full((2 * I,), 981, device=dev, dtype=torch.long)
-        coef = torch.full((I, K), 5.0 / max(K, 1), device=dev) if I > 1 else torch.full((K,), 5.0 / max(K, 1), device=dev)
-        boxes = [centres] * I if I > 1 else centres
-        prompt_state.begin_prompt([local_c] * I if I > 1 else local_c, first_timestep=981)
-
-        def run_eager_call():
-            with torch.no_grad():
-                model.apply_model_extra(x_in, 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
-
-        rows = measure_xattn(run_eager_call)
-        by_shape = {}
-        for r in rows:
-            by_shape.setdefault((r["kind"], r["N"], r["C"]), []).append(r)
-        # the dominant kernel = the launch shape with the largest share of the cross-attention time of a UNet call
-        dom = max(by_shape, key=lambda k_: sum(r["us"] for r in by_shape[k_]))
-        d_us = sum(r["us"] for r in by_shape[dom]) / len(by_shape[dom])
-        d_flops, d_bytes = by_shape[dom][0]["flops"], by_shape[dom][0]["bytes"]
-        t_hbm, t_mfma = d_bytes / (HBM_PEAK_GBS * 1e3), d_flops / (MFMA_PEAK_TFLOPS * 1e6)      # us at either peak
-        all_us, all_bytes, all_flops = (sum(r[k_] for r in rows) for k_ in ("us", "bytes", "flops"))
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "xattn_fwd_hbm_traffic.json")
-        if os.path.exists(pmc):      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, committed per kernel and images-per-launch
-            traffic = json.load(open(pmc)).get("by_kernel", {}).get("%s_N%d_C%d_I%d" % (dom + (I,)), {}).get("bytes_per_launch")
-        # which projection-fused kernel the library dispatches (csrc/sta_xattn_proj.hip): a head pair per workgroup when two
-        # heads' compact operand images fit one CU's LDS (d = 40, K <= 2) and the launch has >= 256 pair workgroups
-        pair = dom[2] == 320 and K <= 2 and (dom[1] // 128) * 4 * I >= 256
-        kname = {"proj": ("xattn_fwd_proj_p3_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, a head pair per workgroup)" if pair else
-                          "xattn_fwd_proj_kernel (to_q GEMM + QK^T + softmax + disc mask + blend + PV in one launch, one head per workgroup)"),
-                 "attn": "xattn_fwd{,_staged}_kernel (QK^T + softmax + disc mask + blend + PV)"}[dom[0]]
-        bound = "hbm" if t_hbm >= t_mfma else "mfma"
-        out["roofline"] = {
-            "bound": bound,
-            "achieved": d_bytes / d_us / 1e3 if bound == "hbm" else d_flops / d_us / 1e6,
-            "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
-            "frac": max(t_hbm, t_mfma) / d_us, "traffic": traffic,
-            "kernel": "%s, N=%d C=%d, %d image(s) per launch, %d of the %d launches of a UNet call (%.0f %% of their time)"
-                      % (kname, dom[1], dom[2], I, len(by_shape[dom]), len(rows), 100.0 * d_us * len(by_shape[dom]) / all_us),
-            "bytes_per_launch": d_bytes, "flops_per_launch": d_flops, "avg_launch_us": d_us,
-            "flop_per_byte": d_flops / d_bytes, "ridge_flop_per_byte": MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS,
-            "hbm_gbps": d_bytes / d_us / 1e3, "hbm_frac": t_hbm / d_us, "mfma_tflops": d_flops / d_us / 1e6, "mfma_frac": t_mfma / d_us,
-            "how": "in situ: 4 real eager CFG UNet calls, one HIP-event pair per launch on the launch stream, RAW event times "
-                   "(an empty pair measures ~4.6 us here; nothing subtracted)",
-            "warm_launch_us": sum(r["warm_us"] for r in by_shape[dom]) / len(by_shape[dom]),
-            "warm_how": "the same launches re-issued 20x back to back between one event pair (operands resident on chip)",
-            "all_launches": {"n": len(rows), "sum_us": all_us, "hbm_gbps": all_bytes / all_us / 1e3, "hbm_frac": all_bytes / all_us / 1e3 / HBM_PEAK_GBS,
-                             "mfma_tflops": all_flops / all_us / 1e6, "mfma_frac": all_flops / all_us / 1e6 / MFMA_PEAK_TFLOPS},
-            "per_shape_us": {"%s_N%d_C%d" % k_: round(sum(r["us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])},
-            "per_shape_warm_us": {"%s_N%d_C%d" % k_: round(sum(r["warm_us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])}}
-        prof = os.path.join(REPO, "profiles", "r03_bench_kernel_stats.csv")
-        if os.path.exists(prof):      # rocprofv3 --kernel-trace summary of this command, committed: the cross-check
-            import csv
-            want = "xattn_fwd_proj" if dom[0] == "proj" else "xattn_fwd_staged"      # xattn_fwd_proj_p3_kernel / xattn_fwd_proj_kernel
-            hit = [r for r in csv.DictReader(open(prof)) if want in r["kernel"]]
-            if hit:
-                best = max(hit, key=lambda r: float(r["total_ns"]))
-                out["roofline"]["rocprof_avg_us_committed"] = float(best["avg_ns"]) / 1e3
+        out["roofline"] = roofline_leg(model, dev, dt, a.dtype, I, K, lat, prompts[mine(0)[0]], centres)
     _phase("roofline leg done")
     if world == 1 and not a.no_side_runs and a.opt_epochs == 0:
         # reported beside the headline, never part of `value`: the other 16-bit type, and BASELINE configs[2]
@@ -499,7 +579,9 @@ def main():
                 torch.cuda.empty_cache()
                 return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if not a.no_other_dtype:
-            out["other_dtype"] = guarded(lambda: side_run(dev, "bf16" if a.dtype == "fp16" else "fp16", 0, I, 1, 1, a.res, a.ddim_steps, K))
+            # the same workload in the other 16-bit type on an equal footing: the headline's steps and warm-up, its own roofline block
+            out["other_dtype"] = guarded(lambda: side_run(dev, "bf16" if a.dtype == "fp16" else "fp16", 0, I, a.steps, a.warmup, a.res, a.ddim_steps, K,
+                                                          roofline=not a.no_roofline))
         # MIOpen's per-shape solver search for the backward convolutions of the UNet and the VAE decoder costs ~10 min on a
         # fresh box; the shipped user find-db (sta/data/miopen_userdb) holds them for fp16 at 512^2, other cases run in
         # immediate mode (no search, slower solvers)

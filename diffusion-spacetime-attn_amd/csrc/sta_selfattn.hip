@@ -58,15 +58,19 @@ __device__ __forceinline__ float bfly_sum(float x) {
 // 2.5 instead of 3.5 vector instructions per score in a loop whose time is the vector pipe's.
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }   // one v_max3_f32
 
-template <typename T, int NKS, int NDT, int QT, bool SUMROW, bool PRE>
-__global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
+// NW waves per workgroup. NW = 4 (QT query tiles of 16 per wave): the general kernel. NW = 8 with QT = 1: the same loop sized for FOUR
+// waves per SIMD (<= 128 registers; two 512-thread workgroups per CU share each K / V^T block among 128 queries as before) —
+// the loop is bound by vector-issue slots (a 64-key block needs ~730 issue-port cycles per 32 queries against ~450 of matrix
+// pipe, profiles/r03_selfattn_32x32.md) and three waves per SIMD left the port a third idle.
+template <typename T, int NKS, int NDT, int QT, bool SUMROW, bool PRE, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void selfattn_fwd_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NKF = 4 * NKS;            // K fragments per block: 4 key tiles x NKS head-dim steps
   constexpr int NVF = 2 * NDT;            // V^T fragments per block: 2 key steps x NDT head-dim tiles
   constexpr int NFR = NKF + NVF;
-  constexpr int PER = (NFR + 3) / 4;      // LDS-DMA instructions per wave per block (same for every wave: the
-  constexpr int NFRP = 4 * PER;           //   counted vmcnt below needs it) -> NFRP - NFR padding copies
+  constexpr int PER = (NFR + NW - 1) / NW; // LDS-DMA instructions per wave per block (same for every wave: the
+  constexpr int NFRP = NW * PER;          //   counted vmcnt below needs it) -> NFRP - NFR padding copies
   constexpr int BB = NFRP * FRAG;         // LDS bytes per block buffer (padding copies land in its tail)
   constexpr int DEPTH = 3;                // blocks resident in LDS: compute blk while blk+1, blk+2 are in flight
   const int lane = threadIdx.x & 63;
@@ -76,7 +80,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   const int b = blockIdx.y;
   int tile, h;
   if (p.H == 8) { tile = blockIdx.x >> 3; h = blockIdx.x & 7; } else { tile = blockIdx.x / p.H; h = blockIdx.x % p.H; }
-  const int px0 = (tile * 4 + wv) * 16 * QT;
+  const int px0 = (tile * NW + wv) * 16 * QT;
 
   const T* qb = (const T*)p.q + (size_t)b * N * p.ldq + h * d;
   const T* kb = (const T*)p.k + (size_t)b * N * p.ldk + h * d;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
   int step[PER];                           // bytes per block
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int f = wv + 4 * i;
+    const int f = wv + NW * i;
     const int fs = f < NFR ? f : 0;       // padding copy: re-read fragment 0 into the unused tail slot
     if (fs < NKF) {
       const int Tt = fs / NKS, s = fs - Tt * NKS;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
     if constexpr (SUMROW) {
-      const int f = wv + 4 * i, f2 = f - NKF;
+      const int f = wv + NW * i, f2 = f - NKF;
       const bool ones_frag = f < NFR && f2 >= 0 && f2 % NDT == NDT - 1;
       if (ones_frag && 16 * (NDT - 1) + c16 == d) {
         keep &= ~(1u << i);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
       for (int i = 0; i < PER; ++i) {
         if (keep >> i & 1)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                           (__attribute__((address_space(3))) void*)(dst + (wv + 4 * i) * FRAG), 16, 0, 0);
+                                           (__attribute__((address_space(3))) void*)(dst + (wv + NW * i) * FRAG), 16, 0, 0);
         src[i] += step[i];
       }
       return;
@@ -152,7 +156,7 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
     const int k0 = blk * KB;               // partial last block (N % 64 != 0): clamp every key
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const int f = wv + 4 * i;
+      const int f = wv + NW * i;
       const int fs = f < NFR ? f : 0;
       const T* sp;
       if (fs < NKF) {
@@ -355,16 +359,26 @@ __global__ __launch_bounds__(256) void selfattn_fwd_kernel(const SParams p) {
 #include "../../tools/experiments/selfattn_fwd32.inc"     // 32x32x16-MFMA variant: measured slower in wall time (lower clocks), tools-only
 #endif
 
+template <typename T, int NKS, int NDT, int QT, bool SUMROW, bool PRE, int NW>
+int launch_sa_geom(const SParams& p, hipStream_t st) {
+  constexpr int lds = 3 * (((4 * NKS + 2 * NDT) + NW - 1) / NW * NW) * FRAG;
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW, PRE, NW>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
+  const int tiles = (p.N + 16 * NW * QT - 1) / (16 * NW * QT);
+  hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW, PRE, NW>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn launch: %s", hipGetErrorString(e));
+}
+
 template <typename T, int NKS, int NDT, bool SUMROW, bool PRE>
 int launch_sa_cfg(const SParams& p, hipStream_t st) {
   constexpr int QT = NDT > 6 ? 1 : 2;     // d > 96: one query tile per wave keeps the 4*NDT accumulator + 8*NDT V^T registers under 256
-  constexpr int lds = 3 * (((4 * NKS + 2 * NDT) + 3) / 4 * 4) * FRAG;
-  static StaLdsAttr attr;
-  if (!attr.ensure((const void*)selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW, PRE>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn) failed");
-  const int tiles = (p.N + 64 * QT - 1) / (64 * QT);
-  hipLaunchKernelGGL((selfattn_fwd_kernel<T, NKS, NDT, QT, SUMROW, PRE>), dim3(tiles * p.H, p.B), dim3(256), lds, st, p);
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn launch: %s", hipGetErrorString(e));
+  // d <= 48 (SD-v1 level 0, the launch that is 10 % of a UNet call): four waves per SIMD, one query tile per wave (STA_OPT_SELFATTN_WAVES)
+  if constexpr (NDT <= 3 && PRE) {
+    const int v = g_sta_opt[STA_OPT_SELFATTN_WAVES];
+    if (v == 8 || (v == 0 && p.N >= 1024)) return launch_sa_geom<T, NKS, NDT, 1, SUMROW, PRE, 8>(p, st);
+  }
+  return launch_sa_geom<T, NKS, NDT, QT, SUMROW, PRE, 4>(p, st);
 }
 
 template <typename T, int NKS, int NDT>

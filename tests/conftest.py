@@ -32,5 +32,5 @@ def _reset_launch_overrides():
     yield
     from sta import lib
     if lib._lib is not None:
-        for key in range(8):
+        for key in range(9):
             lib._lib.sta_set_option(key, 0)

@@ -289,7 +289,8 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters, dtype):
                                           (2, 64, 64, 8), (3, 200, 256, 4), (2, 2304, 640, 8),
                                           # d = 160 (SD-v1 levels 2 and mid at 512^2 / 768^2), 128, 112, 144
                                           (2, 256, 1280, 8), (4, 64, 1280, 8), (2, 576, 1280, 8), (2, 144, 1280, 8),
-                                          (1, 128, 256, 2), (1, 72, 112, 1), (2, 192, 288, 2)])
+                                          (1, 128, 256, 2), (1, 72, 112, 1), (2, 192, 288, 2),
+                                          (2, 1096, 80, 2), (1, 1024, 96, 2)])      # d = 40 / 48 with a ragged / exact eight-wave tiling
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_self_attention_matches_reference(B, N, C, heads, dtype):
     """Flash-style self-attention kernel (attn1) vs softmax(q k^T scale) v in fp64 on the same 16-bit inputs;
@@ -323,6 +324,17 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     ref3 = (torch.softmax(qs64 @ k64.transpose(-1, -2) * ops.LN2, -1) @ v64).transpose(1, 2).reshape(B, N, C)
     err3 = (out3.float().cpu().double() - ref3).abs()
     assert (err3 <= 4 * eps * (1.0 + ref3.abs())).all(), (err3.max(), ref3.abs().max())
+    if d <= 48:
+        # both geometries of the log2-domain kernel at d <= 48, whatever the dispatch picks for this N: four waves x two query
+        # tiles (three waves per SIMD) and eight waves x one tile (four per SIMD; the default from N = 1024)
+        from sta import lib
+        for waves in (4, 8):
+            lib.set_option(lib.OPT_SELFATTN_WAVES, waves)
+            o_w = ops.self_attention(qs.cuda(), qk_d[..., C:], vt_d, heads, ops.LN2)
+            torch.cuda.synchronize()
+            e_w = (o_w.float().cpu().double() - ref3).abs()
+            assert (e_w <= 4 * eps * (1.0 + ref3.abs())).all(), (waves, e_w.max(), ref3.abs().max())
+        lib.set_option(lib.OPT_SELFATTN_WAVES, 0)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])

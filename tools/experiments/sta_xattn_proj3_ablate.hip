@@ -1,3 +1,9 @@
+// EXPERIMENT BUILD of csrc/sta_xattn_proj3.hip (snapshot of round 4, commit "level 0: norm2 writes y in query-fragment order"):
+// the product kernel plus -DSTA_P3_ABLATE=bits ablations (1 no projection MFMAs, 2 no attention, 4 no output stores, 8 no y refills,
+// 16 no Wq fragment reads, 32 fragment-order store ADDRESSES — wrong results, timing only; 19 = the load + store skeleton) and the
+// -DSTA_TRACE timeline points. Never part of libsta_xattn.so; swapped in by tools/lib_ab.py:
+//   python tools/lib_ab.py tools/proj_bench.py --imgs 32 --only pairq -- base= skel=-DSTA_P3_ABLATE=19,src:sta_xattn_proj3.hip=tools/experiments/sta_xattn_proj3_ablate.hip
+// profiles/r03_level0.md and profiles/r04_level0.md quote its numbers.
 // sta_xattn_proj3.hip — projection-fused forward for HEAD PAIRS, second generation (d = 40: SD-v1 level 0, K <= 2).
 //
 // Same decomposition as its predecessor (a workgroup = 8 waves x 16 pixels keeps ONE head pair's operands in LDS — the
@@ -31,12 +37,17 @@
 #include "sta_xattn_dev.h"
 #include "sta_xattn_proj3.h"
 
-// (The ablation / timeline / fragment-order-store experiment build of this kernel, which profiles/r03_level0.md and
-// profiles/r04_level0.md quote, lives in tools/experiments/sta_xattn_proj3_ablate.hip; tools/lib_ab.py swaps it in.)
+
+// Ablation builds for tools/lib_ab.py (-DSTA_P3_ABLATE=bits; 0 in the product library): 1 no projection MFMAs, 2 no attention,
+// 4 no output stores, 8 no y refills (the ring is loaded once per wave), 16 no Wq fragment reads. 19 = the load + store skeleton.
+#ifndef STA_P3_ABLATE
+#define STA_P3_ABLATE 0
+#endif
 
 namespace {
 
 using namespace sta_p3;
+constexpr int ABL = STA_P3_ABLATE;
 
 template <typename T> struct M16;           // the k = 16 MFMA of the same type family
 template <> struct M16<_Float16> {
@@ -350,9 +361,13 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   const int koffb = c16 * KROW + 16 * g, koffs = c16 * KROW + 64 + 8 * g;
   const int voffb = KBYTES + c16 * VROW + 16 * g, voffs = KBYTES + c16 * VROW + 128 + 8 * g;
   const V8* wf = (const V8*)lds_wq + lane;
+  STA_T_INIT();
+  STA_T(0);
   wait_dma_and_sync();
+  STA_T(1);
 
-  while (qcur < nitems) {
+  for (int it = 0; qcur < nitems; ++it) {
+    if (it == 1) STA_T(2);
     // ---- projection: 5 column tiles x both batch rows; Wq fragments one k-step ahead -------------------------------
     f32x4 qa0[NT], qa1[NT];
 #pragma unroll
@@ -367,7 +382,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     for (int s = 0; s < NKC; ++s) {
       if (s + 1 < NKC) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) a[(s + 1) & 1][u] = wf[((s + 1) * NT + u) * 64];
+        for (int u = 0; u < NT; ++u) a[(s + 1) & 1][u] = (ABL & 16) ? a[s & 1][u] : wf[((s + 1) * NT + u) * 64];
       }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (YFULL) {
@@ -389,12 +404,19 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
           }
         }
         const V8 b0 = __builtin_bit_cast(V8, r0), b1 = __builtin_bit_cast(V8, r1);
+        if constexpr (ABL & 1) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          qa0[u] = Tr<T>::mfma(a[s & 1][u], b0, qa0[u]);
-          qa1[u] = Tr<T>::mfma(a[s & 1][u], b1, qa1[u]);
+          for (int u = 0; u < NT; ++u) asm volatile("" :: "v"(a[s & 1][u]));
+          asm volatile("" :: "v"(b0), "v"(b1));
+          if (s < NT) { qa0[s] = __builtin_bit_cast(f32x4, b0); qa1[s] = __builtin_bit_cast(f32x4, b1); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            qa0[u] = Tr<T>::mfma(a[s & 1][u], b0, qa0[u]);
+            qa1[u] = Tr<T>::mfma(a[s & 1][u], b1, qa1[u]);
+          }
         }
-        if (s & 1) {       // the line pair is consumed: request the same pair of the NEXT item into both slots
+        if ((s & 1) && !(ABL & 8)) {       // the line pair is consumed: request the same pair of the NEXT item into both slots
           const unsigned so = 128u * (unsigned)(s >> 1);
           yr0[ja] = srd_load16<V8>(y_srd, voffn, so);
           yr1[ja] = srd_load16<V8>(y_srd, voffn, row1 + so);
@@ -403,12 +425,19 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         }
       } else {
         const int j = s % RING;
+        if constexpr (ABL & 1) {
 #pragma unroll
-        for (int u = 0; u < NT; ++u) {
-          qa0[u] = Tr<T>::mfma(a[s & 1][u], yr0[j], qa0[u]);
-          qa1[u] = Tr<T>::mfma(a[s & 1][u], yr1[j], qa1[u]);
+          for (int u = 0; u < NT; ++u) asm volatile("" :: "v"(a[s & 1][u]));
+          asm volatile("" :: "v"(yr0[j]), "v"(yr1[j]));
+          if (s < NT) { qa0[s] = __builtin_bit_cast(f32x4, yr0[j]); qa1[s] = __builtin_bit_cast(f32x4, yr1[j]); }
+        } else {
+#pragma unroll
+          for (int u = 0; u < NT; ++u) {
+            qa0[u] = Tr<T>::mfma(a[s & 1][u], yr0[j], qa0[u]);
+            qa1[u] = Tr<T>::mfma(a[s & 1][u], yr1[j], qa1[u]);
+          }
         }
-        {
+        if constexpr (!(ABL & 8)) {
           // refill this ring slot with k-step s + RING: of this item, or of the next one (zeros past the last item)
           const bool wrap = s + RING >= NKC;              // compile time after unrolling
           const unsigned vo = wrap ? voffn : voff;
@@ -418,7 +447,9 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if ((s & 1) && s < 9) if (it == 1) STA_T(9 + (s >> 1));
     }
+    if (it == 1) STA_T(3);
     // K operands of the first context (head A, ctx 0): requested here, they land under the accumulator conversions
     KFr<T> kf;
     load_k<T>(kf, lds_kv + koffb, lds_kv + koffs);
@@ -470,13 +501,44 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
       oc = pack_out<T>(ac);
     };
     OutRow au_A, ac_A, au_B, ac_B;
+    if constexpr (ABL & 2) {          // no attention: the projected q goes out through the same stores
+      const f32x4 a0[3] = {qa0[0], qa0[1], qa0[2]}, a1[3] = {qa1[0], qa1[1], qa1[2]};
+      const f32x4 b0[3] = {qa0[2], qa0[3], qa0[4]}, b1[3] = {qa1[2], qa1[3], qa1[4]};
+      asm volatile("" :: "v"(kf.big[0]), "v"(kf.sm[4]), "v"(qA0), "v"(qB1), "v"(qs0), "v"(qs1), "v"(qA1), "v"(qB0));
+      au_A = pack_out<T>(a0); ac_A = pack_out<T>(a1); au_B = pack_out<T>(b0); ac_B = pack_out<T>(b1);
+    } else
     head(std::integral_constant<int, 0>{}, qA0, qA1, au_A, ac_A);
     // head A's dims 0..31 of both batch rows: bytes 0..63 of the pair segment, 16 bytes per lane, no cross-lane exchange
-    __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, valid ? seg + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, valid ? seg1 + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
-    head(std::integral_constant<int, 1>{}, qB0, qB1, au_B, ac_B);
-    store_pair_rest(o_srd, seg, valid, g, au_A.tail, au_B);
-    store_pair_rest(o_srd, seg1, valid, g, ac_A.tail, ac_B);
+    if constexpr (ABL & 32) {      // EXPERIMENT: fragment-order store addresses (1-KiB contiguous per instruction)
+      const unsigned fb = (unsigned)px0_of(qcur) * row_bytes + (unsigned)lane * 16u;
+      __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, valid ? fb + 2048u * pr : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, valid ? fb + row1 + 2048u * pr : 0xfffffff0u, 0, 0);
+    } else
+    if constexpr (ABL & 4) {
+      asm volatile("" :: "v"(au_A.main), "v"(ac_A.main));
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, valid ? seg + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, valid ? seg1 + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
+    }
+    if (it == 1) STA_T(4);
+    if constexpr (!(ABL & 2)) head(std::integral_constant<int, 1>{}, qB0, qB1, au_B, ac_B);
+    if constexpr (ABL & 32) {
+      const unsigned fb = (unsigned)px0_of(qcur) * row_bytes + (unsigned)lane * 16u;
+      __builtin_amdgcn_raw_buffer_store_b128(au_B.main, o_srd, valid ? fb + 2048u * pr + 1024u : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_B.main, o_srd, valid ? fb + row1 + 2048u * pr + 1024u : 0xfffffff0u, 0, 0);
+      const u32x4 zu = {au_A.tail[0], au_A.tail[1], au_B.tail[0], au_B.tail[1]}, zc = {ac_A.tail[0], ac_A.tail[1], ac_B.tail[0], ac_B.tail[1]};
+      const unsigned zo = 8192u + 1024u * (pr >> 1) + 512u * (pr & 1);
+      __builtin_amdgcn_raw_buffer_store_b128(zu, o_srd, (valid && g < 2) ? fb + zo : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(zc, o_srd, (valid && g < 2) ? fb + row1 + zo : 0xfffffff0u, 0, 0);
+    } else
+    if constexpr (ABL & 4) {
+      asm volatile("" :: "v"(au_A.tail[0]), "v"(au_A.tail[1]), "v"(ac_A.tail[0]), "v"(ac_A.tail[1]), "v"(au_B.main), "v"(ac_B.main),
+                   "v"(au_B.tail[0]), "v"(au_B.tail[1]), "v"(ac_B.tail[0]), "v"(ac_B.tail[1]));
+    } else {
+      store_pair_rest(o_srd, seg, valid, g, au_A.tail, au_B);
+      store_pair_rest(o_srd, seg1, valid, g, ac_A.tail, ac_B);
+    }
+    if (it == 1) STA_T(5);
     mb = mbn;
     qcur = qnext;
     qnext = (int)__builtin_amdgcn_readfirstlane(qtake);
@@ -487,6 +549,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
       voffhn = voff_of(qnext, 1);
     }
   }
+  STA_T(8);
+  STA_T_END();
 }
 
 template <typename T, int NKC, int YL>
@@ -510,6 +574,12 @@ int launch_p3(P3 p, int n_img, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef STA_TRACE
+extern "C" int sta_debug_set_trace_p3(void* buf) {      // trace build only (tools/trace_proj.py)
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_trace), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 namespace sta_p3 {
 

@@ -1,6 +1,7 @@
 """A/B harness for kernel experiments: builds the library once per flag set into gpurun_out/libsta_<tag>.so and runs a
 tool script against each build in its own process, `rounds` times interleaved.
-usage: lib_ab.py <tool.py> [tool args ...] -- tag1=-DFLAG1,-DFLAG2 tag2= ...   (an empty flag list = the product build)"""
+usage: lib_ab.py <tool.py> [tool args ...] -- tag1=-DFLAG1,-DFLAG2 tag2= ...   (an empty flag list = the product build;
+"src:<file>=<path>" in a flag list swaps one product source for an experiment build, see below)"""
 import os
 import subprocess
 import sys
@@ -21,10 +22,18 @@ for v in variants:
     if os.path.exists(out) and os.environ.get("AB_REBUILD") != "1":
         continue
     objs = []
+    flag_list = [f for f in flags.split(",") if f]
+    # "src:<product file>=<path>" swaps one translation unit for an experiment build of it (tools/experiments/*.hip), e.g.
+    #   skel=-DSTA_P3_ABLATE=19,src:sta_xattn_proj3.hip=tools/experiments/sta_xattn_proj3_ablate.hip
+    swaps = dict(f[4:].split("=", 1) for f in flag_list if f.startswith("src:"))
+    flag_list = [f for f in flag_list if not f.startswith("src:")]
     for src in lib.SOURCES:
         obj = out + "." + os.path.basename(src) + ".o"
+        base = os.path.basename(src)
+        if base in swaps:
+            src = os.path.join(ROOT, swaps[base])
         cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", lib.INCLUDE, "-I", lib.CSRC,
-               *lib.PER_SOURCE_FLAGS.get(os.path.basename(src), []), *[f for f in flags.split(",") if f], "-c", src, "-o", obj]
+               *lib.PER_SOURCE_FLAGS.get(base, []), *flag_list, "-c", src, "-o", obj]
         objs.append((subprocess.Popen(cmd), obj))
     for pr, _ in objs:
         assert pr.wait() == 0

@@ -28,4 +28,12 @@ for B, N, C, h in ((64, 4096, 320, 8), (64, 1024, 640, 8)):
     lib.load().sta_set_option(lib.OPT_SELFATTN_32, 2)          # the 16x16x32-MFMA kernel where the 32x32x16 one is the default (d = 40)
     c = timed(lambda: ops.self_attention(qk[..., :C], qk[..., C:], vt, h, ops.LN2))
     lib.load().sta_set_option(lib.OPT_SELFATTN_32, 0)
-    print(json.dumps({"B": B, "N": N, "d": d, "scaled_us": round(a, 1), "log2_us": round(b, 1), "log2_16x16x32_us": round(c, 1)}))
+    res = {"B": B, "N": N, "d": d, "scaled_us": round(a, 1), "log2_us": round(b, 1), "log2_16x16x32_us": round(c, 1)}
+    if d <= 48:
+        for waves in (4, 8, 4, 8):          # the two geometries of the d <= 48 kernel, interleaved
+            lib.set_option(lib.OPT_SELFATTN_WAVES, waves)
+            res.setdefault("log2_%dwaves_us" % waves, []).append(round(timed(lambda: ops.self_attention(qk[..., :C], qk[..., C:], vt, h, ops.LN2)), 1))
+        lib.set_option(lib.OPT_SELFATTN_WAVES, 0)
+        flop = 4.0 * B * h * N * N * d
+        res["tflops_best"] = round(flop / min(res["log2_8waves_us"] + res["log2_4waves_us"]) / 1e6, 1)
+    print(json.dumps(res))

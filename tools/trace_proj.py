@@ -18,7 +18,9 @@ from sta import lib, ops  # noqa: E402
 out = os.path.join(ROOT, "gpurun_out", "libsta_trace.so")
 os.makedirs(os.path.dirname(out), exist_ok=True)
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DSTA_TRACE", "-ffinite-math-only",
-                       "-I", lib.INCLUDE, "-I", lib.CSRC, *lib.SOURCES, "-o", out])
+                       "-I", lib.INCLUDE, "-I", lib.CSRC,
+                       *[os.path.join(ROOT, "tools", "experiments", "sta_xattn_proj3_ablate.hip") if s_.endswith("sta_xattn_proj3.hip") else s_ for s_ in lib.SOURCES],
+                       "-o", out])      # the head-pair kernel's timeline points live in the experiment build of its source
 lib.LIB_PATH = out
 L = lib.load()
 P3 = len(sys.argv) > 4 and sys.argv[4] == "pair"    # 1 image landed | 2 item 1 begins | 3 projection issued | 4 head A | 5 head B | 8 end | 9-12 after k-steps 1,3,5,7 of item 1
