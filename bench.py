@@ -478,10 +478,9 @@ def main():
     dev = torch.device("cuda", local)
     from ldm.models.diffusion.plms import PLMSSampler
     from sta import lib
-    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, set_recompute, use_shipped_miopen_db, use_tuned_gemms
+    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, set_recompute, use_shipped_miopen_db
     lib.load()
     use_shipped_miopen_db(local)      # per-rank copy of the shipped MIOpen find-db (before the first convolution)
-    use_tuned_gemms()                 # measured GEMM-kernel table for the bench shapes (process-wide TunableOp lookup, tuning off)
 
     K, dt = a.objects, (torch.float16 if a.dtype == "fp16" else torch.bfloat16)
     ckpt_mode = None
@@ -563,7 +562,7 @@ def main():
                                        "%d weight-optimisation epochs, CLIP stand-in loss (BASELINE configs[2])" % a.opt_epochs),
                    "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt; step j of rank r takes prompts ((j * %d + r) * %d + i) %% 64" % (world, I),
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
-                   "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "tuned_gemm_table": bool(torch.cuda.tunable.is_enabled()), "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
+                   "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,
                    "peak_hbm_gib": round(peak_gb, 1), **({"recompute": ckpt_mode} if a.opt_epochs > 1 else {})},
     }

@@ -58,10 +58,10 @@ __device__ __forceinline__ float bfly_sum(float x) {
 // 2.5 instead of 3.5 vector instructions per score in a loop whose time is the vector pipe's.
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }   // one v_max3_f32
 
-// NW waves per workgroup. NW = 4 (QT query tiles of 16 per wave): the general kernel. NW = 8 with QT = 1: the same loop sized for FOUR
-// waves per SIMD (<= 128 registers; two 512-thread workgroups per CU share each K / V^T block among 128 queries as before) —
-// the loop is bound by vector-issue slots (a 64-key block needs ~730 issue-port cycles per 32 queries against ~450 of matrix
-// pipe, profiles/r03_selfattn_32x32.md) and three waves per SIMD left the port a third idle.
+// NW waves per workgroup. NW = 4 (QT query tiles of 16 per wave): the shipped geometry. NW = 8 with QT = 1: the same loop sized for FOUR
+// waves per SIMD (<= 128 registers; two 512-thread workgroups per CU share each K / V^T block among 128 queries as before),
+// built to test whether a fourth wave fills the third of the vector-issue port that three waves leave idle
+// (profiles/r03_selfattn_32x32.md): it does not (launch_sa_cfg below).
 template <typename T, int NKS, int NDT, int QT, bool SUMROW, bool PRE, int NW>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void selfattn_fwd_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
@@ -373,10 +373,12 @@ int launch_sa_geom(const SParams& p, hipStream_t st) {
 template <typename T, int NKS, int NDT, bool SUMROW, bool PRE>
 int launch_sa_cfg(const SParams& p, hipStream_t st) {
   constexpr int QT = NDT > 6 ? 1 : 2;     // d > 96: one query tile per wave keeps the 4*NDT accumulator + 8*NDT V^T registers under 256
-  // d <= 48 (SD-v1 level 0, the launch that is 10 % of a UNet call): four waves per SIMD, one query tile per wave (STA_OPT_SELFATTN_WAVES)
+  // d <= 48 (SD-v1 level 0, the launch that is 10 % of a UNet call): STA_OPT_SELFATTN_WAVES = 8 selects the four-waves-per-SIMD
+  // geometry (eight waves x one query tile, 92 registers). Measured SLOWER than four waves x two tiles on the same box (2105 vs
+  // 2008 us at 64 x 8 heads, N = 4096: profiles/r04_selfattn_waves.md) — every K / V^T fragment read from LDS then serves 16
+  // instead of 32 queries — so it stays an opt-in that the parity tests keep green.
   if constexpr (NDT <= 3 && PRE) {
-    const int v = g_sta_opt[STA_OPT_SELFATTN_WAVES];
-    if (v == 8 || (v == 0 && p.N >= 1024)) return launch_sa_geom<T, NKS, NDT, 1, SUMROW, PRE, 8>(p, st);
+    if (g_sta_opt[STA_OPT_SELFATTN_WAVES] == 8) return launch_sa_geom<T, NKS, NDT, 1, SUMROW, PRE, 8>(p, st);
   }
   return launch_sa_geom<T, NKS, NDT, QT, SUMROW, PRE, 4>(p, st);
 }

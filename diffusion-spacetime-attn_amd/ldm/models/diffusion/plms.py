@@ -265,45 +265,36 @@ class PLMSSampler(object):
             # Only the image of the last epoch is kept and the weights are discarded afterwards, so the
             # backward + Adam step of the last epoch cannot change any output (reference :275-288).
             track = W.requires_grad and not last
-            # The measured GEMM-kernel table (sta.pipeline.use_tuned_gemms) is a per-call lookup on the host: free under hipGraph
-            # replay, a loss in the launch-bound eager autograd of a tracked epoch (0.425 vs 0.443 images/s) -> off while tracking.
-            tuned = track and torch.cuda.is_available() and torch.cuda.tunable.is_enabled()
-            if tuned:
-                torch.cuda.tunable.enable(False)
-            try:
-                scale_backoff = 1.0
-                by_call = track and getattr(self.model, "sta_call_recompute", False)
-                while True:
-                    # tracked epochs: eager autograd through the 51 calls, or (sta.pipeline.set_recompute mode "call") the
-                    # fixed-weight forward per call + one re-run of the call under autograd in backward, with the glue passes of
-                    # the trunk as autograd Functions over the HIP kernels (sta.fused.tracked)
-                    with torch.set_grad_enabled(track), _fused.tracked(by_call):
-                        img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
-                                               time_range, W if batched else W[0], block_boxes, text_index,
-                                               graph=self.use_graph and (not track or by_call), call_recompute=by_call)
-                        x_img = None
-                        if self.model.first_stage_model is not None:
-                            x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
-                        if track:
-                            loss = sum(self._fidelity_loss(x_img[i].float(), texts[i], boxes[i], names[i]) for i in range(b))
-                            optimizer.zero_grad()
-                            scale = self._loss_scale(float(loss.detach())) * scale_backoff
-                            (loss * scale if scale != 1.0 else loss).backward()
-                            # checked whatever the scale (a backoff can land on exactly 1.0): Adam must never see a non-finite gradient
-                            if not bool(torch.isfinite(W.grad).all()):
-                                if scale_backoff > 2.0 ** -24:
-                                    scale_backoff /= 256.0         # an fp16 overflow somewhere in the backward: same epoch again, smaller scale
-                                    continue
-                                raise FloatingPointError("the gradient of the blend weights is not finite even with the loss scale backed "
-                                                         "off to %g: refusing to step the optimizer on it" % scale)
-                            if scale != 1.0:
-                                W.grad.div_(scale)
-                            optimizer.step()
-                            result.setdefault("losses", []).append(float(loss.detach()))
-                    break
-            finally:
-                if tuned:            # an exception inside the epoch (OOM, missing CLIP, Ctrl-C) must not leave the process-wide switch off
-                    torch.cuda.tunable.enable(True)
+            scale_backoff = 1.0
+            by_call = track and getattr(self.model, "sta_call_recompute", False)
+            while True:
+                # tracked epochs: eager autograd through the 51 calls, or (sta.pipeline.set_recompute mode "call") the
+                # fixed-weight forward per call + one re-run of the call under autograd in backward, with the glue passes of
+                # the trunk as autograd Functions over the HIP kernels (sta.fused.tracked)
+                with torch.set_grad_enabled(track), _fused.tracked(by_call):
+                    img = self._trajectory(img_input.clone(), cond, unconditional_conditioning, unconditional_guidance_scale,
+                                           time_range, W if batched else W[0], block_boxes, text_index,
+                                           graph=self.use_graph and (not track or by_call), call_recompute=by_call)
+                    x_img = None
+                    if self.model.first_stage_model is not None:
+                        x_img = torch.clamp((self.model.decode_first_stage(img) + 1.0) / 2.0, min=0.0, max=1.0)   # :249-250
+                    if track:
+                        loss = sum(self._fidelity_loss(x_img[i].float(), texts[i], boxes[i], names[i]) for i in range(b))
+                        optimizer.zero_grad()
+                        scale = self._loss_scale(float(loss.detach())) * scale_backoff
+                        (loss * scale if scale != 1.0 else loss).backward()
+                        # checked whatever the scale (a backoff can land on exactly 1.0): Adam must never see a non-finite gradient
+                        if not bool(torch.isfinite(W.grad).all()):
+                            if scale_backoff > 2.0 ** -24:
+                                scale_backoff /= 256.0         # an fp16 overflow somewhere in the backward: same epoch again, smaller scale
+                                continue
+                            raise FloatingPointError("the gradient of the blend weights is not finite even with the loss scale backed "
+                                                     "off to %g: refusing to step the optimizer on it" % scale)
+                        if scale != 1.0:
+                            W.grad.div_(scale)
+                        optimizer.step()
+                        result.setdefault("losses", []).append(float(loss.detach()))
+                break
             if last:
                 result.update(x0=img.detach(), image=None if x_img is None else x_img.detach(),
                               W=(W if batched else W[0]).detach().clone())

@@ -80,7 +80,7 @@ def run(kind, default_dataset):
         raise SystemExit("--n_samples must be 1 (the blocks reshape to the CFG batch of 2, attention.py:282)")
     from ldm.models.diffusion.plms import PLMSSampler
     from sta import datasets, parallel
-    from sta.pipeline import build_sd_v1, conditionings, use_shipped_miopen_db, use_tuned_gemms
+    from sta.pipeline import build_sd_v1, conditionings, use_shipped_miopen_db
 
     rank, world, local = parallel.init_from_env()
     if not torch.cuda.is_available():
@@ -89,7 +89,6 @@ def run(kind, default_dataset):
     dev = torch.device("cuda", local)
     dtype = torch.bfloat16 if opt.dtype == "bf16" else torch.float16
     use_shipped_miopen_db(local)      # per-rank copy of the shipped MIOpen find-db; a different MIOpen build ignores it
-    use_tuned_gemms()                 # measured GEMM table (lookup only); ignored by a different PyTorch / hipBLASLt build
 
     prompts = datasets.load_prompts(opt.dataset, kind, opt.limit)
     layouts = datasets.load_layouts(opt.layout) if opt.layout else None

@@ -51,31 +51,6 @@ def use_shipped_miopen_db(rank=None):
     return dst
 
 
-# The GEMM library picks a kernel per shape by heuristic; for the Linear layers of the bench shapes (fp16, 32 prompts per
-# step) PyTorch's TunableOp measured every hipBLASLt / rocBLAS candidate once on an MI355X (e.g. the level-0 GEGLU
-# projection: 446 us instead of 639 us) and the answers (fp16 and bf16 default bench, 768^2, tracked epochs: 160 shapes) ship in sta/data/tunableop: +1.5 % images/s. Applied with
-# tuning OFF (a lookup, nothing is measured at run time); a different PyTorch / hipBLASLt build fails the file's
-# validators and is ignored. PYTORCH_TUNABLEOP_ENABLED in the environment (0 or 1) leaves everything to the caller.
-TUNED_GEMMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "tunableop", "gfx950_gemm_results.csv")
-
-
-def use_tuned_gemms():
-    """Explicit opt-in (bench.py, the entry-point scripts): TunableOp is a PROCESS-WIDE switch other models share."""
-    if "PYTORCH_TUNABLEOP_ENABLED" in os.environ or not os.path.exists(TUNED_GEMMS) or not torch.cuda.is_available():
-        return False
-    import torch.cuda.tunable as tun
-    try:
-        tun.enable(True)
-        tun.tuning_enable(False)
-        tun.write_file_on_exit(False)              # a lookup table: nothing is measured, nothing to dump at exit
-        ok = bool(tun.read_file(TUNED_GEMMS))
-    except Exception:
-        ok = False
-    if not ok:
-        tun.enable(False)
-    return ok
-
-
 DEFAULT_CENTRES = [(0.30, 0.40), (0.70, 0.60), (0.5, 0.2), (0.25, 0.75)]      # SURVEY.md §8(d)
 
 

@@ -68,7 +68,8 @@ enum {
   STA_OPT_SPLIT_QT = 5,     /* sub-tiles per wave of the split kernel: 1, 2, 4 */
   STA_OPT_SELFATTN_32 = 6,  /* experiment builds only (-DSTA_EXPERIMENT_SELFATTN32): 2 = keep the 16x16x32-MFMA self-attention kernel at d = 40 */
   STA_OPT_PROJ_PAIR = 7,    /* sta_xattn_fwd_proj: 1 = head-pair kernel whenever the shape allows, 2 = one head per workgroup */
-  STA_OPT_SELFATTN_WAVES = 8, /* sta_selfattn_fwd at d <= 48: 8 = eight waves x one query tile (four waves per SIMD), 4 = four waves x two tiles */
+  STA_OPT_SELFATTN_WAVES = 8, /* sta_selfattn_fwd at d <= 48, log2-domain path: 8 = eight waves x one query tile (four waves per SIMD; measured
+                                 slower, kept for tests / tools), anything else = four waves x two tiles */
   STA_OPT_COUNT = 9
 };
 int sta_set_option(int key, int value);

@@ -325,8 +325,8 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     err3 = (out3.float().cpu().double() - ref3).abs()
     assert (err3 <= 4 * eps * (1.0 + ref3.abs())).all(), (err3.max(), ref3.abs().max())
     if d <= 48:
-        # both geometries of the log2-domain kernel at d <= 48, whatever the dispatch picks for this N: four waves x two query
-        # tiles (three waves per SIMD) and eight waves x one tile (four per SIMD; the default from N = 1024)
+        # both geometries of the log2-domain kernel at d <= 48: four waves x two query tiles (three waves per SIMD, shipped) and
+        # eight waves x one tile (four per SIMD; opt-in through STA_OPT_SELFATTN_WAVES)
         from sta import lib
         for waves in (4, 8):
             lib.set_option(lib.OPT_SELFATTN_WAVES, waves)
