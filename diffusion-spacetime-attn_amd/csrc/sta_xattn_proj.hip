@@ -396,7 +396,7 @@ static bool takes_pair_kernel(int n_img, int N, int C, int heads, int M, int K) 
 
 static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                          const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
-                         int dtype, void* stream, bool qfrag);
+                         int dtype, void* stream, bool qfrag, bool ofrag = false);
 
 int sta_xattn_fwd_proj_qfrag_supported(int n_img, int N, int C, int heads, int M, int K) {
   const int rc = n_img < 1 ? STA_E_ARG : check_proj_shape(N, C, heads, M, K);
@@ -410,6 +410,12 @@ int sta_xattn_fwd_proj_qfrag(const void* y, const void* packed_wq, const void* p
   return fwd_proj_impl(y, packed_wq, packed_kv, mask, coef, out, n_img, N, C, heads, M, K, scale, dtype, stream, true);
 }
 
+int sta_xattn_fwd_proj_qfrag_ofrag(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                                   const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
+                                   int dtype, void* stream) {
+  return fwd_proj_impl(y, packed_wq, packed_kv, mask, coef, out, n_img, N, C, heads, M, K, scale, dtype, stream, true, true);
+}
+
 int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                        const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
                        int dtype, void* stream) {
@@ -420,7 +426,7 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
 
 static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                          const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
-                         int dtype, void* stream, bool qfrag) {
+                         int dtype, void* stream, bool qfrag, bool ofrag) {
   g_sta_err[0] = 0;
   if (!y || !packed_wq || !packed_kv || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (n_img < 1 || n_img > 65535) return sta_fail(STA_E_ARG, "n_img=%d", n_img);
@@ -445,7 +451,7 @@ static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packe
     const int ndt = (p.d + 15) / 16;
     const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
     const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
-    return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st, qfrag);
+    return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st, qfrag, ofrag);
   }
   if (qfrag) return sta_fail(STA_E_UNSUP, "query-fragment order is read by the head-pair kernel only (sta_xattn_fwd_proj_qfrag_supported)");
   return dtype == STA_BF16 ? dispatch_proj<__bf16>(p, n_img, lds, st) : dispatch_proj<_Float16>(p, n_img, lds, st);

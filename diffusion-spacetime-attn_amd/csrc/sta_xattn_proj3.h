@@ -28,8 +28,31 @@ inline bool eligible(int C, int heads, int M, int K) {
 inline size_t wq_bytes(int C, int heads) { return (size_t)(heads / 2) * NT * (C / 32) * 1024; }      // pair fragments of to_q.weight
 inline size_t kv_bytes(int n_ctx, int heads) { return (size_t)n_ctx * heads * BLK + 1024; }   // + slack: the last DMA piece is read whole
 
+// Head dim held by row r of a V^T image (row 40: the ones row, -1). O^T = V^T P^T leaves the MFMAs as lane (g, c) <- rows
+// 16u + 4g + {0..3}: the permutation makes a lane's tile-0 and tile-1 registers 8 CONSECUTIVE dims, i.e. one 16-byte piece of
+// the output row with no cross-lane exchange; head B (hp = 1) is rotated by one lane row so that the pair's 160-byte segment
+// of an output row goes out as three stores: bytes 0..63 = A dims 0..31 (lane rows 0..3), bytes 64..127 = [A dims 32..39 | B
+// dims 0..23] (lane row 0 | 1..3), bytes 128..159 = [B dims 24..31 | B dims 32..39] (lane rows 0 | 1) — see store_pair_rows.
+__host__ __device__ constexpr int vrow_dim(int r, int hp) {
+  return r == D ? -1 : (r >= 32 ? r : 8 * ((((r & 15) >> 2) + 3 * hp) & 3) + 4 * (r >> 4) + (r & 3));
+}
+
+// Out-fragment order (the kernel's OF mode; consumed by csrc/sta_rowgemm.hip): which channel of the [.., C] blended tensor
+// (head-major, channel = head * 40 + dim) sits in slot j (0..7) of lane row g of fragment f (0..9) of a 16-pixel group.
+//   f = 2 pr, 2 pr + 1: head 2 pr (A) / 2 pr + 1 (B): slots 0..3 = O^T rows 4g + j of tile 0, slots 4..7 = rows 16 + 4g + (j - 4)
+//   f = 8 + q:          lane rows 0, 1 = pair 2q, lane rows 2, 3 = pair 2q + 1; slots 0..3 = head A's O^T row 32 + 4(g & 1) + j,
+//                       slots 4..7 = head B's row 32 + 4(g & 1) + (j - 4)
+__host__ __device__ constexpr int ofrag_channel(int f, int g, int j) {
+  if (f < 8) {
+    const int hp = f & 1, r = j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4);
+    return f * D + vrow_dim(r, hp);
+  }
+  const int pr = 2 * (f - 8) + (g >> 1), hp = j < 4 ? 0 : 1, r = 32 + 4 * (g & 1) + (j & 3);
+  return (2 * pr + hp) * D + vrow_dim(r, hp);
+}
+
 int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype, hipStream_t st);
 int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* mask, const float* coef, void* out, int n_img,
-            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag = false);
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag = false, bool ofrag = false);
 }  // namespace sta_p3
 #endif

@@ -49,15 +49,6 @@ template <> struct M16<__bf16> {
   }
 };
 
-// Head dim held by row r of a V^T image (row 40: the ones row, -1). O^T = V^T P^T leaves the MFMAs as lane (g, c) <- rows
-// 16u + 4g + {0..3}: the permutation makes a lane's tile-0 and tile-1 registers 8 CONSECUTIVE dims, i.e. one 16-byte piece of
-// the output row with no cross-lane exchange; head B (hp = 1) is rotated by one lane row so that the pair's 160-byte segment
-// of an output row goes out as three stores: bytes 0..63 = A dims 0..31 (lane rows 0..3), bytes 64..127 = [A dims 32..39 | B
-// dims 0..23] (lane row 0 | 1..3), bytes 128..159 = [B dims 24..31 | B dims 32..39] (lane rows 0 | 1) — see store_pair_rows.
-__host__ __device__ constexpr int vrow_dim(int r, int hp) {
-  return r == D ? -1 : (r >= 32 ? r : 8 * ((((r & 15) >> 2) + 3 * hp) & 3) + 4 * (r >> 4) + (r & 3));
-}
-
 // K, V [n_ctx][M][C] -> [ctx][head][K rows | V^T rows], BLK bytes each (layout: file header, tools/emu_pair3.py)
 template <typename T>
 __global__ __launch_bounds__(256) void pack_kv_p3_kernel(const T* __restrict__ k, const T* __restrict__ v, T* __restrict__ packed,
@@ -253,8 +244,16 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
 // as C/32 fragments of 1 KiB in B-operand lane order, so a load instruction is one fully coalesced KiB (8 whole lines, adjacent
 // lanes on adjacent bytes), there is no cross-lane hand-over, and an item's 2 x NKC fragments start at the row-major byte
 // offset of its first pixel. N % 16 == 0.
-template <typename T, int NKC, int YL>
+//
+// OF (out-fragment order, with YL = 2 only): the blended output has ONE consumer as well — the to_out GEMM + residual + LayerNorm
+// pass of csrc/sta_rowgemm.hip — so it leaves in that kernel's MFMA B-operand order instead of row-major: per 16-pixel group and
+// batch row ten 1-KiB fragments, [2 pr] = head A's `main` registers of pair pr (lane (g, c): O^T rows 4g..4g+3 of tiles 0 | 1 of
+// pixel c), [2 pr + 1] = head B's, [8 + (pr >> 1)] = the tile-2 tails of two pairs (512 bytes each: lane rows 0, 1 hold
+// [A rows 32+4g.. | B rows 32+4g..]). Every store instruction is one contiguous KiB (or half of one) — no 160-byte pair
+// segments at a 640-byte stride, no cross-lane exchange; sta_p3::ofrag_channel() names the channel behind every slot.
+template <typename T, int NKC, int YL, bool OF>
 __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
+  static_assert(!OF || YL == 2, "out-fragment order rides on the query-fragment path (N % 16 == 0)");
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NWV = 8, TP = 16 * NWV;
@@ -471,12 +470,28 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     };
     OutRow au_A, ac_A, au_B, ac_B;
     head(std::integral_constant<int, 0>{}, qA0, qA1, au_A, ac_A);
-    // head A's dims 0..31 of both batch rows: bytes 0..63 of the pair segment, 16 bytes per lane, no cross-lane exchange
-    __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, valid ? seg + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, valid ? seg1 + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
-    head(std::integral_constant<int, 1>{}, qB0, qB1, au_B, ac_B);
-    store_pair_rest(o_srd, seg, valid, g, au_A.tail, au_B);
-    store_pair_rest(o_srd, seg1, valid, g, ac_A.tail, ac_B);
+    if constexpr (OF) {
+      // out-fragment order: fragment 2 pr of the item's group, one contiguous KiB per batch row
+      const unsigned fb = valid ? (unsigned)px0_of(qcur) * row_bytes + (unsigned)lane * 16u + 2048u * (unsigned)pr : 0xfffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, fb, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, fb, row1, 0);
+      head(std::integral_constant<int, 1>{}, qB0, qB1, au_B, ac_B);
+      __builtin_amdgcn_raw_buffer_store_b128(au_B.main, o_srd, fb, 1024u, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_B.main, o_srd, fb, row1 + 1024u, 0);
+      // tails: lane rows 0, 1 hold [A rows 32 + 4g .. | B rows 32 + 4g ..]; two pairs share fragment 8 + (pr >> 1)
+      const u32x4 zu = {au_A.tail[0], au_A.tail[1], au_B.tail[0], au_B.tail[1]}, zc = {ac_A.tail[0], ac_A.tail[1], ac_B.tail[0], ac_B.tail[1]};
+      const unsigned zb = (valid && g < 2) ? (unsigned)px0_of(qcur) * row_bytes + (unsigned)lane * 16u + 8192u + 1024u * (unsigned)(pr >> 1) + 512u * (unsigned)(pr & 1)
+                                           : 0xfffffff0u;
+      __builtin_amdgcn_raw_buffer_store_b128(zu, o_srd, zb, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(zc, o_srd, zb, row1, 0);
+    } else {
+      // head A's dims 0..31 of both batch rows: bytes 0..63 of the pair segment, 16 bytes per lane, no cross-lane exchange
+      __builtin_amdgcn_raw_buffer_store_b128(au_A.main, o_srd, valid ? seg + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(ac_A.main, o_srd, valid ? seg1 + 16u * (unsigned)g : 0xfffffff0u, 0, 0);
+      head(std::integral_constant<int, 1>{}, qB0, qB1, au_B, ac_B);
+      store_pair_rest(o_srd, seg, valid, g, au_A.tail, au_B);
+      store_pair_rest(o_srd, seg1, valid, g, ac_A.tail, ac_B);
+    }
     mb = mbn;
     qcur = qnext;
     qnext = (int)__builtin_amdgcn_readfirstlane(qtake);
@@ -489,7 +504,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   }
 }
 
-template <typename T, int NKC, int YL>
+template <typename T, int NKC, int YL, bool OF = false>
 int launch_p3(P3 p, int n_img, hipStream_t st) {
   constexpr int TP = 128;
   const int pairs = p.H / 2;
@@ -502,9 +517,9 @@ int launch_p3(P3 p, int n_img, hipStream_t st) {
   p.W = (p.tiles + p.iters - 1) / p.iters;
   const int lds = lds_bytes(p.C, p.K);
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YL>, 160 * 1024))
+  if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YL, OF>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj p3) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YL>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YL, OF>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj p3 launch: %s", hipGetErrorString(e));
 }
@@ -524,12 +539,14 @@ int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C,
 }
 
 int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* mask, const float* coef, void* out, int n_img,
-            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag) {
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag, bool ofrag) {
   P3 p{};
   p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv; p.mask = mask; p.coef = coef; p.out = out;
   p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.sl2e = sl2e;
+  if (ofrag && !(qfrag && C == 320)) return sta_fail(STA_E_UNSUP, "out-fragment order needs y in query-fragment order and C = 320");
   if (qfrag) {      // y in query-fragment order (sta_add_layernorm_qfrag): 1-KiB coalesced loads, no hand-over
     if (N % 16) return sta_fail(STA_E_UNSUP, "query-fragment order needs N %% 16 == 0 (N=%d)", N);
+    if (ofrag) return dtype == STA_BF16 ? launch_p3<__bf16, 10, 2, true>(p, n_img, st) : launch_p3<_Float16, 10, 2, true>(p, n_img, st);
     if (C == 320) return dtype == STA_BF16 ? launch_p3<__bf16, 10, 2>(p, n_img, st) : launch_p3<_Float16, 10, 2>(p, n_img, st);
     return dtype == STA_BF16 ? launch_p3<__bf16, 5, 2>(p, n_img, st) : launch_p3<_Float16, 5, 2>(p, n_img, st);
   }

@@ -69,10 +69,13 @@ ATTN_CHUNK = 8      # images per batched GEMM of the decoder's attention
 def _attention_chunked(q, k, v, scale):
     """softmax(scale q k^T) v for the decoder's one single-head attention (hw = 4096, c = 512; reference
     ldm/modules/diffusionmodules/model.py AttnBlock: bmm - softmax - bmm) as plain library GEMMs with an fp32 softmax, a few
-    images at a time: no Triton-built SDPA kernel in the product path, and the batched GEMMs stay far below the size at which
-    the library faulted (one bmm over 32 images in bf16: tools/repro_bmm_fault.py). The scale rides on q so that the 16-bit
+    images at a time: no Triton-built SDPA kernel in the product path. The scale rides on q so that the 16-bit
     scores stay small; runs once per image, under autograd in the tracked epochs (P of a chunk is what backward keeps)."""
-    q = q * scale
+    # CONTIGUOUS [b, hw, c] operands: q, k, v arrive as transposed views of the 1x1 convolutions' [b, c, hw] outputs, and a
+    # batched GEMM whose operands are such views returns wrong values in bf16 on this library build (max error 5.7 against
+    # fp32 at [32..48, 4096, 512]; the same call on contiguous tensors is right: tools/repro_bmm_fault.py, profiles/r04_bmm_repro.txt)
+    # — the memory-access fault the 32-image bf16 decode ran into. Three 4 MB-per-image copies, once per image.
+    q, k, v = (q * scale).contiguous(), k.contiguous(), v.contiguous()
     outs = []
     for i in range(0, q.shape[0], ATTN_CHUNK):
         s = torch.bmm(q[i:i + ATTN_CHUNK], k[i:i + ATTN_CHUNK].transpose(1, 2))

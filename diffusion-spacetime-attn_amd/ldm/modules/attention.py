@@ -161,13 +161,14 @@ class _PromptCache:
     """What a block keeps per prompt for one (N, K) shape: the packed K/V image of the K+2 contexts
     and the disc masks. Buffers are allocated once per shape and refilled in place for later prompts,
     so a captured hipGraph that holds their addresses stays valid across prompts."""
-    __slots__ = ("version", "packed", "packed_proj", "qfrag", "mask", "centres")
+    __slots__ = ("version", "packed", "packed_proj", "qfrag", "ofrag", "mask", "centres")
 
     def __init__(self):
         self.version = -1
         self.packed = None
         self.packed_proj = None      # forward-only image for the projection-fused kernel (None: shape not taken)
         self.qfrag = False           # that kernel reads norm2's output in query-fragment order (head-pair launches)
+        self.ofrag = False           # ... and leaves its output in out-fragment order for the fused to_out + norm3 pass (C = 320)
         self.mask = None
         self.centres = None
 
@@ -236,8 +237,9 @@ class BasicTransformerBlock(nn.Module):
             if k.is_cuda and _ops.proj_supported(k.shape[2], self.attn2.heads, k.shape[1], K, N=n, n_img=n_img):
                 cache.packed_proj = _ops.pack_kv_proj(k, v, self.attn2.heads, out=cache.packed_proj, n_img=n_img)
                 cache.qfrag = _ops.proj_qfrag_supported(k.shape[2], self.attn2.heads, k.shape[1], K, n, n_img)
+                cache.ofrag = cache.qfrag and _ops.proj_ofrag_supported(k.shape[2], self.attn2.heads)
             else:
-                cache.packed_proj, cache.qfrag = None, False
+                cache.packed_proj, cache.qfrag, cache.ofrag = None, False, False
             if K:
                 m = torch.stack([_ops.disc_mask_bits(c, dim) for c in centres]).to(context.device)   # [I, N]
                 if cache.mask is None:
@@ -278,7 +280,14 @@ class BasicTransformerBlock(nn.Module):
             x, y = _fused.add_layernorm(x, self.attn1(y), None, n2.weight, n2.bias, n2.eps, qfrag=qfrag)
             if fused_q:
                 # to_q runs INSIDE the attention kernel: no [2I, N, C] query round trip through HBM
-                blended = _ops.xattn_forward_proj(y, self._wq_fragments(), cache.packed_proj, cache.mask, c, self.attn2.scale, qfrag=qfrag)
+                ofrag = qfrag and cache.ofrag and isinstance(self.attn2.to_out[0], nn.Linear)
+                blended = _ops.xattn_forward_proj(y, self._wq_fragments(), cache.packed_proj, cache.mask, c, self.attn2.scale, qfrag=qfrag, ofrag=ofrag)
+                if ofrag:
+                    # ... and to_out + the residual + norm3 are ONE pass over the kernel's out-fragment output: to_out's [2I, N, C]
+                    # result never reaches HBM either (csrc/sta_rowgemm.hip)
+                    lin = self.attn2.to_out[0]
+                    x, y = _fused.to_out_add_layernorm_ofrag(x, blended, self._wo_fragments(), lin.bias, n3.weight, n3.bias, n3.eps, self.attn2.heads)
+                    return self.ff(y) + x
             else:
                 q = self.attn2.to_q(y)
                 self._keep_maps(q, c, cache)
@@ -312,6 +321,14 @@ class BasicTransformerBlock(nn.Module):
         if getattr(self, "_wq_key", None) != key:
             self._wq_frag, self._wq_key = _ops.pack_wq(w, self.attn2.heads), key
         return self._wq_frag
+
+    def _wo_fragments(self):
+        """to_out.weight of attn2 as sta_to_out_ln_ofrag streams it, repacked only when the weight tensor changes."""
+        w = self.attn2.to_out[0].weight
+        key = (w.data_ptr(), w._version, w.dtype)
+        if getattr(self, "_wo_key", None) != key:
+            self._wo_frag, self._wo_key = _fused.pack_to_out_weight(w, self.attn2.heads), key
+        return self._wo_frag
 
     def _keep_maps(self, q, coef, cache):
         """Parity hook (off by default): the per-step attention maps are a local of the reference's forward

@@ -256,17 +256,69 @@ def from_qfrag(yf):
     return t.permute(0, 3, 1, 2, 4).contiguous().view(yf.shape)
 
 
-def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False):
+def _vrow_dim(r, hp):
+    """csrc/sta_xattn_proj3.h::vrow_dim — head dim held by row r of a head's V^T image (= O^T row r of the pair kernel)."""
+    return -1 if r == 40 else (r if r >= 32 else 8 * ((((r & 15) >> 2) + 3 * hp) & 3) + 4 * (r >> 4) + (r & 3))
+
+
+def ofrag_channels():
+    """[10, 4, 8] long tensor: channel (head * 40 + dim) behind slot j of lane row g of fragment f in OUT-FRAGMENT order
+    (csrc/sta_xattn_proj3.h::ofrag_channel restated on the host; C = 320, 8 heads)."""
+    t = torch.empty(10, 4, 8, dtype=torch.long)
+    for f in range(10):
+        for g in range(4):
+            for j in range(8):
+                if f < 8:
+                    hp, r = f & 1, (4 * g + j if j < 4 else 16 + 4 * g + (j - 4))
+                    t[f, g, j] = f * 40 + _vrow_dim(r, hp)
+                else:
+                    pr, hp, r = 2 * (f - 8) + (g >> 1), (0 if j < 4 else 1), 32 + 4 * (g & 1) + (j & 3)
+                    t[f, g, j] = (2 * pr + hp) * 40 + _vrow_dim(r, hp)
+    return t
+
+
+def from_ofrag(of):
+    """Out-fragment order (what sta_xattn_fwd_proj_qfrag_ofrag writes) -> row-major [..., N, 320]; tests and tools only."""
+    C = of.shape[-1]
+    rows = of.numel() // C
+    if C != 320 or rows % 16:
+        raise ValueError("out-fragment order: C = 320 and a multiple of 16 rows, got %s" % (tuple(of.shape),))
+    t = of.reshape(rows // 16, 10, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(rows // 16, 16, 320)     # [P, c, (f, g, j)]
+    idx = ofrag_channels().reshape(-1).to(of.device)
+    out = torch.empty_like(t)
+    out[..., idx] = t
+    return out.reshape(of.shape)
+
+
+def to_ofrag(x):
+    """Inverse of from_ofrag."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    idx = ofrag_channels().reshape(-1).to(x.device)
+    t = x.reshape(rows // 16, 16, 320)[..., idx].reshape(rows // 16, 16, 10, 4, 8).permute(0, 2, 3, 1, 4)
+    return t.contiguous().view(x.shape)
+
+
+def proj_ofrag_supported(C, heads):
+    """Shapes whose blended output the attention kernel can leave in out-fragment order for sta.fused.to_out_add_layernorm_ofrag."""
+    return bool(_lib.load().sta_to_out_ln_packed_wo_bytes(C, heads))
+
+
+def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofrag=False):
     """y [2I, N, C] = norm2(hidden) -> blended pre-projection output [2I, N, C]; the query projection happens inside
     the attention kernel (no autograd). `packed` comes from pack_kv_proj, `wq_packed` from pack_wq. `qfrag`: y is in
-    query-fragment order (fused.add_layernorm(..., qfrag=True) / to_qfrag); only where proj_qfrag_supported."""
+    query-fragment order (fused.add_layernorm(..., qfrag=True) / to_qfrag); only where proj_qfrag_supported. `ofrag`: the result
+    leaves in out-fragment order for fused.to_out_add_layernorm_ofrag (from_ofrag restores row-major)."""
     I, N, C, K = _check_inputs(y, packed, mask, coef)
     L = _lib.load()
     y = y.contiguous()
     coef32 = coef.detach().to(torch.float32).contiguous() if K else None
     maskc = mask.contiguous() if K else None
     out = torch.empty_like(y)
-    fn, name = (L.sta_xattn_fwd_proj_qfrag, "sta_xattn_fwd_proj_qfrag") if qfrag else (L.sta_xattn_fwd_proj, "sta_xattn_fwd_proj")
+    if ofrag and not qfrag:
+        raise ValueError("out-fragment order rides on the query-fragment path (qfrag=True)")
+    fn, name = (L.sta_xattn_fwd_proj_qfrag_ofrag, "sta_xattn_fwd_proj_qfrag_ofrag") if ofrag else \
+        (L.sta_xattn_fwd_proj_qfrag, "sta_xattn_fwd_proj_qfrag") if qfrag else (L.sta_xattn_fwd_proj, "sta_xattn_fwd_proj")
     def launch():
         _lib.check(fn(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
                       out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y), _stream(y)), name)

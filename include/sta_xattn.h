@@ -163,6 +163,31 @@ int sta_xattn_fwd_proj_qfrag(const void* y_frag, const void* packed_wq, const vo
                              const float* coef, void* out,
                              int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
 
+/*
+ * The chain's last private layout: sta_xattn_fwd_proj_qfrag_ofrag = sta_xattn_fwd_proj_qfrag whose OUTPUT leaves in
+ * OUT-FRAGMENT order, the MFMA B-operand order of sta_to_out_ln_ofrag below (per 16-pixel group and batch row ten 1-KiB
+ * fragments: [2 pr], [2 pr + 1] = heads 2 pr / 2 pr + 1 of pair pr, 32 channels each, [8 + q] = the 8 remaining channels of the
+ * four heads of pairs 2q, 2q + 1; csrc/sta_xattn_proj3.h::ofrag_channel names the channel behind every slot): every store
+ * instruction of the attention kernel is one contiguous KiB instead of 160-byte pair segments at a 640-byte stride. C = 320 only.
+ *
+ * sta_to_out_ln_ofrag — the rest of the block's cross-attention section in one pass (csrc/sta_rowgemm.hip):
+ *     s = x + blended . to_out.weight^T + to_out.bias          attention.py:215 (to_out), :294 (residual)
+ *     y = LayerNorm(s) * gamma + beta                           attention.py:299 (norm3, feeding ff)
+ * with `blended` read in out-fragment order and to_out's [R][C] result never written to HBM (row-major: a library GEMM that
+ * writes it + sta_add_layernorm that reads it back). The weight is re-laid out once per model by sta_to_out_ln_pack_wo
+ * (sta_to_out_ln_packed_wo_bytes(C, heads) bytes; 0 = unsupported: C = 320 with 8 heads only) and streamed through LDS.
+ *   x, s, y : [R][C] dtype, row-major (s: the new residual stream, rounded to dtype before it is normalised, as sta_add_layernorm does)
+ *   bias    : [C] dtype or NULL;  gamma, beta: [C] dtype;  R % 16 == 0
+ */
+int sta_xattn_fwd_proj_qfrag_ofrag(const void* y_frag, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                                   const float* coef, void* out_frag,
+                                   int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+size_t sta_to_out_ln_packed_wo_bytes(int C, int heads);
+int sta_to_out_ln_pack_wo(const void* wo, void* packed, int C, int heads, int dtype, void* stream);
+int sta_to_out_ln_ofrag(const void* blended_ofrag, const void* packed_wo, const void* bias, const void* x,
+                        const void* gamma, const void* beta, void* s, void* y,
+                        long R, int C, int heads, float eps, int dtype, void* stream);
+
 /* Bytes of fp32 workspace sta_xattn_bwd needs for the given shape (deterministic dcoef reduce). */
 size_t sta_xattn_bwd_workspace_bytes(int n_img, int N, int heads, int K);
 

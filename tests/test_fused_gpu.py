@@ -107,6 +107,42 @@ def test_add_layernorm_query_fragment_order(R, C, dtype, with_f, with_bias, stor
         assert rc == -1 and "qfrag" in lib.last_error()
 
 
+@pytest.mark.parametrize("R", [16, 128, 4096 + 48, 2 * 4096 * 3])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_to_out_add_layernorm_out_fragment_order(R, dtype, with_bias):
+    """sta_to_out_ln_ofrag (csrc/sta_rowgemm.hip): s = x + blended . W^T + bias, y = LayerNorm(s), with `blended` in the out-fragment
+    order of the head-pair attention kernel and W streamed through LDS, against fp64 torch on the same 16-bit inputs. Replaces
+    to_out (attention.py:215) + the residual + norm3 (:294-299). Row counts: one item, one pass, a partial last workgroup pass,
+    several passes per workgroup."""
+    from sta import fused, lib, ops
+    C, heads = 320, 8
+    g = torch.Generator().manual_seed(R)
+    bl = torch.randn(R, C, generator=g).to(dtype)
+    x = torch.randn(R, C, generator=g).to(dtype)
+    w = (torch.randn(C, C, generator=g) / C ** 0.5).to(dtype)
+    bias = (torch.randn(C, generator=g) * 0.3).to(dtype) if with_bias else None
+    lw = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dtype)
+    lb = (0.2 * torch.randn(C, generator=g)).to(dtype)
+    wo = fused.pack_to_out_weight(w.cuda(), heads)
+    s, y = fused.to_out_add_layernorm_ofrag(x.cuda(), ops.to_ofrag(bl.cuda()), wo, None if bias is None else bias.cuda(), lw.cuda(), lb.cuda(), 1e-5, heads)
+    torch.cuda.synchronize()
+    s_ref = x.double() + bl.double() @ w.double().t() + (bias.double() if with_bias else 0.0)
+    _close(s, s_ref.float(), dtype, k=1.0)
+    # the kernel normalises the ROUNDED sum (what the residual stream carries on), as sta_add_layernorm does
+    y_ref = F.layer_norm(s.float().cpu(), (C,), lw.float(), lb.float(), 1e-5)
+    _close(y, y_ref, dtype)
+    # and it is the same function as the unfused pair it replaces (library GEMM + sta_add_layernorm), up to the GEMM result's own rounding
+    s2, y2 = fused.add_layernorm(x.cuda(), F.linear(bl.cuda(), w.cuda(), None if bias is None else bias.cuda()), None, lw.cuda(), lb.cuda(), 1e-5)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert ((s.float() - s2.float()).abs() <= 4 * eps * (1.0 + s2.float().abs())).all()
+    L = lib.load()
+    assert L.sta_to_out_ln_packed_wo_bytes(640, 8) == 0 and L.sta_to_out_ln_packed_wo_bytes(320, 4) == 0
+    rc = L.sta_to_out_ln_ofrag(x.cuda().data_ptr(), wo.data_ptr(), 0, x.cuda().data_ptr(), lw.cuda().data_ptr(), lb.cuda().data_ptr(), s.data_ptr(), y.data_ptr(),
+                               R + 8, C, heads, 1e-5, lib.STA_F16, 0)
+    assert rc == -1 and "multiple of 16" in lib.last_error()
+
+
 @pytest.mark.parametrize("B,C,H", [(2, 320, 64), (3, 1280, 8), (2, 64, 12)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_add_bias_nchw(B, C, H, dtype):

@@ -656,6 +656,13 @@ def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
     if N % 16 == 0:
         out_f = ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True)
         assert torch.equal(out_f, out)
+        if ops.proj_ofrag_supported(C, heads):
+            # ... and leaving its output in OUT-FRAGMENT order (for the fused to_out + LayerNorm pass): the same values, permuted
+            out_o = ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True)
+            assert torch.equal(ops.from_ofrag(out_o), out)
+        else:
+            with pytest.raises(RuntimeError, match="C = 320"):
+                ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True)
     else:
         with pytest.raises(RuntimeError, match="N % 16"):
             ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale, qfrag=True)

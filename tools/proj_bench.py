@@ -68,15 +68,28 @@ def main():
     arms["pair"] = pair                     # a head pair per workgroup (sta_xattn_proj3.hip)
     if N % 16 == 0:
         yq = ops.to_qfrag(y)
+        from sta import fused
+        xs, fs = torch.randn_like(y), torch.randn_like(y)
+        lw, lb = torch.ones(C, device=dev, dtype=dt), torch.zeros(C, device=dev, dtype=dt)
         def pairq():
             lib.set_option(lib.OPT_PROJ_PAIR, 1)
             r = ops.xattn_forward_proj(yq, wqf, packed_p, mask, coef, scale, qfrag=True)
             lib.set_option(lib.OPT_PROJ_PAIR, 0)
             return r
         arms["pairq"] = pairq               # the same kernel reading y in query-fragment order
-        from sta import fused
-        xs, fs = torch.randn_like(y), torch.randn_like(y)
-        lw, lb = torch.ones(C, device=dev, dtype=dt), torch.zeros(C, device=dev, dtype=dt)
+        if C == 320:
+            def pairqo():
+                lib.set_option(lib.OPT_PROJ_PAIR, 1)
+                r = ops.xattn_forward_proj(yq, wqf, packed_p, mask, coef, scale, qfrag=True, ofrag=True)
+                lib.set_option(lib.OPT_PROJ_PAIR, 0)
+                return r
+            arms["pairqo"] = pairqo         # ... and writing its output in out-fragment order
+            wo = (torch.randn(C, C, generator=g) / C ** 0.5).to(dt).to(dev)
+            bo = torch.zeros(C, device=dev, dtype=dt)
+            wof = fused.pack_to_out_weight(wo, heads)
+            blo = ops.to_ofrag(y)
+            arms["toln_fused"] = lambda: fused.to_out_add_layernorm_ofrag(xs, blo, wof, bo, lw, lb, 1e-5, heads)      # to_out + residual + LayerNorm, one pass
+            arms["toln_gemm+ln"] = lambda: fused.add_layernorm(xs, torch.nn.functional.linear(y, wo, bo), None, lw, lb, 1e-5)   # what it replaces
         arms["ln"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5)                     # the producer pass, row-major y
         arms["lnq"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5, qfrag=True)        # ... query-fragment order
     if a.only:
