@@ -237,7 +237,7 @@ class BasicTransformerBlock(nn.Module):
             if k.is_cuda and _ops.proj_supported(k.shape[2], self.attn2.heads, k.shape[1], K, N=n, n_img=n_img):
                 cache.packed_proj = _ops.pack_kv_proj(k, v, self.attn2.heads, out=cache.packed_proj, n_img=n_img)
                 cache.qfrag = _ops.proj_qfrag_supported(k.shape[2], self.attn2.heads, k.shape[1], K, n, n_img)
-                cache.ofrag = cache.qfrag and _ops.proj_ofrag_supported(k.shape[2], self.attn2.heads)
+                cache.ofrag = cache.qfrag and _ops.proj_ofrag_supported(k.shape[2], self.attn2.heads, k.dtype)
             else:
                 cache.packed_proj, cache.qfrag, cache.ofrag = None, False, False
             if K:

@@ -649,6 +649,7 @@ def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
         lib.set_option(lib.OPT_STAGED_TILES, tiles)
     lib.set_option(lib.OPT_PROJ_PAIR, 1)
     wqf, kvp = ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I)
+    out_ofrag = None
     out = ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale)
     # the same launch reading y in QUERY-FRAGMENT order (what sta_add_layernorm_qfrag writes for it): same MFMAs on the same
     # values in the same order => bit-identical; N % 16 != 0 is refused
@@ -656,12 +657,14 @@ def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
     if N % 16 == 0:
         out_f = ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True)
         assert torch.equal(out_f, out)
-        if ops.proj_ofrag_supported(C, heads):
-            # ... and leaving its output in OUT-FRAGMENT order (for the fused to_out + LayerNorm pass): the same values, permuted
-            out_o = ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True)
-            assert torch.equal(ops.from_ofrag(out_o), out)
+        if ops.proj_ofrag_supported(C, heads, dtype):
+            # ... and leaving its output in OUT-FRAGMENT order (for the fused to_out + LayerNorm pass): the same values, permuted.
+            # (This equality is what caught hipcc 7.2 miscompiling the bf16 instantiation of that mode — a write-after-read hazard
+            # around the PV MFMAs, profiles/r04_level0.md section 5 — which the library therefore refuses.)
+            out_ofrag = ops.from_ofrag(ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True))
+            assert torch.equal(out_ofrag, out), (out_ofrag != out).float().mean().item()
         else:
-            with pytest.raises(RuntimeError, match="C = 320"):
+            with pytest.raises(RuntimeError, match="C = 320|fp16 only"):
                 ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True)
     else:
         with pytest.raises(RuntimeError, match="N % 16"):
@@ -684,6 +687,9 @@ def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
         ref = orc.fused_xattn(q16.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
         err = (a[2 * i:2 * i + 2].cpu().double() - ref).abs()
         assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item(), (err / (1.0 + ref.abs())).max().item() / eps)
+        if out_ofrag is not None:      # the out-fragment instantiation against the oracle, same bound
+            err = (out_ofrag[2 * i:2 * i + 2].float().cpu().double() - ref).abs()
+            assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
 
 
 def test_fwd_proj_rejects_what_it_cannot_hold():
