@@ -26,7 +26,7 @@ for cnt in ("FETCH_SIZE", "WRITE_SIZE"):
     d = "/tmp/pmck_%s" % cnt
     subprocess.run(["rm", "-rf", d])
     r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc", cnt, "-d", d, "-o", "k", "--", sys.executable, os.path.join(ROOT, "tools", "proj_bench.py"),
-                        "--only", "pairq", "--iters", "10", "--rounds", "1", "--imgs", str(a.imgs), "--dtype", a.dtype], cwd="/tmp", env=env,
+                        "--only", "pairqo", "--iters", "10", "--rounds", "1", "--imgs", str(a.imgs), "--dtype", a.dtype], cwd="/tmp", env=env,
                        capture_output=True, text=True)
     db = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("_results.db")]
     assert db, r.stderr[-2000:]
@@ -39,7 +39,7 @@ alg = a.imgs * (8 * N * C + 4 * (K + 2) * M * C + K * N) + 2 * C * C
 ent = {"kernel": kernel + " (to_q inside, a head pair per workgroup, y in query-fragment order), N=%d C=%d K=%d, %d images per launch" % (N, C, K, a.imgs),
        "raw_KiB": raw, "bytes_per_launch": (2 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024, "algorithmic_bytes": alg, "dtype": a.dtype,
        "source_sha": bench.source_sha(),
-       "how": "tools/pmc_traffic_kernel.py: separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/proj_bench.py --only pairq "
+       "how": "tools/pmc_traffic_kernel.py: separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/proj_bench.py --only pairqo "
               "(KiB per dispatch, average of 16 launches); FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md); round 4"}
 ent["ratio_to_algorithmic"] = round(ent["bytes_per_launch"] / alg, 4)
 src = os.path.join(ROOT, "profiles", "xattn_fwd_hbm_traffic.json")
