@@ -44,17 +44,24 @@ constexpr int RG_LDS = 2 * RG_SLOT + RG_TAB;
 
 __host__ __device__ constexpr int rg_sigma(int u, int rho) { return 32 * (u >> 1) + 8 * (rho >> 2) + 4 * (u & 1) + (rho & 3); }
 
+// Channel behind slot j of lane row g of fragment f of the SELF-attention kernel's out-fragment order (sta_selfattn_fwd_sfrag):
+// f < 8: head f, O^T rows 4g + j of tile 0 | 16 + 4g + (j - 4) of tile 1 (= head dims, no permutation there);
+// f >= 8: lane row g is head 4 (f - 8) + g, slots = its dims 32 .. 39.
+__host__ __device__ constexpr int sfrag_channel(int f, int g, int j) {
+  return f < 8 ? f * 40 + (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : (4 * (f - 8) + g) * 40 + 32 + j;
+}
+
 // to_out.weight [C out][C in] -> [chunk v][t][k-step f] fragments: lane (g, c) of fragment (u = 2v + t, f) holds
-// Wo[sigma(u, c)][ofrag_channel(f, g, 0 .. 7)]
+// Wo[sigma(u, c)][channel(f, g, 0 .. 7)], channel = ofrag_channel (kind 0: the cross-attention kernel's order) or sfrag_channel (kind 1)
 template <typename T>
-__global__ __launch_bounds__(64) void pack_wo_ofrag_kernel(const T* __restrict__ wo, T* __restrict__ packed) {
+__global__ __launch_bounds__(64) void pack_wo_ofrag_kernel(const T* __restrict__ wo, T* __restrict__ packed, int kind) {
   const int fr = blockIdx.x;               // (v * 2 + t) * NKS + f
   const int u = fr / RG_NKS, f = fr % RG_NKS;
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
   const int row = rg_sigma(u, c);
   T* dst = packed + (size_t)fr * (FRAG / 2) + lane * 8;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) dst[j] = wo[(size_t)row * RG_C + sta_p3::ofrag_channel(f, g, j)];
+  for (int j = 0; j < 8; ++j) dst[j] = wo[(size_t)row * RG_C + (kind ? sfrag_channel(f, g, j) : sta_p3::ofrag_channel(f, g, j))];
 }
 
 struct RG {
@@ -68,6 +75,7 @@ struct RG {
   void* y;              // [R][C] LayerNorm(s)
   long R;
   float eps;
+  int y_qfrag;          // 1: y leaves in QUERY-fragment order (it is norm2's output feeding sta_xattn_fwd_proj_qfrag*)
 };
 
 template <typename T>
@@ -196,7 +204,9 @@ __global__ __launch_bounds__(64 * RG_NW, 2) void to_out_ln_ofrag_kernel(const RG
       V8 o;
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[e] = (T)((acc[2 * v + (e >> 2)][e & 3] - mean) * rstd * (float)gm[e] + (float)bt[e]);
-      *(V8*)((T*)p.y + row * RG_C + 32 * v + 8 * g) = o;
+      // query-fragment order: tile pair v of lane (g, c) IS fragment v's lane 16 g + c (channels 32 v + 8 g .. + 7 of row c)
+      if (p.y_qfrag) *(V8*)((char*)p.y + (size_t)row0 * RG_C * sizeof(T) + v * FRAG + lane * 16) = o;
+      else *(V8*)((T*)p.y + row * RG_C + 32 * v + 8 * g) = o;
       __builtin_amdgcn_sched_barrier(0);
     }
     }
@@ -212,27 +222,28 @@ size_t sta_to_out_ln_packed_wo_bytes(int C, int heads) {
   return (C == RG_C && heads == 8) ? (size_t)RG_NRT * RG_NKS * FRAG : 0;
 }
 
-int sta_to_out_ln_pack_wo(const void* wo, void* packed, int C, int heads, int dtype, void* stream) {
+int sta_to_out_ln_pack_wo(const void* wo, void* packed, int C, int heads, int kind, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!wo || !packed) return sta_fail(STA_E_ARG, "null pointer");
   if (sta_to_out_ln_packed_wo_bytes(C, heads) == 0) return sta_fail(STA_E_UNSUP, "to_out + LayerNorm in out-fragment order: C = 320 with 8 heads only (C=%d heads=%d)", C, heads);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  if (kind != 0 && kind != 1) return sta_fail(STA_E_ARG, "fragment kind %d (0: cross-attention out fragments, 1: self-attention out fragments)", kind);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == STA_BF16) hipLaunchKernelGGL(pack_wo_ofrag_kernel<__bf16>, dim3(RG_NRT * RG_NKS), dim3(64), 0, st, (const __bf16*)wo, (__bf16*)packed);
-  else hipLaunchKernelGGL(pack_wo_ofrag_kernel<_Float16>, dim3(RG_NRT * RG_NKS), dim3(64), 0, st, (const _Float16*)wo, (_Float16*)packed);
+  if (dtype == STA_BF16) hipLaunchKernelGGL(pack_wo_ofrag_kernel<__bf16>, dim3(RG_NRT * RG_NKS), dim3(64), 0, st, (const __bf16*)wo, (__bf16*)packed, kind);
+  else hipLaunchKernelGGL(pack_wo_ofrag_kernel<_Float16>, dim3(RG_NRT * RG_NKS), dim3(64), 0, st, (const _Float16*)wo, (_Float16*)packed, kind);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_wo_ofrag launch: %s", hipGetErrorString(e));
 }
 
 int sta_to_out_ln_ofrag(const void* blended_ofrag, const void* packed_wo, const void* bias, const void* x, const void* gamma,
-                        const void* beta, void* s, void* y, long R, int C, int heads, float eps, int dtype, void* stream) {
+                        const void* beta, void* s, void* y, long R, int C, int heads, float eps, int y_qfrag, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!blended_ofrag || !packed_wo || !x || !gamma || !beta || !s || !y) return sta_fail(STA_E_ARG, "null pointer");
   if (sta_to_out_ln_packed_wo_bytes(C, heads) == 0) return sta_fail(STA_E_UNSUP, "to_out + LayerNorm in out-fragment order: C = 320 with 8 heads only (C=%d heads=%d)", C, heads);
   if (R <= 0 || R % 16) return sta_fail(STA_E_ARG, "to_out_ln_ofrag: R=%ld (need a positive multiple of 16 rows)", R);
   if ((size_t)R * C * 2 >= 0xfffffff0ull) return sta_fail(STA_E_UNSUP, "activations must stay below 4 GiB (R=%ld)", R);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
-  RG p{(const char*)blended_ofrag, (const char*)packed_wo, bias, gamma, beta, x, s, y, R, eps};
+  RG p{(const char*)blended_ofrag, (const char*)packed_wo, bias, gamma, beta, x, s, y, R, eps, y_qfrag ? 1 : 0};
   const long nblk = (R + 16 * RG_NW - 1) / (16 * RG_NW);
   const unsigned grid = (unsigned)(nblk < 256 ? nblk : 256);       // one persistent workgroup per CU
   hipStream_t st = (hipStream_t)stream;

@@ -29,6 +29,7 @@ struct SParams {
   long vt_rs, vt_bs;   // row (channel) and batch strides of vt in elements: [B][C][N] -> (N, C*N); [C][B*N] -> (B*N, N)
   float sl2e;       // scale * log2(e)
   float* lse;       // optional [B][H][N]: log2-domain log-sum-exp of the scaled scores (what the backward kernels re-derive P from)
+  int sfrag;        // 1: `out` leaves in self-attention out-fragment order (sta_selfattn_fwd_sfrag; d = 40, 8 heads, N % 16 == 0)
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem_sa[];
@@ -337,6 +338,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void selfattn_fwd_kernel(
       l = bfly_sum(lrun[qt]);
     }
     const float inv = 1.0f / l;
+    if constexpr (NDT == 3) {
+      if (p.sfrag) {
+        // Out-fragment order for sta_to_out_ln_ofrag (csrc/sta_rowgemm.hip): the wave's 16 pixels are one row group; head h's
+        // dims 0..31 are fragment h (lane (g, c): O^T rows 4g.. of tile 0 | tile 1 of pixel c — the accumulators as they are),
+        // its dims 32..39 one lane row of fragment 8 + h / 4 (lane rows 0, 1 store 8 bytes each). d = 40, N % 16 == 0.
+        if (px0 + 16 * qt >= N) continue;
+        char* gb = (char*)p.out + ((size_t)b * N + px0 + 16 * qt) * C * sizeof(T);
+        typename Tr<T>::V8 x8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { x8[r] = (T)(o[qt][0][r] * inv); x8[4 + r] = (T)(o[qt][1][r] * inv); }
+        *(typename Tr<T>::V8*)(gb + h * FRAG + lane * 16) = x8;
+        if (g < 2) {
+          V4 t4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t4[r] = (T)(o[qt][2][r] * inv);
+          *(V4*)(gb + (8 + (h >> 2)) * FRAG + (16 * (h & 3) + c16) * 16 + 8 * g) = t4;
+        }
+        if (p.lse && g == 0 && px < N) p.lse[((size_t)b * p.H + h) * N + px] = mrun[qt] * p.sl2e + __builtin_amdgcn_logf(l);
+        continue;
+      }
+    }
     if (px >= N) continue;
     if (p.lse && g == 0)                   // P = exp2(s * sl2e - lse): exact whether or not the running maximum is stale
       p.lse[((size_t)b * p.H + h) * N + px] = mrun[qt] * p.sl2e + __builtin_amdgcn_logf(l);
@@ -413,7 +435,7 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
 
 static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int N, int C,
                             int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
-                            void* stream) {
+                            void* stream, int sfrag = 0) {
   g_sta_err[0] = 0;
   if (!q || !k || !vt || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (B < 1 || B > 65535 || N < 8 || N % 8 || C <= 0 || heads <= 0 || C % heads)
@@ -426,7 +448,9 @@ static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* 
     return sta_fail(STA_E_ARG, "selfattn: vt strides (%ld, %ld) must be multiples of 8 with row stride >= N", vt_row_stride, vt_batch_stride);
   float sl2e = scale * 1.4426950408889634f;
   if (fabsf(sl2e - 1.0f) < 1e-6f) sl2e = 1.0f;       // scale = ln 2: q is already in log2 units (pre-scaled W_q) -> the PRE kernels
-  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, sl2e, lse};
+  if (sfrag && !(C == 320 && heads == 8 && N % 16 == 0))
+    return sta_fail(STA_E_UNSUP, "self-attention out-fragment order: C = 320 with 8 heads and N %% 16 == 0 (C=%d heads=%d N=%d)", C, heads, N);
+  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, sl2e, lse, sfrag};
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_sa<__bf16>(p, st) : dispatch_sa<_Float16>(p, st);
 }
@@ -442,4 +466,10 @@ extern "C" int sta_selfattn_fwd_lse(const void* q, const void* k, const void* vt
                                     void* stream) {
   if (!lse) return sta_fail(STA_E_ARG, "null pointer");
   return selfattn_fwd_any(q, k, vt, out, lse, B, N, C, heads, ldq, ldk, vt_row_stride, vt_batch_stride, scale, dtype, stream);
+}
+
+extern "C" int sta_selfattn_fwd_sfrag(const void* q, const void* k, const void* vt, void* out_frag, int B, int N, int C,
+                                      int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
+                                      void* stream) {
+  return selfattn_fwd_any(q, k, vt, out_frag, nullptr, B, N, C, heads, ldq, ldk, vt_row_stride, vt_batch_stride, scale, dtype, stream, 1);
 }

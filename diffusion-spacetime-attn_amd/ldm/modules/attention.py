@@ -118,8 +118,9 @@ class CrossAttention(nn.Module):
         o = _ops.SelfAttentionQKV.apply(F.linear(x, self._wqkv), self.heads, _ops.LN2)
         return self.to_out(o)
 
-    def _self_attention_hip(self, x):
-        """attn1 without autograd: the flash-style HIP kernel (csrc/sta_selfattn.hip). q and k come out of ONE
+    def _self_attention_hip(self, x, pre_to_out_sfrag=False):
+        """attn1 without autograd: the flash-style HIP kernel (csrc/sta_selfattn.hip). `pre_to_out_sfrag`: return the kernel's
+        output BEFORE to_out, in its out-fragment order (the block then runs to_out + residual + norm2 as one pass). q and k come out of ONE
         GEMM against the concatenated [Wq; Wk] (the kernel takes a row stride), V is produced already
         transposed because the PV product wants keys contiguous per channel: ONE plain GEMM W_v . X^T over the
         flattened batch gives [C, B*N], which the kernel reads through (row, batch) strides. (A batched
@@ -137,8 +138,8 @@ class CrossAttention(nn.Module):
         qk = F.linear(x, self._wqk)                                   # [B, N, 2C]
         b, n, _ = x.shape
         vt = torch.mm(self.to_v.weight, x.reshape(b * n, c).t()).view(c, b, n).permute(1, 0, 2)    # [B, C, N] view of [C, B*N]
-        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, _ops.LN2)
-        return self.to_out(o)
+        o = _ops.self_attention(qk[..., :c], qk[..., c:], vt, self.heads, _ops.LN2, sfrag=pre_to_out_sfrag)
+        return o if pre_to_out_sfrag else self.to_out(o)
 
 
     def _self_attention_hip_fp8(self, x):
@@ -277,7 +278,14 @@ class BasicTransformerBlock(nn.Module):
             # norm2's output has ONE consumer when to_q runs inside the attention kernel: the pass then writes it in the MFMA
             # operand order that kernel loads (query-fragment order, 1-KiB coalesced loads) instead of row-major
             qfrag = fused_q and cache.qfrag
-            x, y = _fused.add_layernorm(x, self.attn1(y), None, n2.weight, n2.bias, n2.eps, qfrag=qfrag)
+            a1 = self.attn1
+            if _ops.self_attention_sfrag_supported(y, a1.heads) and isinstance(a1.to_q, nn.Linear) and isinstance(a1.to_out[0], nn.Linear):
+                # level 0: the self-attention kernel leaves its output in out-fragment order and attn1.to_out + the residual + norm2
+                # are ONE pass over it (csrc/sta_rowgemm.hip) — to_out's result never reaches HBM, y leaves in the order its consumer wants
+                o = a1._self_attention_hip(y, pre_to_out_sfrag=True)
+                x, y = _fused.to_out_add_layernorm_ofrag(x, o, self._wo1_fragments(), a1.to_out[0].bias, n2.weight, n2.bias, n2.eps, a1.heads, y_qfrag=qfrag)
+            else:
+                x, y = _fused.add_layernorm(x, a1(y), None, n2.weight, n2.bias, n2.eps, qfrag=qfrag)
             if fused_q:
                 # to_q runs INSIDE the attention kernel: no [2I, N, C] query round trip through HBM
                 ofrag = qfrag and cache.ofrag and isinstance(self.attn2.to_out[0], nn.Linear)
@@ -321,6 +329,14 @@ class BasicTransformerBlock(nn.Module):
         if getattr(self, "_wq_key", None) != key:
             self._wq_frag, self._wq_key = _ops.pack_wq(w, self.attn2.heads), key
         return self._wq_frag
+
+    def _wo1_fragments(self):
+        """attn1.to_out.weight laid out for the self-attention kernel's out-fragment order."""
+        w = self.attn1.to_out[0].weight
+        key = (w.data_ptr(), w._version, w.dtype)
+        if getattr(self, "_wo1_key", None) != key:
+            self._wo1_frag, self._wo1_key = _fused.pack_to_out_weight(w, self.attn1.heads, _fused.FRAG_SELFATTN), key
+        return self._wo1_frag
 
     def _wo_fragments(self):
         """to_out.weight of attn2 as sta_to_out_ln_ofrag streams it, repacked only when the weight tensor changes."""

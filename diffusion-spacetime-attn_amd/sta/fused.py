@@ -134,8 +134,13 @@ def add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True, qfrag=Fal
     return s, y
 
 
-def pack_to_out_weight(weight, heads):
-    """to_out.weight [C, C] -> the fragment image sta_to_out_ln_ofrag streams through LDS (uint8 tensor); once per model."""
+FRAG_XATTN, FRAG_SELFATTN = 0, 1       # whose out-fragment order the packed weight's k-slots follow
+
+
+def pack_to_out_weight(weight, heads, kind=FRAG_XATTN):
+    """to_out.weight [C, C] -> the fragment image sta_to_out_ln_ofrag streams through LDS (uint8 tensor); once per model.
+    `kind`: the producer of the activations it will multiply — the cross-attention kernel (attn2.to_out) or the self-attention
+    kernel (attn1.to_out); their out-fragment orders differ."""
     C = weight.shape[0]
     L = lib.load()
     n = L.sta_to_out_ln_packed_wo_bytes(C, heads)
@@ -143,19 +148,21 @@ def pack_to_out_weight(weight, heads):
         raise ValueError("to_out + LayerNorm in out-fragment order: a square CUDA weight with C = 320, 8 heads; got %s heads=%d" % (tuple(weight.shape), heads))
     w = weight.detach().contiguous()
     buf = torch.empty(n, dtype=torch.uint8, device=w.device)
-    lib.check(L.sta_to_out_ln_pack_wo(w.data_ptr(), buf.data_ptr(), C, heads, _DT[w.dtype], _stream()), "sta_to_out_ln_pack_wo")
+    lib.check(L.sta_to_out_ln_pack_wo(w.data_ptr(), buf.data_ptr(), C, heads, int(kind), _DT[w.dtype], _stream()), "sta_to_out_ln_pack_wo")
     return buf
 
 
-def to_out_add_layernorm_ofrag(x, blended_ofrag, wo_packed, bias, ln_weight, ln_bias, eps, heads=8):
-    """s = x + blended . W_o^T + bias; returns (s, LayerNorm(s)) — `blended_ofrag` in the out-fragment order the head-pair
-    attention kernel writes (sta.ops.xattn_forward_proj(..., ofrag=True)); to_out's result never exists in HBM (csrc/sta_rowgemm.hip)."""
+def to_out_add_layernorm_ofrag(x, blended_ofrag, wo_packed, bias, ln_weight, ln_bias, eps, heads=8, y_qfrag=False):
+    """s = x + blended . W_o^T + bias; returns (s, LayerNorm(s)) — `blended_ofrag` in the out-fragment order of the kernel that
+    produced it (sta.ops.xattn_forward_proj(..., ofrag=True) or sta.ops.self_attention(..., sfrag=True); `wo_packed` packed for
+    that kind); to_out's result never exists in HBM (csrc/sta_rowgemm.hip). `y_qfrag`: LayerNorm(s) comes back in query-fragment
+    order (as add_layernorm(..., qfrag=True))."""
     C = x.shape[-1]
     R = x.numel() // C
     x = x.contiguous()
     s, y = torch.empty_like(x), torch.empty_like(x)
     lib.check(lib.load().sta_to_out_ln_ofrag(blended_ofrag.data_ptr(), wo_packed.data_ptr(), _ptr(bias), x.data_ptr(), ln_weight.data_ptr(),
-                                             ln_bias.data_ptr(), s.data_ptr(), y.data_ptr(), R, C, heads, float(eps), _DT[x.dtype], _stream()),
+                                             ln_bias.data_ptr(), s.data_ptr(), y.data_ptr(), R, C, heads, float(eps), int(bool(y_qfrag)), _DT[x.dtype], _stream()),
               "sta_to_out_ln_ofrag")
     return s, y
 

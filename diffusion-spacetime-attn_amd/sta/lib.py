@@ -54,8 +54,9 @@ SYMBOLS = {
     "sta_xattn_fwd_proj_qfrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_fwd_proj_qfrag_ofrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_to_out_ln_packed_wo_bytes": (_sz, [_i, _i]),
-    "sta_to_out_ln_pack_wo": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "sta_to_out_ln_ofrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _i, _vp]),
+    "sta_to_out_ln_pack_wo": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sta_to_out_ln_ofrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _f, _i, _i, _vp]),
+    "sta_selfattn_fwd_sfrag": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),

@@ -360,11 +360,43 @@ def xattn_blend(q, coef, packed, mask, scale):
 LN2 = 0.6931471805599453     # pass as `scale` when q is already multiplied by (softmax scale * log2 e): the kernel's log2-domain fast path
 
 
-def self_attention(q, k, vt, heads, scale):
+def sfrag_channels():
+    """[10, 4, 8] long tensor: channel behind slot j of lane row g of fragment f in the SELF-attention kernel's out-fragment order
+    (csrc/sta_rowgemm.hip::sfrag_channel restated; C = 320, 8 heads of 40)."""
+    t = torch.empty(10, 4, 8, dtype=torch.long)
+    for f in range(10):
+        for g in range(4):
+            for j in range(8):
+                t[f, g, j] = f * 40 + (4 * g + j if j < 4 else 16 + 4 * g + (j - 4)) if f < 8 else (4 * (f - 8) + g) * 40 + 32 + j
+    return t
+
+
+def from_sfrag(of):
+    """Self-attention out-fragment order -> row-major [B, N, 320]; tests and tools only."""
+    rows = of.numel() // 320
+    t = of.reshape(rows // 16, 10, 4, 16, 8).permute(0, 3, 1, 2, 4).reshape(rows // 16, 16, 320)
+    out = torch.empty_like(t)
+    out[..., sfrag_channels().reshape(-1).to(of.device)] = t
+    return out.reshape(of.shape)
+
+
+def to_sfrag(x):
+    rows = x.numel() // 320
+    t = x.reshape(rows // 16, 16, 320)[..., sfrag_channels().reshape(-1).to(x.device)].reshape(rows // 16, 16, 10, 4, 8).permute(0, 2, 3, 1, 4)
+    return t.contiguous().view(x.shape)
+
+
+def self_attention_sfrag_supported(x, heads):
+    B, N, C = x.shape
+    return self_attention_supported(x, heads) and C == 320 and heads == 8 and N % 16 == 0
+
+
+def self_attention(q, k, vt, heads, scale, sfrag=False):
     """Flash-style self-attention through the HIP kernel (inference only, no autograd).
     q, k: [B, N, C] (last dim contiguous; a row stride > C is allowed, e.g. slices of a fused QKV buffer);
     vt: [B, C, N] (V transposed), last dim contiguous, any batch / channel strides that are multiples of 8 — e.g.
-    the [C, B*N] result of ONE GEMM W_v . X^T viewed as [B, C, N]. Returns [B, N, C]."""
+    the [C, B*N] result of ONE GEMM W_v . X^T viewed as [B, C, N]. Returns [B, N, C]; `sfrag`: in the kernel's out-fragment order
+    (C = 320, 8 heads, N % 16 == 0) for sta.fused.to_out_add_layernorm_ofrag with a FRAG_SELFATTN weight."""
     B, N, C = q.shape
     if k.shape != q.shape or tuple(vt.shape) != (B, C, N):
         raise ValueError("shapes: q/k [B,N,C], vt [B,C,N]; got %s %s %s" % (tuple(q.shape), tuple(k.shape), tuple(vt.shape)))
@@ -377,9 +409,9 @@ def self_attention(q, k, vt, heads, scale):
         vt = vt.contiguous()
     out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
     L = _lib.load()
-    _lib.check(L.sta_selfattn_fwd(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, N, C, heads,
-                                  q.stride(1), k.stride(1), vt.stride(1), vt.stride(0), float(scale), _dtype_code(q), _stream(q)),
-               "sta_selfattn_fwd")
+    fn, name = (L.sta_selfattn_fwd_sfrag, "sta_selfattn_fwd_sfrag") if sfrag else (L.sta_selfattn_fwd, "sta_selfattn_fwd")
+    _lib.check(fn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, N, C, heads,
+                  q.stride(1), k.stride(1), vt.stride(1), vt.stride(0), float(scale), _dtype_code(q), _stream(q)), name)
     return out
 
 

@@ -183,10 +183,20 @@ int sta_xattn_fwd_proj_qfrag_ofrag(const void* y_frag, const void* packed_wq, co
                                    const float* coef, void* out_frag,
                                    int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
 size_t sta_to_out_ln_packed_wo_bytes(int C, int heads);
-int sta_to_out_ln_pack_wo(const void* wo, void* packed, int C, int heads, int dtype, void* stream);
+int sta_to_out_ln_pack_wo(const void* wo, void* packed, int C, int heads, int kind, int dtype, void* stream);
 int sta_to_out_ln_ofrag(const void* blended_ofrag, const void* packed_wo, const void* bias, const void* x,
                         const void* gamma, const void* beta, void* s, void* y,
-                        long R, int C, int heads, float eps, int dtype, void* stream);
+                        long R, int C, int heads, float eps, int y_qfrag, int dtype, void* stream);
+/*
+ * The same pass behind the SELF-attention of the block (attn1: attention.py:274 `x = attn1(norm1(x)) + x`, then norm2 at :279):
+ * sta_selfattn_fwd_sfrag = sta_selfattn_fwd whose output leaves in its own out-fragment order (per 16-pixel group ten 1-KiB
+ * fragments: [h] = dims 0..31 of head h, [8 + q] = dims 32..39 of heads 4q..4q+3, one lane row each; C = 320, 8 heads,
+ * N % 16 == 0), sta_to_out_ln_pack_wo(kind = 1) lays attn1.to_out.weight out for that order (kind = 0: the cross-attention
+ * kernel's), and y_qfrag = 1 makes sta_to_out_ln_ofrag write y = norm2(s) in QUERY-fragment order — the input layout of
+ * sta_xattn_fwd_proj_qfrag*: attn1.to_out's result and norm2's row-major output never exist in HBM either.
+ */
+int sta_selfattn_fwd_sfrag(const void* q, const void* k, const void* vt, void* out_frag, int B, int N, int C, int heads,
+                           int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype, void* stream);
 
 /* Bytes of fp32 workspace sta_xattn_bwd needs for the given shape (deterministic dcoef reduce). */
 size_t sta_xattn_bwd_workspace_bytes(int n_img, int N, int heads, int K);

@@ -136,10 +136,17 @@ def test_to_out_add_layernorm_out_fragment_order(R, dtype, with_bias):
     s2, y2 = fused.add_layernorm(x.cuda(), F.linear(bl.cuda(), w.cuda(), None if bias is None else bias.cuda()), None, lw.cuda(), lb.cuda(), 1e-5)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     assert ((s.float() - s2.float()).abs() <= 4 * eps * (1.0 + s2.float().abs())).all()
+    # the self-attention side of the block: the activations in the SELF-attention kernel's out-fragment order, the weight packed for
+    # it, and y = norm2(s) written in query-fragment order for the cross-attention kernel — the same values
+    wo1 = fused.pack_to_out_weight(w.cuda(), heads, fused.FRAG_SELFATTN)
+    s3, y3 = fused.to_out_add_layernorm_ofrag(x.cuda(), ops.to_sfrag(bl.cuda()), wo1, None if bias is None else bias.cuda(), lw.cuda(), lb.cuda(), 1e-5, heads,
+                                              y_qfrag=True)
+    torch.cuda.synchronize()
+    assert torch.equal(s3, s) and torch.equal(ops.from_qfrag(y3), y)
     L = lib.load()
     assert L.sta_to_out_ln_packed_wo_bytes(640, 8) == 0 and L.sta_to_out_ln_packed_wo_bytes(320, 4) == 0
     rc = L.sta_to_out_ln_ofrag(x.cuda().data_ptr(), wo.data_ptr(), 0, x.cuda().data_ptr(), lw.cuda().data_ptr(), lb.cuda().data_ptr(), s.data_ptr(), y.data_ptr(),
-                               R + 8, C, heads, 1e-5, lib.STA_F16, 0)
+                               R + 8, C, heads, 1e-5, 0, lib.STA_F16, 0)
     assert rc == -1 and "multiple of 16" in lib.last_error()
 
 

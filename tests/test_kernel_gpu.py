@@ -290,7 +290,8 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters, dtype):
                                           # d = 160 (SD-v1 levels 2 and mid at 512^2 / 768^2), 128, 112, 144
                                           (2, 256, 1280, 8), (4, 64, 1280, 8), (2, 576, 1280, 8), (2, 144, 1280, 8),
                                           (1, 128, 256, 2), (1, 72, 112, 1), (2, 192, 288, 2),
-                                          (2, 1096, 80, 2), (1, 1024, 96, 2)])      # d = 40 / 48 with a ragged / exact eight-wave tiling
+                                          (2, 1096, 80, 2), (1, 1024, 96, 2),       # d = 40 / 48 with a ragged / exact eight-wave tiling
+                                          (3, 272, 320, 8)])                        # C = 320, N % 16 == 0 but not % 32: a half-empty last wave tile
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_self_attention_matches_reference(B, N, C, heads, dtype):
     """Flash-style self-attention kernel (attn1) vs softmax(q k^T scale) v in fp64 on the same 16-bit inputs;
@@ -324,6 +325,16 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     ref3 = (torch.softmax(qs64 @ k64.transpose(-1, -2) * ops.LN2, -1) @ v64).transpose(1, 2).reshape(B, N, C)
     err3 = (out3.float().cpu().double() - ref3).abs()
     assert (err3 <= 4 * eps * (1.0 + ref3.abs())).all(), (err3.max(), ref3.abs().max())
+    if ops.self_attention_sfrag_supported(qk_d[..., :C], heads):
+        # the same launches leaving their output in the kernel's OUT-FRAGMENT order (for the fused to_out + residual + norm2 pass):
+        # identical values at permuted addresses
+        for q_, sc_, ref_ in ((qk_d[..., :C], scale, out), (qs.cuda(), ops.LN2, out3)):
+            o_f = ops.self_attention(q_, qk_d[..., C:], vt_d, heads, sc_, sfrag=True)
+            torch.cuda.synchronize()
+            assert torch.equal(ops.from_sfrag(o_f), ref_)
+    elif C != 320:
+        with pytest.raises(RuntimeError, match="C = 320"):
+            ops.self_attention(qk_d[..., :C], qk_d[..., C:], vt_d, heads, scale, sfrag=True)
     if d <= 48:
         # both geometries of the log2-domain kernel at d <= 48: four waves x two query tiles (three waves per SIMD, shipped) and
         # eight waves x one tile (four per SIMD; opt-in through STA_OPT_SELFATTN_WAVES)

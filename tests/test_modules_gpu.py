@@ -68,9 +68,12 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     blk = BasicTransformerBlock(C, heads, C // heads, context_dim=768, checkpoint=False)
     seeded_fill_(blk, seed)
     blk = blk.to("cuda", dtype)
-    calls = []
+    calls, tails = [], []
     real = ops.xattn_forward_proj
     monkeypatch.setattr(ops, "xattn_forward_proj", lambda *a, **k: (calls.append(k), real(*a, **k))[1])
+    from sta import fused
+    real_tail = fused.to_out_add_layernorm_ofrag
+    monkeypatch.setattr(fused, "to_out_add_layernorm_ofrag", lambda *a, **k: (tails.append(k.get("y_qfrag", False)), real_tail(*a, **k))[1])
     prompt_state.begin_prompt([c.cuda() for c in local_ctx], first_timestep=981)
     with torch.no_grad():
         out = blk(x.cuda().to(dtype), context=context.cuda().to(dtype), time=torch.tensor(981),
@@ -79,6 +82,9 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     assert [kw.get("qfrag", False) for kw in calls] == [pair], "query-fragment order is taken exactly by the head-pair launches"
     # C = 320 with 8 heads: the pair launch also hands its output over in out-fragment order to the fused to_out + norm3 pass
     assert [kw.get("ofrag", False) for kw in calls] == [pair and C == 320 and heads == 8 and dtype == torch.float16]
+    # the fused to_out + residual + LayerNorm pass: always behind attn1 at this shape (its y in query-fragment order exactly when the pair
+    # kernel consumes it), and behind attn2 when the attention kernel wrote out fragments
+    assert tails == [pair] + ([False] if pair and dtype == torch.float16 else [])
     ref = g["out"]
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     err = np.abs(out.float().cpu().numpy() - ref)
