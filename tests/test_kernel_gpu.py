@@ -327,11 +327,14 @@ def test_self_attention_matches_reference(B, N, C, heads, dtype):
     assert (err3 <= 4 * eps * (1.0 + ref3.abs())).all(), (err3.max(), ref3.abs().max())
     if ops.self_attention_sfrag_supported(qk_d[..., :C], heads):
         # the same launches leaving their output in the kernel's OUT-FRAGMENT order (for the fused to_out + residual + norm2 pass):
-        # identical values at permuted addresses
-        for q_, sc_, ref_ in ((qk_d[..., :C], scale, out), (qs.cuda(), ops.LN2, out3)):
-            o_f = ops.self_attention(q_, qk_d[..., C:], vt_d, heads, sc_, sfrag=True)
+        # the same values at permuted addresses — up to the last bit of a few in fp16, where hipcc fuses `o * (1 / l)` with the
+        # conversion in one epilogue (v_fma_mixlo_f16: one rounding) and not in the other (measured: 1e-5 of the values, 1 ulp)
+        for q_, sc_, ref_, ref64 in ((qk_d[..., :C], scale, out, ref), (qs.cuda(), ops.LN2, out3, ref3)):
+            o_f = ops.from_sfrag(ops.self_attention(q_, qk_d[..., C:], vt_d, heads, sc_, sfrag=True))
             torch.cuda.synchronize()
-            assert torch.equal(ops.from_sfrag(o_f), ref_)
+            assert (o_f != ref_).float().mean() < 1e-3 and ((o_f.float() - ref_.float()).abs() <= 2.0 ** -10 * ref_.float().abs() + 1e-12).all()
+            e_f = (o_f.float().cpu().double() - ref64).abs()
+            assert (e_f <= 4 * eps * (1.0 + ref64.abs())).all(), (e_f.max(), ref64.abs().max())
     elif C != 320:
         with pytest.raises(RuntimeError, match="C = 320"):
             ops.self_attention(qk_d[..., :C], qk_d[..., C:], vt_d, heads, scale, sfrag=True)
