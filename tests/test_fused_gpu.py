@@ -142,7 +142,11 @@ def test_to_out_add_layernorm_out_fragment_order(R, dtype, with_bias):
     s3, y3 = fused.to_out_add_layernorm_ofrag(x.cuda(), ops.to_sfrag(bl.cuda()), wo1, None if bias is None else bias.cuda(), lw.cuda(), lb.cuda(), 1e-5, heads,
                                               y_qfrag=True)
     torch.cuda.synchronize()
-    assert torch.equal(s3, s) and torch.equal(ops.from_qfrag(y3), y)
+    # (the k-slots of the MFMAs hold the channels in another order: the fp32 sums may differ in the last bit, so the two are held to
+    # the fp64 reference separately, not to each other)
+    _close(s3, s_ref.float(), dtype, k=1.0)
+    _close(ops.from_qfrag(y3), F.layer_norm(s3.float().cpu(), (C,), lw.float(), lb.float(), 1e-5), dtype)
+    assert (s3 != s).float().mean() < 0.02
     L = lib.load()
     assert L.sta_to_out_ln_packed_wo_bytes(640, 8) == 0 and L.sta_to_out_ln_packed_wo_bytes(320, 4) == 0
     rc = L.sta_to_out_ln_ofrag(x.cuda().data_ptr(), wo.data_ptr(), 0, x.cuda().data_ptr(), lw.cuda().data_ptr(), lb.cuda().data_ptr(), s.data_ptr(), y.data_ptr(),
