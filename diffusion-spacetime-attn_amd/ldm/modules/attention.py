@@ -275,11 +275,14 @@ class BasicTransformerBlock(nn.Module):
             s, y = _fused.add_layernorm(x, None, in_bias, n1.weight, n1.bias, n1.eps, store_sum=in_bias is not None)
             x = x if s is None else s
             fused_q = cache.packed_proj is not None and not self.keep_maps
+            # the GEGLU projection of the feed-forward as one pass over norm3's output in query-fragment order (csrc/sta_ffgemm.hip)
+            ffq = _fused.rowgemm_worthwhile(x) and self._ff_fusable(x)
             # norm2's output has ONE consumer when to_q runs inside the attention kernel: the pass then writes it in the MFMA
             # operand order that kernel loads (query-fragment order, 1-KiB coalesced loads) instead of row-major
             qfrag = fused_q and cache.qfrag
             a1 = self.attn1
-            if _ops.self_attention_sfrag_supported(y, a1.heads) and isinstance(a1.to_q, nn.Linear) and isinstance(a1.to_out[0], nn.Linear):
+            big = _fused.rowgemm_worthwhile(x)      # enough rows for the persistent row-GEMM passes to fill the chip
+            if big and _ops.self_attention_sfrag_supported(y, a1.heads) and isinstance(a1.to_q, nn.Linear) and isinstance(a1.to_out[0], nn.Linear):
                 # level 0: the self-attention kernel leaves its output in out-fragment order and attn1.to_out + the residual + norm2
                 # are ONE pass over it (csrc/sta_rowgemm.hip) — to_out's result never reaches HBM, y leaves in the order its consumer wants
                 o = a1._self_attention_hip(y, pre_to_out_sfrag=True)
@@ -294,14 +297,15 @@ class BasicTransformerBlock(nn.Module):
                     # ... and to_out + the residual + norm3 are ONE pass over the kernel's out-fragment output: to_out's [2I, N, C]
                     # result never reaches HBM either (csrc/sta_rowgemm.hip)
                     lin = self.attn2.to_out[0]
-                    x, y = _fused.to_out_add_layernorm_ofrag(x, blended, self._wo_fragments(), lin.bias, n3.weight, n3.bias, n3.eps, self.attn2.heads)
-                    return self.ff(y) + x
+                    x, y = _fused.to_out_add_layernorm_ofrag(x, blended, self._wo_fragments(), lin.bias, n3.weight, n3.bias, n3.eps, self.attn2.heads,
+                                                             y_qfrag=ffq)
+                    return self._ff_tail(x, y, ffq)
             else:
                 q = self.attn2.to_q(y)
                 self._keep_maps(q, c, cache)
                 blended = _ops.xattn_blend(q, c, cache.packed, cache.mask, self.attn2.scale)
-            x, y = _fused.add_layernorm(x, self.attn2.to_out(blended), None, n3.weight, n3.bias, n3.eps)
-            return self.ff(y) + x
+            x, y = _fused.add_layernorm(x, self.attn2.to_out(blended), None, n3.weight, n3.bias, n3.eps, qfrag=ffq)
+            return self._ff_tail(x, y, ffq)
         if _fused.tracked_usable(x):
             # tracked epochs (opt-in, fused.TRACKED): the residual adds run inside the LayerNorm passes as above, each pass an
             # autograd Function whose backward is one HIP input-gradient kernel (parameters are frozen)
@@ -329,6 +333,22 @@ class BasicTransformerBlock(nn.Module):
         if getattr(self, "_wq_key", None) != key:
             self._wq_frag, self._wq_key = _ops.pack_wq(w, self.attn2.heads), key
         return self._wq_frag
+
+    def _ff_fusable(self, x):
+        net = self.ff.net
+        return isinstance(net[0], GEGLU) and isinstance(net[0].proj, nn.Linear) and (x.numel() // x.shape[-1]) % 16 == 0 \
+            and _fused.ff_geglu_supported(x.shape[-1], net[0].proj.out_features // 2)
+
+    def _ff_tail(self, x, y, ffq):
+        """x + ff(y) (attention.py:299). `ffq`: y is in query-fragment order and the GEGLU projection runs as the fused pass."""
+        if not ffq:
+            return self.ff(y) + x
+        proj = self.ff.net[0].proj
+        key = (proj.weight.data_ptr(), proj.weight._version, proj.weight.dtype)
+        if getattr(self, "_w1_key", None) != key:
+            self._w1_frag, self._w1_key = _fused.pack_geglu_weight(proj.weight), key
+        h = _fused.ff_geglu_qfrag(y, self._w1_frag, proj.bias, proj.out_features // 2)
+        return self.ff.net[2](self.ff.net[1](h)) + x
 
     def _wo1_fragments(self):
         """attn1.to_out.weight laid out for the self-attention kernel's out-fragment order."""

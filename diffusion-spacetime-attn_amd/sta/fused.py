@@ -167,6 +167,43 @@ def to_out_add_layernorm_ofrag(x, blended_ofrag, wo_packed, bias, ln_weight, ln_
     return s, y
 
 
+# Rows from which the persistent row-GEMM passes (to_out + LayerNorm: 128 rows per workgroup pass; GEGLU projection: 256) fill the
+# chip: below it the library GEMM + the separate pass are taken (8 prompts per UNet call at 512^2 = 65536 rows at level 0).
+ROWGEMM_MIN_ROWS = 65536
+
+
+def rowgemm_worthwhile(x):
+    return x.numel() // x.shape[-1] >= ROWGEMM_MIN_ROWS
+
+
+def pack_geglu_weight(weight):
+    """GEGLU proj.weight [2 * inner, C] -> the fragment image sta_ff_geglu_qfrag streams through LDS (uint8 tensor); once per model."""
+    two_inner, C = weight.shape
+    L = lib.load()
+    n = L.sta_ff_geglu_packed_w_bytes(C, two_inner // 2)
+    if n == 0 or not weight.is_cuda:
+        raise ValueError("fused GEGLU projection: a CUDA weight [2560, 320]; got %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    buf = torch.empty(n, dtype=torch.uint8, device=w.device)
+    lib.check(L.sta_ff_geglu_pack_w(w.data_ptr(), buf.data_ptr(), C, two_inner // 2, _DT[w.dtype], _stream()), "sta_ff_geglu_pack_w")
+    return buf
+
+
+def ff_geglu_supported(C, inner):
+    return bool(lib.load().sta_ff_geglu_packed_w_bytes(C, inner))
+
+
+def ff_geglu_qfrag(y_qfrag, w_packed, bias, inner):
+    """h = (y W_v^T + b_v) * gelu(y W_g^T + b_g) with y in query-fragment order ([.., C] container); returns h [.., inner] row-major.
+    The [.., 2 * inner] projection never exists in HBM (csrc/sta_ffgemm.hip)."""
+    C = y_qfrag.shape[-1]
+    R = y_qfrag.numel() // C
+    h = torch.empty(*y_qfrag.shape[:-1], inner, dtype=y_qfrag.dtype, device=y_qfrag.device)
+    lib.check(lib.load().sta_ff_geglu_qfrag(y_qfrag.data_ptr(), w_packed.data_ptr(), _ptr(bias), h.data_ptr(), R, C, inner, _DT[y_qfrag.dtype], _stream()),
+              "sta_ff_geglu_qfrag")
+    return h
+
+
 def add_bias_nchw(a, b=None, bias=None):
     """a + b + bias[None, :, None, None] over 4-D activations (both NCHW-contiguous or both channels_last)."""
     B, C = a.shape[0], a.shape[1]

@@ -58,6 +58,20 @@ int sta_add_layernorm_qfrag(const void* x, const void* f, const void* bias, cons
                             void* s, void* y, long R, int C, float eps, int dtype, void* stream);
 
 /*
+ * The first half of the block's feed-forward in one pass (csrc/sta_ffgemm.hip):
+ *     h = (y W_v^T + b_v) * gelu(y W_g^T + b_g)      GEGLU.forward (attention.py:42-45), exact-erf GELU as sta_geglu
+ * y = norm3(x) read in QUERY-FRAGMENT order (sta_add_layernorm_qfrag / sta_to_out_ln_ofrag with y_qfrag), proj.weight
+ * [2 * inner][C] re-laid out once per model by sta_ff_geglu_pack_w (sta_ff_geglu_packed_w_bytes bytes; 0 = unsupported:
+ * C = 320, inner = 1280 only) and streamed through LDS; the [R][2 * inner] projection never exists in HBM (row-major: a library
+ * GEMM that writes it + sta_geglu that reads it back).
+ *   bias: [2 * inner] dtype (value half, then gate half) or NULL;  h: [R][inner] dtype row-major;  R % 16 == 0
+ */
+size_t sta_ff_geglu_packed_w_bytes(int C, int inner);
+int sta_ff_geglu_pack_w(const void* w, void* packed, int C, int inner, int dtype, void* stream);
+int sta_ff_geglu_qfrag(const void* y_qfrag, const void* packed_w, const void* bias, void* h, long R, int C, int inner,
+                       int dtype, void* stream);
+
+/*
  * y = a + b + bias[c]  over NCHW tensors [B][C][HW] (HW % 8 == 0); b and/or bias may be NULL.
  * Replaces a convolution's separate bias pass plus the residual add that follows it
  * (`skip_connection(x) + out_layers(h)`, openaimodel.py ResBlock._forward; `proj_out(x) + x_in`, attention.py:346).

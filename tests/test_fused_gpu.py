@@ -154,6 +154,35 @@ def test_to_out_add_layernorm_out_fragment_order(R, dtype, with_bias):
     assert rc == -1 and "multiple of 16" in lib.last_error()
 
 
+@pytest.mark.parametrize("R", [16, 256, 4096 + 48, 256 * 9])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("with_bias", [True, False])
+def test_ff_geglu_query_fragment_order(R, dtype, with_bias):
+    """sta_ff_geglu_qfrag (csrc/sta_ffgemm.hip): h = (y Wv^T + bv) * gelu(y Wg^T + bg) from y in query-fragment order, the weight
+    streamed through LDS, against fp64 torch on the same 16-bit inputs (exact-erf GELU). Replaces GEGLU.forward's projection GEMM +
+    chunk + gelu + mul (attention.py:42-45). Row counts: one item, one pass, a ragged last pass, several passes per workgroup."""
+    from sta import fused, lib, ops
+    C, inner = 320, 1280
+    g = torch.Generator().manual_seed(R + 7)
+    y = torch.randn(R, C, generator=g).to(dtype)
+    w = (torch.randn(2 * inner, C, generator=g) / C ** 0.5).to(dtype)
+    bias = (torch.randn(2 * inner, generator=g) * 0.3).to(dtype) if with_bias else None
+    wp = fused.pack_geglu_weight(w.cuda())
+    h = fused.ff_geglu_qfrag(ops.to_qfrag(y.cuda()), wp, None if bias is None else bias.cuda(), inner)
+    torch.cuda.synchronize()
+    proj = y.double() @ w.double().t() + (bias.double() if with_bias else 0.0)
+    ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+    _close(h, ref.float(), dtype, k=2.0)
+    # and against the pair it replaces (library GEMM rounding its result to 16 bit, then sta_geglu)
+    h2 = fused.geglu(F.linear(y.cuda(), w.cuda(), None if bias is None else bias.cuda()))
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert ((h.float() - h2.float()).abs() <= 16 * eps * (1.0 + h2.float().abs())).all()
+    L = lib.load()
+    assert L.sta_ff_geglu_packed_w_bytes(640, 2560) == 0 and L.sta_ff_geglu_packed_w_bytes(320, 640) == 0
+    rc = L.sta_ff_geglu_qfrag(h.data_ptr(), wp.data_ptr(), 0, h.data_ptr(), R + 8, C, inner, lib.STA_F16, 0)
+    assert rc == -1 and "multiple of 16" in lib.last_error()
+
+
 @pytest.mark.parametrize("B,C,H", [(2, 320, 64), (3, 1280, 8), (2, 64, 12)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_add_bias_nchw(B, C, H, dtype):

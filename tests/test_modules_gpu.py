@@ -60,6 +60,8 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     from ldm.modules.attention import BasicTransformerBlock
     from sta import lib, ops, prompt_state
     monkeypatch.setattr(ops, "PROJ_MIN_WORKGROUPS", 0)
+    from sta import fused as fused_
+    monkeypatch.setattr(fused_, "ROWGEMM_MIN_ROWS", 0 if pair else 1 << 40)      # pair: every fused row-GEMM pass of level 0 as well
     if pair:
         lib.set_option(lib.OPT_PROJ_PAIR, 1)          # reset after the test by conftest
     g = _load("block_d40.npz")
@@ -74,6 +76,8 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     from sta import fused
     real_tail = fused.to_out_add_layernorm_ofrag
     monkeypatch.setattr(fused, "to_out_add_layernorm_ofrag", lambda *a, **k: (tails.append(k.get("y_qfrag", False)), real_tail(*a, **k))[1])
+    ffs, real_ff = [], fused.ff_geglu_qfrag
+    monkeypatch.setattr(fused, "ff_geglu_qfrag", lambda *a, **k: (ffs.append(1), real_ff(*a, **k))[1])
     prompt_state.begin_prompt([c.cuda() for c in local_ctx], first_timestep=981)
     with torch.no_grad():
         out = blk(x.cuda().to(dtype), context=context.cuda().to(dtype), time=torch.tensor(981),
@@ -84,7 +88,9 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     assert [kw.get("ofrag", False) for kw in calls] == [pair and C == 320 and heads == 8 and dtype == torch.float16]
     # the fused to_out + residual + LayerNorm pass: always behind attn1 at this shape (its y in query-fragment order exactly when the pair
     # kernel consumes it), and behind attn2 when the attention kernel wrote out fragments
-    assert tails == [pair] + ([False] if pair and dtype == torch.float16 else [])
+    # (y_qfrag of the second one: its consumer is the fused GEGLU projection)
+    assert tails == ([True] + ([True] if dtype == torch.float16 else []) if pair else [])
+    assert ffs == ([1] if pair else [])
     ref = g["out"]
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     err = np.abs(out.float().cpu().numpy() - ref)

@@ -90,6 +90,12 @@ def main():
             blo = ops.to_ofrag(y)
             arms["toln_fused"] = lambda: fused.to_out_add_layernorm_ofrag(xs, blo, wof, bo, lw, lb, 1e-5, heads)      # to_out + residual + LayerNorm, one pass
             arms["toln_gemm+ln"] = lambda: fused.add_layernorm(xs, torch.nn.functional.linear(y, wo, bo), None, lw, lb, 1e-5)   # what it replaces
+        if C == 320:
+            w1 = (torch.randn(2560, C, generator=g) / C ** 0.5).to(dt).to(dev)
+            b1 = torch.zeros(2560, device=dev, dtype=dt)
+            w1f = fused.pack_geglu_weight(w1)
+            arms["ff1_fused"] = lambda: fused.ff_geglu_qfrag(yq, w1f, b1, 1280)                              # GEGLU projection + gelu * mul, one pass
+            arms["ff1_gemm+geglu"] = lambda: fused.geglu(torch.nn.functional.linear(y, w1, b1))              # what it replaces
         arms["ln"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5)                     # the producer pass, row-major y
         arms["lnq"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5, qfrag=True)        # ... query-fragment order
     if a.only:
