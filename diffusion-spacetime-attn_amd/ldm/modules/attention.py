@@ -347,8 +347,16 @@ class BasicTransformerBlock(nn.Module):
         key = (proj.weight.data_ptr(), proj.weight._version, proj.weight.dtype)
         if getattr(self, "_w1_key", None) != key:
             self._w1_frag, self._w1_key = _fused.pack_geglu_weight(proj.weight), key
+        out = self.ff.net[2]
+        if isinstance(out, nn.Linear):
+            # ... and the output Linear + the block's last residual as one pass over h in fragment order (net[1] is Dropout(0))
+            key2 = (out.weight.data_ptr(), out.weight._version, out.weight.dtype)
+            if getattr(self, "_w2_key", None) != key2:
+                self._w2_frag, self._w2_key = _fused.pack_ff_out_weight(out.weight), key2
+            h = _fused.ff_geglu_qfrag(y, self._w1_frag, proj.bias, proj.out_features // 2, h_frag=True)
+            return _fused.ff_out_res_hfrag(x, h, self._w2_frag, out.bias)
         h = _fused.ff_geglu_qfrag(y, self._w1_frag, proj.bias, proj.out_features // 2)
-        return self.ff.net[2](self.ff.net[1](h)) + x
+        return out(self.ff.net[1](h)) + x
 
     def _wo1_fragments(self):
         """attn1.to_out.weight laid out for the self-attention kernel's out-fragment order."""

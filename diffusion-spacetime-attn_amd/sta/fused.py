@@ -193,15 +193,39 @@ def ff_geglu_supported(C, inner):
     return bool(lib.load().sta_ff_geglu_packed_w_bytes(C, inner))
 
 
-def ff_geglu_qfrag(y_qfrag, w_packed, bias, inner):
-    """h = (y W_v^T + b_v) * gelu(y W_g^T + b_g) with y in query-fragment order ([.., C] container); returns h [.., inner] row-major.
-    The [.., 2 * inner] projection never exists in HBM (csrc/sta_ffgemm.hip)."""
+def ff_geglu_qfrag(y_qfrag, w_packed, bias, inner, h_frag=False):
+    """h = (y W_v^T + b_v) * gelu(y W_g^T + b_g) with y in query-fragment order ([.., C] container); returns h [.., inner], row-major
+    or (`h_frag`) in the fragment order ff_out_res_hfrag reads. The [.., 2 * inner] projection never exists in HBM (csrc/sta_ffgemm.hip)."""
     C = y_qfrag.shape[-1]
     R = y_qfrag.numel() // C
     h = torch.empty(*y_qfrag.shape[:-1], inner, dtype=y_qfrag.dtype, device=y_qfrag.device)
-    lib.check(lib.load().sta_ff_geglu_qfrag(y_qfrag.data_ptr(), w_packed.data_ptr(), _ptr(bias), h.data_ptr(), R, C, inner, _DT[y_qfrag.dtype], _stream()),
-              "sta_ff_geglu_qfrag")
+    lib.check(lib.load().sta_ff_geglu_qfrag(y_qfrag.data_ptr(), w_packed.data_ptr(), _ptr(bias), h.data_ptr(), R, C, inner, int(bool(h_frag)),
+                                            _DT[y_qfrag.dtype], _stream()), "sta_ff_geglu_qfrag")
     return h
+
+
+def pack_ff_out_weight(weight):
+    """FeedForward net[2].weight [C, inner] -> the fragment image sta_ff_out_res_hfrag streams through LDS; once per model."""
+    C, inner = weight.shape
+    L = lib.load()
+    n = L.sta_ff_out_packed_w_bytes(C, inner)
+    if n == 0 or not weight.is_cuda:
+        raise ValueError("fused feed-forward output: a CUDA weight [320, 1280]; got %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    buf = torch.empty(n, dtype=torch.uint8, device=w.device)
+    lib.check(L.sta_ff_out_pack_w(w.data_ptr(), buf.data_ptr(), C, inner, _DT[w.dtype], _stream()), "sta_ff_out_pack_w")
+    return buf
+
+
+def ff_out_res_hfrag(x, h_frag, w_packed, bias):
+    """x + h W2^T + b2 with h in fragment order (ff_geglu_qfrag(..., h_frag=True)); one pass (csrc/sta_ffgemm.hip)."""
+    C, inner = x.shape[-1], h_frag.shape[-1]
+    R = x.numel() // C
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    lib.check(lib.load().sta_ff_out_res_hfrag(h_frag.data_ptr(), w_packed.data_ptr(), _ptr(bias), x.data_ptr(), out.data_ptr(), R, C, inner,
+                                              _DT[x.dtype], _stream()), "sta_ff_out_res_hfrag")
+    return out
 
 
 def add_bias_nchw(a, b=None, bias=None):

@@ -68,7 +68,10 @@ SYMBOLS = {
     "sta_add_layernorm_qfrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _f, _i, _vp]),
     "sta_ff_geglu_packed_w_bytes": (_sz, [_i, _i]),
     "sta_ff_geglu_pack_w": (_i, [_vp, _vp, _i, _i, _i, _vp]),
-    "sta_ff_geglu_qfrag": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "sta_ff_geglu_qfrag": (_i, [_vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _vp]),
+    "sta_ff_out_packed_w_bytes": (_sz, [_i, _i]),
+    "sta_ff_out_pack_w": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sta_ff_out_res_hfrag": (_i, [_vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "sta_add_bias_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sta_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sta_groupnorm_silu_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),

@@ -64,12 +64,26 @@ int sta_add_layernorm_qfrag(const void* x, const void* f, const void* bias, cons
  * [2 * inner][C] re-laid out once per model by sta_ff_geglu_pack_w (sta_ff_geglu_packed_w_bytes bytes; 0 = unsupported:
  * C = 320, inner = 1280 only) and streamed through LDS; the [R][2 * inner] projection never exists in HBM (row-major: a library
  * GEMM that writes it + sta_geglu that reads it back).
- *   bias: [2 * inner] dtype (value half, then gate half) or NULL;  h: [R][inner] dtype row-major;  R % 16 == 0
+ *   bias: [2 * inner] dtype (value half, then gate half) or NULL;  h: [R][inner] dtype, row-major (h_frag = 0) or in the
+ *   fragment order of sta_ff_out_res_hfrag (h_frag = 1);  R % 16 == 0
  */
 size_t sta_ff_geglu_packed_w_bytes(int C, int inner);
 int sta_ff_geglu_pack_w(const void* w, void* packed, int C, int inner, int dtype, void* stream);
 int sta_ff_geglu_qfrag(const void* y_qfrag, const void* packed_w, const void* bias, void* h, long R, int C, int inner,
-                       int dtype, void* stream);
+                       int h_frag, int dtype, void* stream);
+/*
+ * ... and the second half with the block's last residual (attention.py:66-69 and the `+ x` of :299):
+ *     out = x + h W2^T + b2
+ * h read in FRAGMENT order (sta_ff_geglu_qfrag with h_frag = 1: per 16-row group inner/32 fragments of 1 KiB, lane 16 g + c =
+ * row c, channels 32 s + 8 g .. + 7 — one contiguous KiB per store of the first kernel, one coalesced load of this one);
+ * net[2].weight [C][inner] re-laid out once by sta_ff_out_pack_w (sta_ff_out_packed_w_bytes bytes; C = 320, inner = 1280 only).
+ * Row-major this is a library GEMM + a separate residual add; here h crosses HBM once in each direction as whole KiB.
+ *   bias: [C] or NULL;  x, out: [R][C] dtype row-major;  R % 16 == 0
+ */
+size_t sta_ff_out_packed_w_bytes(int C, int inner);
+int sta_ff_out_pack_w(const void* w, void* packed, int C, int inner, int dtype, void* stream);
+int sta_ff_out_res_hfrag(const void* h_frag, const void* packed_w, const void* bias, const void* x, void* out, long R, int C,
+                         int inner, int dtype, void* stream);
 
 /*
  * y = a + b + bias[c]  over NCHW tensors [B][C][HW] (HW % 8 == 0); b and/or bias may be NULL.

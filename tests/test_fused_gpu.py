@@ -177,9 +177,19 @@ def test_ff_geglu_query_fragment_order(R, dtype, with_bias):
     h2 = fused.geglu(F.linear(y.cuda(), w.cuda(), None if bias is None else bias.cuda()))
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     assert ((h.float() - h2.float()).abs() <= 16 * eps * (1.0 + h2.float().abs())).all()
+    # h in fragment order + the second half of the feed-forward with the block's residual (sta_ff_out_res_hfrag): out = x + h W2^T + b2
+    hf = fused.ff_geglu_qfrag(ops.to_qfrag(y.cuda()), wp, None if bias is None else bias.cuda(), inner, h_frag=True)
+    assert torch.equal(ops.from_qfrag(hf), h)                       # the same values; h's fragment order is query-fragment order at C = inner
+    x = torch.randn(R, C, generator=g).to(dtype)
+    w2 = (torch.randn(C, inner, generator=g) / inner ** 0.5).to(dtype)
+    b2 = (torch.randn(C, generator=g) * 0.3).to(dtype) if with_bias else None
+    out = fused.ff_out_res_hfrag(x.cuda(), hf, fused.pack_ff_out_weight(w2.cuda()), None if b2 is None else b2.cuda())
+    torch.cuda.synchronize()
+    ref2 = x.double() + h.double().cpu() @ w2.double().t() + (b2.double() if with_bias else 0.0)
+    _close(out, ref2.float(), dtype, k=1.0)
     L = lib.load()
-    assert L.sta_ff_geglu_packed_w_bytes(640, 2560) == 0 and L.sta_ff_geglu_packed_w_bytes(320, 640) == 0
-    rc = L.sta_ff_geglu_qfrag(h.data_ptr(), wp.data_ptr(), 0, h.data_ptr(), R + 8, C, inner, lib.STA_F16, 0)
+    assert L.sta_ff_geglu_packed_w_bytes(640, 2560) == 0 and L.sta_ff_geglu_packed_w_bytes(320, 640) == 0 and L.sta_ff_out_packed_w_bytes(640, 2560) == 0
+    rc = L.sta_ff_geglu_qfrag(h.data_ptr(), wp.data_ptr(), 0, h.data_ptr(), R + 8, C, inner, 0, lib.STA_F16, 0)
     assert rc == -1 and "multiple of 16" in lib.last_error()
 
 

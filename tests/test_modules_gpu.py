@@ -76,8 +76,9 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     from sta import fused
     real_tail = fused.to_out_add_layernorm_ofrag
     monkeypatch.setattr(fused, "to_out_add_layernorm_ofrag", lambda *a, **k: (tails.append(k.get("y_qfrag", False)), real_tail(*a, **k))[1])
-    ffs, real_ff = [], fused.ff_geglu_qfrag
+    ffs, real_ff, real_ff2 = [], fused.ff_geglu_qfrag, fused.ff_out_res_hfrag
     monkeypatch.setattr(fused, "ff_geglu_qfrag", lambda *a, **k: (ffs.append(1), real_ff(*a, **k))[1])
+    monkeypatch.setattr(fused, "ff_out_res_hfrag", lambda *a, **k: (ffs.append(2), real_ff2(*a, **k))[1])
     prompt_state.begin_prompt([c.cuda() for c in local_ctx], first_timestep=981)
     with torch.no_grad():
         out = blk(x.cuda().to(dtype), context=context.cuda().to(dtype), time=torch.tensor(981),
@@ -90,7 +91,7 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     # kernel consumes it), and behind attn2 when the attention kernel wrote out fragments
     # (y_qfrag of the second one: its consumer is the fused GEGLU projection)
     assert tails == ([True] + ([True] if dtype == torch.float16 else []) if pair else [])
-    assert ffs == ([1] if pair else [])
+    assert ffs == ([1, 2] if pair else [])          # both halves of the feed-forward as fused passes
     ref = g["out"]
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     err = np.abs(out.float().cpu().numpy() - ref)

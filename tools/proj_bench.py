@@ -96,6 +96,14 @@ def main():
             w1f = fused.pack_geglu_weight(w1)
             arms["ff1_fused"] = lambda: fused.ff_geglu_qfrag(yq, w1f, b1, 1280)                              # GEGLU projection + gelu * mul, one pass
             arms["ff1_gemm+geglu"] = lambda: fused.geglu(torch.nn.functional.linear(y, w1, b1))              # what it replaces
+            w2 = (torch.randn(C, 1280, generator=g) / 1280 ** 0.5).to(dt).to(dev)
+            b2 = torch.zeros(C, device=dev, dtype=dt)
+            w2f = fused.pack_ff_out_weight(w2)
+            hrm = fused.ff_geglu_qfrag(yq, w1f, b1, 1280)
+            hfr = fused.ff_geglu_qfrag(yq, w1f, b1, 1280, h_frag=True)
+            arms["ff1_fused_hfrag"] = lambda: fused.ff_geglu_qfrag(yq, w1f, b1, 1280, h_frag=True)
+            arms["ff2_fused"] = lambda: fused.ff_out_res_hfrag(xs, hfr, w2f, b2)                              # output Linear + residual, one pass
+            arms["ff2_gemm+add"] = lambda: torch.nn.functional.linear(hrm, w2, b2) + xs                       # what it replaces
         arms["ln"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5)                     # the producer pass, row-major y
         arms["lnq"] = lambda: fused.add_layernorm(xs, fs, None, lw, lb, 1e-5, qfrag=True)        # ... query-fragment order
     if a.only:
