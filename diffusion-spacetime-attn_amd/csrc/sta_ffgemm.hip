@@ -36,16 +36,19 @@ constexpr int FF_SLOT = FF_SC_FR * FRAG;       // 40 KiB
 constexpr int FF_TAB = 2 * FF_INNER * 2;       // bias (value | gate) as 16-bit behind the ring
 constexpr int FF_LDS = 2 * FF_SLOT + FF_TAB;
 
-__device__ __forceinline__ float ff_gelu_erf(float g) {      // = gelu_erf of csrc/sta_unet.hip (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7)
-  const float x = fabsf(g) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, x, 1.0f));
-  float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-  p = __builtin_fmaf(p, t, 1.421413741f);
-  p = __builtin_fmaf(p, t, -0.284496736f);
-  p = __builtin_fmaf(p, t, 0.254829592f);
-  const float e = p * t * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);
-  const float phi = g >= 0.f ? 1.0f - 0.5f * e : 0.5f * e;
-  return g * phi;
+// Exact-erf GELU, the formula of csrc/sta_unet.hip::gelu_erf (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 on erf) with the
+// constants folded and the sign handled without a select — gelu(g) = max(g, 0) - |g| * (0.5 * (1 - erf(|g| / sqrt 2))):
+// a reciprocal, an exp2 and 11 plain vector instructions per value instead of 16 (|g| is an operand modifier): this kernel's
+// vector-issue port is as loaded as its matrix pipe. Max |difference| to the fp64 GELU on [-12, 12]: 5.2e-7.
+__device__ __forceinline__ float ff_gelu_erf(float g) {
+  const float a = fabsf(g);
+  const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752f, a, 1.0f));
+  float p = __builtin_fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = __builtin_fmaf(p, t, 0.5f * 1.421413741f);
+  p = __builtin_fmaf(p, t, 0.5f * -0.284496736f);
+  p = __builtin_fmaf(p, t, 0.5f * 0.254829592f);
+  const float e = (p * t) * __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * g * g);      // 0.5 * (1 - erf(|g| / sqrt 2))
+  return __builtin_fmaf(-a, e, fmaxf(g, 0.f));
 }
 
 // proj.weight [2 * inner][C] (rows 0 .. inner-1: value, inner ..: gate) -> [sub-chunk v][part][t][k-step f] fragments:
