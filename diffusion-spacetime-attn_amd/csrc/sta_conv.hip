@@ -1,0 +1,312 @@
+// sta_conv.hip — the 3x3, stride-1, padding-1 convolutions of the UNet's ResBlocks / Upsample layers on NHWC activations as an
+// implicit GEMM on gfx950 MFMAs (reference: ResBlock in_layers / out_layers and Upsample.conv, openaimodel.py:163-275, :91-120;
+// called once per ResBlock half inside UNetModel.forward :710-743). These convolutions are ~45 % of a UNet call's GPU time through
+// the library kernels (17 - 27 % of the MFMA peak at the UNet's shapes); this is the same operation laid out for this chip.
+//
+//   out[b][y][x][o] = sum_{ky, kx, i} w[o][i][ky][kx] * in[b][y + ky - 1][x + kx - 1][i]          (zero outside the image)
+//
+// Pixels are the MFMA columns: Out^T[o][px] = sum over (tap, 32-channel step) of W_tap[o][i] . X_tap^T[i][px]  (v_mfma_f32_16x16x32).
+//   * A workgroup (8 waves) owns an output tile of 256 pixels (8 rows x 32 columns, or 16 x 16 for 16-pixel-wide images) and 160
+//     output channels; a wave owns 64 of the pixels (four 16-pixel row segments) and 80 of the channels: 20 accumulator tiles.
+//   * The input tile WITH its one-pixel halo ((8+2) x (32+2) pixels x 32 channels = 21.25 KiB per channel step) is copied to LDS
+//     once per channel step by LDS-DMA with per-lane source addresses (pixels outside the image read a page of zeros), double
+//     buffered; all nine taps read their B operands from it: one ds_read_b128 per (tap, pixel segment), with the four 16-byte
+//     channel chunks of a pixel stored at slot g ^ 2 ((p >> 2) & 1) so that the read is bank-conflict-free at every tap offset.
+//   * The weights are re-laid out once per model into 1-KiB A-operand fragments [part][channel step][ky][kx][tile] and streamed
+//     through a 2-slot LDS ring, one kernel row (3 taps x 10 tiles = 30 KiB) per step; a step is 60 MFMAs per wave behind
+//     27 operand reads, one barrier per step, the next step's DMA issued right behind the barrier.
+//   * Workgroups are persistent; the (tile, part) -> workgroup map keeps the parts of one pixel tile on one XCD (shared L2).
+//   * `up2`: the input is the nearest-neighbour 2x upsampling of a half-resolution tensor (Upsample.forward, :107-120): the
+//     halo copy reads pixel (y >> 1, x >> 1) of the small tensor, so the upsampled tensor never exists in HBM.
+//
+// Roofline: MFMA (2 * 9 * Cin * Cout flop per pixel against 2 (Cin + Cout) bytes: 1440 flop/B at 320 -> 320).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+#include "sta_xattn.h"
+#include "sta_unet.h"
+#include "sta_internal.h"
+#include "sta_xattn_dev.h"
+
+namespace {
+
+constexpr int CV_NW = 8;
+constexpr int CV_PART = 160;                  // output channels per workgroup
+constexpr int CV_NT = CV_PART / 16;           // 10 row tiles per part, 5 per wave
+constexpr int CV_WFR = 3 * CV_NT;             // 30 weight fragments per step (one kernel row)
+constexpr int CV_WPER = (CV_WFR + CV_NW - 1) / CV_NW;   // 4 weight DMAs per wave per step
+constexpr int CV_WSLOT = CV_WPER * CV_NW * FRAG;        // 32 KiB
+constexpr int CV_XPIECES = 3 * CV_NW;         // 24 input DMA pieces of 16 pixels per channel step (one per wave per step)
+constexpr int CV_XBUF = CV_XPIECES * FRAG;    // 24 KiB
+constexpr int CV_LDS = 2 * CV_WSLOT + 2 * CV_XBUF;      // 112 KiB
+
+// conv weight (o, i, ky, kx) at o*so + i*si + ky*sy + kx*sx -> fragments [part][kc][ky][kx][tile t]: lane (g, c) holds
+// W[160 part + 16 t + c][32 kc + 8 g .. + 7][ky][kx]
+template <typename T>
+__global__ __launch_bounds__(64) void pack_conv_w_kernel(const T* __restrict__ w, long so, long si, long sy, long sx, T* __restrict__ packed,
+                                                         int nkc) {
+  const int fr = blockIdx.x;                   // (((part * nkc + kc) * 3 + ky) * 3 + kx) * 10 + t
+  const int t = fr % CV_NT, kx = (fr / CV_NT) % 3, ky = (fr / (3 * CV_NT)) % 3, kc = (fr / (9 * CV_NT)) % nkc, part = fr / (9 * CV_NT * nkc);
+  const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
+  const T* src = w + (size_t)(CV_PART * part + 16 * t + c) * so + (size_t)(32 * kc + 8 * g) * si + ky * sy + kx * sx;
+  typename Tr<T>::V8 x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = src[j * si];
+  *(typename Tr<T>::V8*)(packed + (size_t)fr * (FRAG / 2) + lane * 8) = x;
+}
+
+struct CV {
+  const char* x;        // [B][Hs][Ws][Cin] (Hs = H >> up2)
+  const char* w;        // packed weights
+  const char* zeros;    // >= 2 * Cin bytes of zeros
+  void* out;            // [B][H][W][Cout]
+  int B, H, W, Cin, Cout, up2;
+  int parts, tiles_x, tiles_per_img, items;
+};
+
+template <typename T, int TR, int TC>
+__global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  // halo tile: (TR + 2) rows of TC + 2 pixels at a pitch of TC + 4 (a multiple of 4 with an odd quarter: the chunk swizzle of pixel
+  // (row, xx) is then ((row + (xx >> 2)) & 1) << 1 — separable, so a lane needs 12 operand addresses instead of 36): 360 pixels
+  constexpr int TWH = TC + 2, PITCH = TC + 4, NPX = (TR + 2) * PITCH;
+  static_assert(NPX <= 16 * CV_XPIECES && (PITCH / 4) % 2 == 1, "halo tile geometry");
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int pq = wv & 3, ch = wv >> 2;                     // pixel quarter (4 row segments), channel half (5 row tiles)
+  char* xring = smem;                                      // input buffers first: their operand reads then fit ds_read's 16-bit offset field
+  char* wring = smem + 2 * CV_XBUF;
+  const int nkc = p.Cin >> 5;
+  const int Hs = p.H >> p.up2, Ws = p.W >> p.up2;
+  const __amdgpu_buffer_rsrc_t w_srd = make_srd(p.w, (unsigned)((size_t)p.parts * nkc * 9 * CV_NT * FRAG));
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  // item -> (tile, part): the parts of a pixel tile run back to back on ONE XCD (workgroup id % 8), so the input tile is fetched
+  // from HBM once per XCD-L2 and the weight stream of a part is shared by the XCD's CUs walking the channel steps together
+  auto item_tile = [&](int it, int& tile, int& part) {
+    const int j = it >> 3;
+    tile = (j / p.parts) * 8 + (it & 7);
+    part = j % p.parts;
+  };
+  // per-lane source pointer of input piece `pc` (pixels 16 pc .. + 15 of the halo tile, this lane: pixel 16 pc + (lane >> 2), LDS slot
+  // lane & 3) at channel step 0
+  auto in_ptr = [&](int tile, int pc) -> const char* {
+    const int b = tile / p.tiles_per_img, tt = tile - b * p.tiles_per_img;
+    const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+    const int pp = 16 * pc + (lane >> 2);
+    const int hy = pp / PITCH, hx = pp - hy * PITCH;
+    const int y = ty * TR - 1 + hy, x = tx * TC - 1 + hx;
+    const int chunk = (lane & 3) ^ (((pp >> 2) & 1) << 1);
+    const bool ok = pp < NPX && hx < TWH && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    const size_t px = ((size_t)b * Hs + (y >> p.up2)) * Ws + (x >> p.up2);
+    return ok ? p.x + px * (size_t)p.Cin * sizeof(T) + chunk * 16 : p.zeros + chunk * 16;
+  };
+  auto stage_w = [&](int part, int kc, int ky, int slot) __attribute__((always_inline)) {
+    const unsigned base = (unsigned)(((part * nkc + kc) * 3 + ky) * CV_WFR) * (unsigned)FRAG;
+#pragma unroll
+    for (int i = 0; i < CV_WPER; ++i) {
+      const int f = wv + CV_NW * i;
+      const int fs = f < CV_WFR ? f : 0;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w_srd, (__attribute__((address_space(3))) void*)(wring + slot * CV_WSLOT + f * FRAG), 16, lane16,
+                                               base + (unsigned)fs * (unsigned)FRAG, 0, 0);
+    }
+  };
+  auto stage_x = [&](const char* src, int pc, int buf) __attribute__((always_inline)) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(xring + buf * CV_XBUF + pc * FRAG), 16, 0, 0);
+  };
+
+  // this wave's four pixel segments: segment index gi = 4 pq + q -> (row, first column) inside the tile. Byte offset inside an input
+  // buffer of this lane's B operand chunk for tap (ky, kx): seg_e[q][kx] + ky * PITCH * 64, bit 5 flipped when ky is odd
+  unsigned seg_e[4][3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int gi = 4 * pq + q;
+    const int ry = TC == 32 ? gi >> 1 : gi, x0 = TC == 32 ? (gi & 1) * 16 : 0;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = x0 + c16 + kx;
+      seg_e[q][kx] = (unsigned)((ry * PITCH + xx) * 64 + ((g ^ (((ry + (xx >> 2)) & 1) << 1)) << 4));
+    }
+  }
+
+  int it = blockIdx.x;
+  if (it >= p.items) return;
+  int tile, part;
+  item_tile(it, tile, part);
+  const char* xp[3];                                       // this wave's three input pieces (wv, wv + 8, wv + 16) of the NEXT channel step
+#pragma unroll
+  for (int i = 0; i < 3; ++i) xp[i] = in_ptr(tile, wv + CV_NW * i);
+  // prologue: kernel row 0 of channel step 0 and the whole input tile of channel step 0
+  stage_w(part, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { stage_x(xp[i], wv + CV_NW * i, 0); xp[i] += 64; }
+
+  const size_t obytes = (size_t)p.B * p.H * p.W * p.Cout * sizeof(T);
+  const __amdgpu_buffer_rsrc_t o_srd = make_srd(p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
+  bool first_of_tile = false;                              // the step that follows an epilogue: 20 stores are younger than its DMAs
+
+  while (true) {
+    f32x4 acc[4][5];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int t = 0; t < 5; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int nit = it + gridDim.x, ntile = 0, npart = 0;
+    const bool more = nit < p.items;
+    if (more) item_tile(nit, ntile, npart);
+
+    // one step = one kernel row (3 taps) of one channel step. Slots are compile-time: two channel steps (6 steps) per trip.
+    auto step = [&](auto xb_tag, auto ws_tag, auto ky_tag, const int kc) __attribute__((always_inline)) {
+      constexpr int XB = decltype(xb_tag)::value, WS = decltype(ws_tag)::value, KY = decltype(ky_tag)::value;
+      if (first_of_tile) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      first_of_tile = false;
+      __builtin_amdgcn_s_barrier();
+      // behind the barrier: the next step's kernel row, and one piece of the next channel step's input tile
+      const bool last_kc = kc + 1 == nkc;
+      if (KY < 2) stage_w(part, kc, KY + 1, WS ^ 1);
+      else if (!last_kc) stage_w(part, kc + 1, 0, WS ^ 1);
+      else if (more) stage_w(npart, 0, 0, WS ^ 1);
+      if (!last_kc || more) {
+        if (last_kc) xp[KY] = in_ptr(ntile, wv + CV_NW * KY);
+        stage_x(xp[KY], wv + CV_NW * KY, XB ^ 1);
+        xp[KY] += 64;
+      }
+      const char* xb = xring + XB * CV_XBUF;
+      const V8* wf = (const V8*)(wring + WS * CV_WSLOT + lane * 16) + (5 * ch) * 64;
+      // operands of tap kx + 1 are requested before the 20 MFMAs of tap kx (two register sets)
+      V8 a[5], b[4];
+      auto load_tap = [&](int kx, V8 (&aa)[5], V8 (&bb)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bb[q] = *(const V8*)(xb + KY * PITCH * 64 + (KY & 1 ? seg_e[q][kx] ^ 32u : seg_e[q][kx]));
+#pragma unroll
+        for (int t = 0; t < 5; ++t) aa[t] = wf[(kx * CV_NT + t) * 64];
+      };
+      load_tap(0, a, b);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        V8 an[5], bn[4];
+        if (kx < 2) load_tap(kx + 1, an, bn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q][t] = Tr<T>::mfma(a[t], b[q], acc[q][t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kx < 2) {
+#pragma unroll
+          for (int t = 0; t < 5; ++t) a[t] = an[t];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) b[q] = bn[q];
+        }
+      }
+    };
+    for (int kc = 0; kc < nkc; kc += 2) {
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      step(I0{}, I0{}, I0{}, kc);
+      step(I0{}, I1{}, I1{}, kc);
+      step(I0{}, I0{}, I2{}, kc);
+      step(I1{}, I1{}, I0{}, kc + 1);
+      step(I1{}, I0{}, I1{}, kc + 1);
+      step(I1{}, I1{}, I2{}, kc + 1);
+    }
+    // epilogue: lane (g, c) of tile t holds output channels 16 t + 4 g .. + 3 of pixel c: ALWAYS 20 stores of 8 bytes
+    {
+      const int b = tile / p.tiles_per_img, tt = tile - b * p.tiles_per_img;
+      const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int gi = 4 * pq + q;
+        const int ry = TC == 32 ? gi >> 1 : gi, x0 = TC == 32 ? (gi & 1) * 16 : 0;
+        const size_t px = ((size_t)b * p.H + ty * TR + ry) * p.W + tx * TC + x0 + c16;
+        const unsigned base = (unsigned)((px * p.Cout + part * CV_PART + ch * 80 + 4 * g) * sizeof(T));
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+          V4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (T)acc[q][t][r];
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, o), o_srd,
+                                                base + (unsigned)(16 * t * sizeof(T)), 0, 0);
+        }
+      }
+    }
+    if (!more) break;
+    it = nit; tile = ntile; part = npart;
+    first_of_tile = true;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+bool conv_geom(int H, int W, int& tr, int& tc) {
+  if (W % 32 == 0 && H % 8 == 0) { tr = 8; tc = 32; return true; }
+  if (W == 16 && H % 16 == 0) { tr = 16; tc = 16; return true; }
+  return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sta_conv3x3_nhwc_supported(int B, int H, int W, int Cin, int Cout) {
+  int tr, tc;
+  if (B <= 0 || !conv_geom(H, W, tr, tc)) return 0;
+  if (Cin <= 0 || Cin % 64 || Cout <= 0 || Cout % CV_PART) return 0;
+  const long tiles = (long)B * (H / tr) * (W / tc);
+  if (tiles % 8) return 0;
+  if ((size_t)B * H * W * (size_t)Cout * 2 >= 0xfffffff0ull) return 0;
+  return 1;
+}
+
+size_t sta_conv3x3_packed_w_bytes(int Cin, int Cout) {
+  return (Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % CV_PART == 0) ? (size_t)Cout * Cin * 9 * 2 : 0;
+}
+
+int sta_conv3x3_pack_w(const void* w, long so, long si, long sy, long sx, void* packed, int Cin, int Cout, int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!w || !packed) return sta_fail(STA_E_ARG, "null pointer");
+  if (sta_conv3x3_packed_w_bytes(Cin, Cout) == 0) return sta_fail(STA_E_UNSUP, "conv3x3: Cin %% 64 and Cout %% 160 must be 0 (Cin=%d Cout=%d)", Cin, Cout);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  hipStream_t st = (hipStream_t)stream;
+  const int nkc = Cin / 32;
+  const unsigned nfr = (unsigned)(Cout / CV_PART) * nkc * 9 * CV_NT;
+  if (dtype == STA_BF16) hipLaunchKernelGGL(pack_conv_w_kernel<__bf16>, dim3(nfr), dim3(64), 0, st, (const __bf16*)w, so, si, sy, sx, (__bf16*)packed, nkc);
+  else hipLaunchKernelGGL(pack_conv_w_kernel<_Float16>, dim3(nfr), dim3(64), 0, st, (const _Float16*)w, so, si, sy, sx, (_Float16*)packed, nkc);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_conv_w launch: %s", hipGetErrorString(e));
+}
+
+int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, void* out, int B, int H, int W, int Cin, int Cout, int up2,
+                     int dtype, void* stream) {
+  g_sta_err[0] = 0;
+  if (!x || !packed_w || !zeros || !out) return sta_fail(STA_E_ARG, "null pointer");
+  if (!sta_conv3x3_nhwc_supported(B, H, W, Cin, Cout))
+    return sta_fail(STA_E_UNSUP, "conv3x3_nhwc: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
+  if (up2 && (H % 2 || W % 2)) return sta_fail(STA_E_ARG, "conv3x3_nhwc: up2 needs even H, W");
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  int tr, tc;
+  conv_geom(H, W, tr, tc);
+  CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, B, H, W, Cin, Cout, up2 ? 1 : 0,
+       Cout / CV_PART, W / tc, (H / tr) * (W / tc), 0};
+  p.items = B * p.tiles_per_img * p.parts;
+  const unsigned grid = (unsigned)(p.items < 256 ? p.items : 256);
+  hipStream_t st = (hipStream_t)stream;
+  static StaLdsAttr attr[4];
+#define STA_CONV_LAUNCH(T, TR, TC, A)                                                                                              \
+  do {                                                                                                                             \
+    if (!attr[A].ensure((const void*)conv3x3_nhwc_kernel<T, TR, TC>, CV_LDS)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(conv3x3) failed"); \
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, TR, TC>), dim3(grid), dim3(64 * CV_NW), CV_LDS, st, p);                            \
+  } while (0)
+  if (dtype == STA_BF16) { if (tc == 32) STA_CONV_LAUNCH(__bf16, 8, 32, 0); else STA_CONV_LAUNCH(__bf16, 16, 16, 1); }
+  else { if (tc == 32) STA_CONV_LAUNCH(_Float16, 8, 32, 2); else STA_CONV_LAUNCH(_Float16, 16, 16, 3); }
+#undef STA_CONV_LAUNCH
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "conv3x3_nhwc launch: %s", hipGetErrorString(e));
+}
+
+}  // extern "C"

@@ -228,6 +228,50 @@ def ff_out_res_hfrag(x, h_frag, w_packed, bias):
     return out
 
 
+CONV3X3 = True          # the HIP implicit-GEMM 3x3 convolution for the NHWC trunk (csrc/sta_conv.hip); False: library convolution
+_conv_zeros = {}
+
+
+def conv3x3_supported(x, weight, up2=False):
+    """The HIP 3x3 convolution applies to NHWC 16-bit CUDA activations outside autograd at the geometries
+    sta_conv3x3_nhwc_supported lists (the UNet's ResBlock / Upsample convolutions at 512^2 down to the 16x16 level)."""
+    if not (CONV3X3 and usable(x) and x.dim() == 4 and is_nhwc(x) and weight.dtype == x.dtype and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    B, Cin, H, W = x.shape
+    if up2:
+        H, W = 2 * H, 2 * W
+    return bool(lib.load().sta_conv3x3_nhwc_supported(B, H, W, Cin, weight.shape[0]))
+
+
+def pack_conv3x3_weight(weight):
+    """Conv2d weight [Cout, Cin, 3, 3] (any memory format) -> the A-operand fragment image of sta_conv3x3_nhwc; once per model."""
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    L = lib.load()
+    n = L.sta_conv3x3_packed_w_bytes(Cin, Cout)
+    if n == 0 or not weight.is_cuda or tuple(weight.shape[2:]) != (3, 3):
+        raise ValueError("conv3x3: a CUDA weight [Cout %% 160 == 0, Cin %% 64 == 0, 3, 3]; got %s" % (tuple(weight.shape),))
+    w = weight.detach()
+    buf = torch.empty(n, dtype=torch.uint8, device=w.device)
+    so, si, sy, sx = w.stride()
+    lib.check(L.sta_conv3x3_pack_w(w.data_ptr(), so, si, sy, sx, buf.data_ptr(), Cin, Cout, _DT[w.dtype], _stream()), "sta_conv3x3_pack_w")
+    return buf
+
+
+def conv3x3_nhwc(x, w_packed, Cout, up2=False):
+    """conv2d(x, w, padding=1) without bias on an NHWC activation (logical shape [B, Cin, H, W], channels_last strides);
+    up2: of the nearest-neighbour 2x upsampling of x, which is never written. Returns [B, Cout, H', W'] channels_last."""
+    B, Cin, H, W = x.shape
+    if up2:
+        H, W = 2 * H, 2 * W
+    z = _conv_zeros.get(x.device)
+    if z is None or z.numel() < 2 * Cin:
+        z = _conv_zeros[x.device] = torch.zeros(max(2 * Cin, 8192), dtype=torch.uint8, device=x.device)
+    out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    lib.check(lib.load().sta_conv3x3_nhwc(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, int(bool(up2)),
+                                          _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
+    return out
+
+
 def add_bias_nchw(a, b=None, bias=None):
     """a + b + bias[None, :, None, None] over 4-D activations (both NCHW-contiguous or both channels_last)."""
     B, C = a.shape[0], a.shape[1]

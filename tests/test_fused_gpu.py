@@ -371,3 +371,50 @@ def test_add_bias_tracked_gradient():
     y.backward(dy)
     _close(y.detach(), (a.float() + b.float() + bias.float()[None, :, None, None]).detach().cpu(), torch.float16)
     assert torch.equal(a.grad, dy) and torch.equal(b.grad, dy)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,up2", [
+    (8, 64, 160, 8, 32, False),      # one 8 x 32 tile per image, one part, two channel steps
+    (2, 320, 320, 32, 32, False),    # four tiles per image, two parts (level 1 geometry)
+    (1, 128, 160, 64, 64, False),    # 16 tiles of one image: every border case of the 8 x 32 tiling
+    (8, 192, 320, 16, 16, False),    # the 16 x 16 tile (level 2 geometry), six channel steps
+    (2, 64, 160, 32, 32, True),      # Upsample.conv: 16 x 16 input read through (y >> 1, x >> 1)
+    (8, 128, 160, 16, 16, True),     # 8 x 8 input upsampled into the 16 x 16 tile
+    (16, 640, 320, 64, 64, False),   # more items than workgroups: the persistent loop crosses tiles (512 items)
+])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("w_nhwc", [True, False])
+def test_conv3x3_nhwc(B, Cin, Cout, H, W, up2, dtype, w_nhwc):
+    """csrc/sta_conv.hip against an fp32 convolution of the same 16-bit operands (ResBlock / Upsample convolutions,
+    openaimodel.py:163-275, :107-120). fp32 accumulation over 9 * Cin products: the error is the 16-bit rounding of the result."""
+    from sta import fused
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    Hs, Ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dtype)
+    xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up2 else x.float()
+    ref = F.conv2d(xi, w.float(), None, 1, 1)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    wd = w.cuda().contiguous(memory_format=torch.channels_last) if w_nhwc else w.cuda()
+    with torch.no_grad():
+        assert fused.conv3x3_supported(xd, wd, up2=up2)
+        got = fused.conv3x3_nhwc(xd, fused.pack_conv3x3_weight(wd), Cout, up2=up2)
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    _close(got, ref, dtype, k=2.0)
+
+
+def test_conv3x3_unsupported_geometries_are_refused():
+    from sta import fused, lib
+    L = lib.load()
+    assert not L.sta_conv3x3_nhwc_supported(64, 8, 8, 1280, 1280)       # the 8 x 8 level stays with the library
+    assert not L.sta_conv3x3_nhwc_supported(64, 64, 64, 4, 320)         # conv_in
+    assert not L.sta_conv3x3_nhwc_supported(64, 64, 64, 320, 4)         # conv_out
+    assert not L.sta_conv3x3_nhwc_supported(1, 32, 32, 320, 320)        # 4 tiles: not a multiple of the XCD count
+    assert L.sta_conv3x3_nhwc_supported(64, 64, 64, 960, 320) and L.sta_conv3x3_nhwc_supported(64, 16, 16, 2560, 1280)
+    x = torch.zeros(64, 320, 8, 8, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    w = torch.zeros(320, 320, 3, 3, device="cuda", dtype=torch.float16)
+    assert not fused.conv3x3_supported(x, w)
+    z = torch.zeros(8192, dtype=torch.uint8, device="cuda")
+    assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), x.data_ptr(), 64, 8, 8, 320, 320, 0, 1, None) != 0
+    assert "unsupported geometry" in lib.last_error()
