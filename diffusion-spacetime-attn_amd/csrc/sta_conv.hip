@@ -61,6 +61,8 @@ struct CV {
   const char* w;        // packed weights
   const char* zeros;    // >= 2 * Cin bytes of zeros
   void* out;            // [B][H][W][Cout]
+  const void* bias;     // [Cout] or null
+  const void* res;      // [B][H][W][Cout] or null: out = conv + bias + res
   int B, H, W, Cin, Cout, up2;
   int parts, tiles_x, tiles_per_img, items;
 };
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
 
   const size_t obytes = (size_t)p.B * p.H * p.W * p.Cout * sizeof(T);
   const __amdgpu_buffer_rsrc_t o_srd = make_srd(p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
+  const __amdgpu_buffer_rsrc_t r_srd = make_srd(p.res ? p.res : p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
   bool first_of_tile = false;                              // the step that follows an epilogue: 20 stores are younger than its DMAs
 
   while (true) {
@@ -216,23 +219,38 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
       step(I1{}, I0{}, I1{}, kc + 1);
       step(I1{}, I1{}, I2{}, kc + 1);
     }
-    // epilogue: lane (g, c) of tile t holds output channels 16 t + 4 g .. + 3 of pixel c: ALWAYS 20 stores of 8 bytes
+    // epilogue: lane (g, c) of tile t holds output channels 16 t + 4 g .. + 3 of pixel c (+ bias, + the residual tensor):
+    // ALWAYS 20 stores of 8 bytes, issued behind every load of the epilogue
     {
       const int b = tile / p.tiles_per_img, tt = tile - b * p.tiles_per_img;
       const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+      typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+      float bs[5][4];
+#pragma unroll
+      for (int t = 0; t < 5; ++t) {
+        V4 bv = {};
+        if (p.bias) bv = *(const V4*)((const T*)p.bias + part * CV_PART + ch * 80 + 16 * t + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bs[t][r] = (float)bv[r];
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int gi = 4 * pq + q;
         const int ry = TC == 32 ? gi >> 1 : gi, x0 = TC == 32 ? (gi & 1) * 16 : 0;
         const size_t px = ((size_t)b * p.H + ty * TR + ry) * p.W + tx * TC + x0 + c16;
         const unsigned base = (unsigned)((px * p.Cout + part * CV_PART + ch * 80 + 4 * g) * sizeof(T));
+        V4 rv[5];
+        if (p.res) {
+#pragma unroll
+          for (int t = 0; t < 5; ++t)
+            rv[t] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b64(r_srd, base + (unsigned)(16 * t * sizeof(T)), 0, 0));
+        }
 #pragma unroll
         for (int t = 0; t < 5; ++t) {
           V4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (T)acc[q][t][r];
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, o), o_srd,
-                                                base + (unsigned)(16 * t * sizeof(T)), 0, 0);
+          for (int r = 0; r < 4; ++r) o[r] = (T)(acc[q][t][r] + bs[t][r] + (p.res ? (float)rv[t][r] : 0.f));
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), o_srd, base + (unsigned)(16 * t * sizeof(T)), 0, 0);
         }
       }
     }
@@ -281,8 +299,8 @@ int sta_conv3x3_pack_w(const void* w, long so, long si, long sy, long sx, void* 
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_conv_w launch: %s", hipGetErrorString(e));
 }
 
-int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, void* out, int B, int H, int W, int Cin, int Cout, int up2,
-                     int dtype, void* stream) {
+int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, int B, int H, int W,
+                     int Cin, int Cout, int up2, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!x || !packed_w || !zeros || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (!sta_conv3x3_nhwc_supported(B, H, W, Cin, Cout))
@@ -291,7 +309,7 @@ int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, voi
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   int tr, tc;
   conv_geom(H, W, tr, tc);
-  CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, B, H, W, Cin, Cout, up2 ? 1 : 0,
+  CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, bias, res, B, H, W, Cin, Cout, up2 ? 1 : 0,
        Cout / CV_PART, W / tc, (H / tr) * (W / tc), 0};
   p.items = B * p.tiles_per_img * p.parts;
   const unsigned grid = (unsigned)(p.items < 256 ? p.items : 256);

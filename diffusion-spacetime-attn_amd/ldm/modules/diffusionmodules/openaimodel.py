@@ -4,8 +4,9 @@ configs/stable-diffusion/v1-inference.yaml) with the reference's hook surface:
 `(context, timesteps[0], text_index, coef, bboxs_curr)` to every SpatialTransformer
 (reference openaimodel.py:80-88, :710-743). Module and parameter names follow the reference's
 state_dict (`input_blocks.N.M...`, `middle_block...`, `output_blocks...`, `time_embed`, `out`), so an
-SD-v1-4 checkpoint loads without key remapping. Convolutions / ResBlocks stay on PyTorch-ROCm
-(MIOpen / hipBLASLt); only the cross-attention inside SpatialTransformer is custom HIP.
+SD-v1-4 checkpoint loads without key remapping. Outside autograd on an NHWC trunk the 3x3 convolutions of the
+ResBlocks and Upsample layers run on csrc/sta_conv.hip (implicit GEMM on the MFMAs; bias, skip add and the nearest-2x
+read folded in); stride-2, 1x1, conv_in / conv_out and the 8x8 level stay on MIOpen, as does everything under autograd.
 """
 import torch
 import torch.nn.functional as F
@@ -14,6 +15,28 @@ from torch import nn
 from ldm.modules.attention import SpatialTransformer
 from ldm.modules.diffusionmodules.util import checkpoint, normalization, timestep_embedding, zero_module
 from sta import fused as _fused
+
+
+def _packed_conv(owner, conv):
+    """conv.weight as sta_conv3x3_nhwc streams it (sta.fused.pack_conv3x3_weight), repacked only when the weight tensor changes."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.dtype)
+    cache = owner.__dict__.setdefault("_sta_conv_cache", {})
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        hit = cache[id(conv)] = (key, _fused.pack_conv3x3_weight(w))
+    return hit[1]
+
+
+def _conv3x3(owner, conv, x, bias=None, res=None, up2=False):
+    """conv(x) (+ bias + res) through the HIP convolution where it applies, the library convolution (+ the fused bias / residual pass)
+    elsewhere. `bias=None` means bias-free (the caller folds conv.bias into a later pass)."""
+    if _fused.conv3x3_supported(x, conv.weight, up2=up2) and (res is None or _fused.is_nhwc(res)):
+        return _fused.conv3x3_nhwc(x, _packed_conv(owner, conv), conv.weight.shape[0], up2=up2, bias=bias, res=res)
+    if up2:
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+    h = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+    return h if bias is None and res is None else _fused.add_bias_nchw(h if res is None else res, None if res is None else h, bias)
 
 
 class TimestepBlock(nn.Module):
@@ -43,6 +66,8 @@ class Upsample(nn.Module):
             self.conv = nn.Conv2d(self.channels, self.out_channels, 3, padding=padding)
 
     def forward(self, x):
+        if self.use_conv and _fused.conv3x3_supported(x, self.conv.weight, up2=True):
+            return _conv3x3(self, self.conv, x, bias=self.conv.bias, up2=True)      # the upsampled tensor is never written
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         return self.conv(x) if self.use_conv else x
 
@@ -115,21 +140,20 @@ class ResBlock(TimestepBlock):
 
     def _forward_fused(self, x, emb):
         """Inference: GroupNorm+SiLU are one pass each; the timestep-embedding add AND conv1's bias ride into the
-        second GroupNorm pass as a per-(b, c) pre-add; conv2's bias, the skip's bias and the residual add are
-        one pass. The convolutions themselves run bias-free (no separate bias kernel). csrc/sta_unet.hip."""
+        second GroupNorm pass as a per-(b, c) pre-add; conv2's bias, the skip's bias and the residual add are the
+        epilogue of the second convolution (csrc/sta_conv.hip; with the library convolution: one pass of csrc/sta_unet.hip)."""
         gn1, _, conv1 = self.in_layers
         gn2, _, _, conv2 = self.out_layers
         h = _fused.groupnorm_silu(x, gn1.weight, gn1.bias, gn1.num_groups, gn1.eps)
-        h = F.conv2d(h, conv1.weight, None, conv1.stride, conv1.padding)
+        h = _conv3x3(self, conv1, h)
         add = self.emb_layers(emb).float() + conv1.bias.float()                       # [B, C_out]
         h = _fused.groupnorm_silu(h, gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, add=add)
-        h = F.conv2d(h, conv2.weight, None, conv2.stride, conv2.padding)
         skip, bias = x, conv2.bias
         if not isinstance(self.skip_connection, nn.Identity):
             sc = self.skip_connection
             skip = F.conv2d(x, sc.weight, None, sc.stride, sc.padding)
             bias = conv2.bias + sc.bias
-        return _fused.add_bias_nchw(skip, h, bias)
+        return _conv3x3(self, conv2, h, bias=bias, res=skip)
 
 
 class UNetModel(nn.Module):

@@ -257,8 +257,8 @@ def pack_conv3x3_weight(weight):
     return buf
 
 
-def conv3x3_nhwc(x, w_packed, Cout, up2=False):
-    """conv2d(x, w, padding=1) without bias on an NHWC activation (logical shape [B, Cin, H, W], channels_last strides);
+def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None):
+    """conv2d(x, w, bias, padding=1) + res on an NHWC activation (logical shape [B, Cin, H, W], channels_last strides);
     up2: of the nearest-neighbour 2x upsampling of x, which is never written. Returns [B, Cout, H', W'] channels_last."""
     B, Cin, H, W = x.shape
     if up2:
@@ -267,8 +267,12 @@ def conv3x3_nhwc(x, w_packed, Cout, up2=False):
     if z is None or z.numel() < 2 * Cin:
         z = _conv_zeros[x.device] = torch.zeros(max(2 * Cin, 8192), dtype=torch.uint8, device=x.device)
     out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
-    lib.check(lib.load().sta_conv3x3_nhwc(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, int(bool(up2)),
-                                          _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
+    if res is not None:
+        assert res.shape == out.shape and res.dtype == x.dtype and is_nhwc(res)
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    lib.check(lib.load().sta_conv3x3_nhwc(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), B, H, W, Cin, Cout,
+                                          int(bool(up2)), _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
     return out
 
 

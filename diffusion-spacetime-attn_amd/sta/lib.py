@@ -75,7 +75,7 @@ SYMBOLS = {
     "sta_conv3x3_nhwc_supported": (_i, [_i, _i, _i, _i, _i]),
     "sta_conv3x3_packed_w_bytes": (_sz, [_i, _i]),
     "sta_conv3x3_pack_w": (_i, [_vp, _l, _l, _l, _l, _vp, _i, _i, _i, _vp]),
-    "sta_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sta_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sta_add_bias_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sta_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sta_groupnorm_silu_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),

@@ -87,9 +87,10 @@ int sta_ff_out_res_hfrag(const void* h_frag, const void* packed_w, const void* b
 
 /*
  * The 3x3, stride-1, padding-1 convolutions of the UNet trunk on NHWC activations as an implicit GEMM on the MFMAs
- * (ResBlock in_layers / out_layers, openaimodel.py:163-275; Upsample.conv :107-120; csrc/sta_conv.hip). Bias-free: the callers
- * fold the bias into the pass that follows (the second GroupNorm's pre-add, sta_add_bias_nhwc).
+ * (ResBlock in_layers / out_layers, openaimodel.py:163-275; Upsample.conv :107-120; csrc/sta_conv.hip):
+ *     out = conv(x) + bias + res            (`skip_connection(x) + out_layers(h)` of ResBlock._forward in the epilogue)
  *   x: [B][H >> up2][W >> up2][Cin] dtype;  out: [B][H][W][Cout] dtype;  zeros: >= 2 * Cin bytes of zeros (the padding halo);
+ *   bias: [Cout] dtype or NULL;  res: [B][H][W][Cout] dtype or NULL (may not alias out);
  *   packed_w: the weight re-laid out once per model by sta_conv3x3_pack_w (element (o, i, ky, kx) of the source at
  *   o*so + i*si + ky*sy + kx*sx, strides in elements: any memory format of a [Cout][Cin][3][3] tensor);
  *   up2 = 1: the input is the nearest-neighbour 2x upsampling of x (Upsample.forward), read through (y >> 1, x >> 1) — the
@@ -100,8 +101,8 @@ int sta_ff_out_res_hfrag(const void* h_frag, const void* packed_w, const void* b
 int sta_conv3x3_nhwc_supported(int B, int H, int W, int Cin, int Cout);
 size_t sta_conv3x3_packed_w_bytes(int Cin, int Cout);
 int sta_conv3x3_pack_w(const void* w, long so, long si, long sy, long sx, void* packed, int Cin, int Cout, int dtype, void* stream);
-int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, void* out, int B, int H, int W, int Cin, int Cout,
-                     int up2, int dtype, void* stream);
+int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, int B, int H,
+                     int W, int Cin, int Cout, int up2, int dtype, void* stream);
 
 /*
  * y = a + b + bias[c]  over NCHW tensors [B][C][HW] (HW % 8 == 0); b and/or bias may be NULL.

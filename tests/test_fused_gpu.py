@@ -383,8 +383,8 @@ def test_add_bias_tracked_gradient():
     (16, 640, 320, 64, 64, False),   # more items than workgroups: the persistent loop crosses tiles (512 items)
 ])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("w_nhwc", [True, False])
-def test_conv3x3_nhwc(B, Cin, Cout, H, W, up2, dtype, w_nhwc):
+@pytest.mark.parametrize("w_nhwc,epi", [(True, False), (False, True)])
+def test_conv3x3_nhwc(B, Cin, Cout, H, W, up2, dtype, w_nhwc, epi):
     """csrc/sta_conv.hip against an fp32 convolution of the same 16-bit operands (ResBlock / Upsample convolutions,
     openaimodel.py:163-275, :107-120). fp32 accumulation over 9 * Cin products: the error is the 16-bit rounding of the result."""
     from sta import fused
@@ -393,12 +393,15 @@ def test_conv3x3_nhwc(B, Cin, Cout, H, W, up2, dtype, w_nhwc):
     x = torch.randn(B, Cin, Hs, Ws, generator=g).to(dtype)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dtype)
     xi = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up2 else x.float()
-    ref = F.conv2d(xi, w.float(), None, 1, 1)
+    bias = (0.5 * torch.randn(Cout, generator=g)).to(dtype) if epi else None
+    res = torch.randn(B, Cout, H, W, generator=g).to(dtype) if epi else None
+    ref = F.conv2d(xi, w.float(), None if bias is None else bias.float(), 1, 1) + (res.float() if epi else 0.0)
     xd = x.cuda().contiguous(memory_format=torch.channels_last)
     wd = w.cuda().contiguous(memory_format=torch.channels_last) if w_nhwc else w.cuda()
     with torch.no_grad():
         assert fused.conv3x3_supported(xd, wd, up2=up2)
-        got = fused.conv3x3_nhwc(xd, fused.pack_conv3x3_weight(wd), Cout, up2=up2)
+        got = fused.conv3x3_nhwc(xd, fused.pack_conv3x3_weight(wd), Cout, up2=up2, bias=None if bias is None else bias.cuda(),
+                                 res=None if res is None else res.cuda().contiguous(memory_format=torch.channels_last))
     torch.cuda.synchronize()
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     _close(got, ref, dtype, k=2.0)
@@ -416,5 +419,5 @@ def test_conv3x3_unsupported_geometries_are_refused():
     w = torch.zeros(320, 320, 3, 3, device="cuda", dtype=torch.float16)
     assert not fused.conv3x3_supported(x, w)
     z = torch.zeros(8192, dtype=torch.uint8, device="cuda")
-    assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), x.data_ptr(), 64, 8, 8, 320, 320, 0, 1, None) != 0
+    assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), None, None, x.data_ptr(), 64, 8, 8, 320, 320, 0, 1, None) != 0
     assert "unsupported geometry" in lib.last_error()
