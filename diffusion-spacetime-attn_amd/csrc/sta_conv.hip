@@ -64,7 +64,7 @@ struct CV {
   const void* bias;     // [Cout] or null
   const void* res;      // [B][H][W][Cout] or null: out = conv + bias + res
   int B, H, W, Cin, Cout, up2;
-  int parts, tiles_x, tiles_per_img, items;
+  int parts, tiles_x, tiles_per_img, items, xcd_map;
 };
 
 template <typename T, int TR, int TC>
@@ -88,10 +88,16 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
 
   // item -> (tile, part): the parts of a pixel tile run back to back on ONE XCD (workgroup id % 8), so the input tile is fetched
   // from HBM once per XCD-L2 and the weight stream of a part is shared by the XCD's CUs walking the channel steps together
+  // (tile counts that are not a multiple of 8 — small batches — take the plain order)
   auto item_tile = [&](int it, int& tile, int& part) {
-    const int j = it >> 3;
-    tile = (j / p.parts) * 8 + (it & 7);
-    part = j % p.parts;
+    if (p.xcd_map) {
+      const int j = it >> 3;
+      tile = (j / p.parts) * 8 + (it & 7);
+      part = j % p.parts;
+    } else {
+      tile = it / p.parts;
+      part = it - tile * p.parts;
+    }
   };
   // per-lane source pointer of input piece `pc` (pixels 16 pc .. + 15 of the halo tile, this lane: pixel 16 pc + (lane >> 2), LDS slot
   // lane & 3) at channel step 0
@@ -275,8 +281,6 @@ int sta_conv3x3_nhwc_supported(int B, int H, int W, int Cin, int Cout) {
   int tr, tc;
   if (B <= 0 || !conv_geom(H, W, tr, tc)) return 0;
   if (Cin <= 0 || Cin % 64 || Cout <= 0 || Cout % CV_PART) return 0;
-  const long tiles = (long)B * (H / tr) * (W / tc);
-  if (tiles % 8) return 0;
   if ((size_t)B * H * W * (size_t)Cout * 2 >= 0xfffffff0ull) return 0;
   return 1;
 }
@@ -310,8 +314,9 @@ int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, con
   int tr, tc;
   conv_geom(H, W, tr, tc);
   CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, bias, res, B, H, W, Cin, Cout, up2 ? 1 : 0,
-       Cout / CV_PART, W / tc, (H / tr) * (W / tc), 0};
+       Cout / CV_PART, W / tc, (H / tr) * (W / tc), 0, 0};
   p.items = B * p.tiles_per_img * p.parts;
+  p.xcd_map = (B * p.tiles_per_img) % 8 == 0;
   const unsigned grid = (unsigned)(p.items < 256 ? p.items : 256);
   hipStream_t st = (hipStream_t)stream;
   static StaLdsAttr attr[4];

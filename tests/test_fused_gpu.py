@@ -380,6 +380,8 @@ def test_add_bias_tracked_gradient():
     (8, 192, 320, 16, 16, False),    # the 16 x 16 tile (level 2 geometry), six channel steps
     (2, 64, 160, 32, 32, True),      # Upsample.conv: 16 x 16 input read through (y >> 1, x >> 1)
     (8, 128, 160, 16, 16, True),     # 8 x 8 input upsampled into the 16 x 16 tile
+    (1, 64, 320, 16, 16, False),     # one tile, two parts: the plain item order (tile count not a multiple of 8)
+    (3, 64, 160, 32, 32, True),      # 12 tiles, plain order, upsampled input
     (16, 640, 320, 64, 64, False),   # more items than workgroups: the persistent loop crosses tiles (512 items)
 ])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -413,7 +415,6 @@ def test_conv3x3_unsupported_geometries_are_refused():
     assert not L.sta_conv3x3_nhwc_supported(64, 8, 8, 1280, 1280)       # the 8 x 8 level stays with the library
     assert not L.sta_conv3x3_nhwc_supported(64, 64, 64, 4, 320)         # conv_in
     assert not L.sta_conv3x3_nhwc_supported(64, 64, 64, 320, 4)         # conv_out
-    assert not L.sta_conv3x3_nhwc_supported(1, 32, 32, 320, 320)        # 4 tiles: not a multiple of the XCD count
     assert L.sta_conv3x3_nhwc_supported(64, 64, 64, 960, 320) and L.sta_conv3x3_nhwc_supported(64, 16, 16, 2560, 1280)
     x = torch.zeros(64, 320, 8, 8, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     w = torch.zeros(320, 320, 3, 3, device="cuda", dtype=torch.float16)

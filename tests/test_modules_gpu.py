@@ -550,6 +550,48 @@ def test_bench_step_images_match_single_prompt():
     assert (xb[0] - xb[I - 1]).abs().max() > 1e-3        # different prompts give different images
 
 
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_full_width_unet_hip_convolutions_match_library_convolutions(dtype, monkeypatch):
+    """One CFG call of the FULL-width SD-v1 UNet (NHWC trunk, fixed weights) with the ResBlock / Upsample 3x3 convolutions on
+    csrc/sta_conv.hip (levels 0-2: 64x64, 32x32, 16x16; the bias, skip add and nearest-2x read folded in) against the same call with
+    every convolution on the library (what the reference-golden tests of the reduced-width UNet run, whose channel counts the HIP
+    kernel does not take). Stated tolerance: 1 % of max |eps| per element, 0.3 % of mean |eps| on average — two 16-bit trunks with
+    independent roundings (the library path itself moves by that much between its own algorithms)."""
+    from sta import fused, prompt_state
+    from sta.pipeline import build_sd_v1, use_shipped_miopen_db
+    use_shipped_miopen_db(0)
+    dev = torch.device("cuda", 0)
+    model = build_sd_v1(dev, dtype, with_vae=False, init_weights=True, seed=0, channels_last=True)
+    unet = model.model.diffusion_model
+    c, local_ctx, x = gi.unet_inputs(2, 5, lat=64)
+    ctx = torch.cat([gi.load_uncond(), c]).to(dev, dtype)
+    xin = x.expand(2, -1, -1, -1).contiguous().to(dev)
+    t = torch.tensor([981, 981], device=dev)
+    coef = torch.tensor([2.5, 2.5], device=dev)
+    calls = []
+    real = fused.conv3x3_nhwc
+    monkeypatch.setattr(fused, "conv3x3_nhwc", lambda *a, **k: (calls.append(tuple(a[0].shape) + (k.get("up2", False),)), real(*a, **k))[1])
+    out = {}
+    for hip in (True, False):
+        monkeypatch.setattr(fused, "CONV3X3", hip)
+        prompt_state.begin_prompt([l.to(dev) for l in local_ctx], first_timestep=981)
+        with torch.no_grad():
+            out[hip] = unet(xin, 0, t, context=ctx, coef=coef, bboxs_curr=[[0.3, 0.4], [0.7, 0.6]]).float()
+        if hip:
+            n_hip = len(calls)
+    assert len(calls) == n_hip                      # the second pass took no HIP convolution
+    # 2 per ResBlock at levels 0-2 (2 + 2 + 2 down, 3 + 3 + 3 up = 15 blocks) + the three Upsample convolutions
+    assert n_hip == 33 and sum(1 for cc in calls if cc[-1]) == 3, (n_hip, calls)
+    assert {cc[2] for cc in calls} == {64, 32, 16, 8}, calls      # 8: the upsample from the 8x8 level into 16x16
+    ref, got = out[False], out[True]
+    assert torch.isfinite(got).all() and ref.abs().max() > 1e-2
+    e_max = ((got - ref).abs().max() / ref.abs().max()).item()
+    e_mean = ((got - ref).abs().mean() / ref.abs().mean()).item()
+    print("full-width UNet, HIP vs library convolutions (%s): max %.5f mean %.5f (relative)" % (dtype, e_max, e_mean))
+    tol = (0.01, 0.003) if dtype == torch.float16 else (0.06, 0.02)
+    assert e_max < tol[0] and e_mean < tol[1], (e_max, e_mean)
+
+
 def test_entry_point_script_end_to_end(tmp_path):
     """scripts/txt2img-mscoco.py on a 4-prompt dataset with a layout JSON: synthetic SD-v1 weights, fixed blend
     weights, 3 PLMS steps; one prompt alone + batches grouped by object count; PNGs named like the reference's
