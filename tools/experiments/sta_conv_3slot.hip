@@ -39,7 +39,8 @@ constexpr int CV_WPER = (CV_WFR + CV_NW - 1) / CV_NW;   // 4 weight DMAs per wav
 constexpr int CV_WSLOT = CV_WPER * CV_NW * FRAG;        // 32 KiB
 constexpr int CV_XPIECES = 3 * CV_NW;         // 24 input DMA pieces of 16 pixels per channel step (one per wave per step)
 constexpr int CV_XBUF = CV_XPIECES * FRAG;    // 24 KiB
-constexpr int CV_LDS = 2 * CV_WSLOT + 2 * CV_XBUF;      // 112 KiB
+constexpr int CV_NSLOT = 3;                   // weight ring: the kernel row of step s + 2 is in flight while step s computes
+constexpr int CV_LDS = CV_NSLOT * CV_WSLOT + 2 * CV_XBUF;      // 144 KiB
 #ifndef CV_STAGE_AFTER_TAP
 #define CV_STAGE_AFTER_TAP 0                  // the next step's DMA is issued behind the MFMAs of this tap (not right behind the barrier,
 #endif                                        // where every wave of the workgroup would pay the issue cost with the matrix pipe idle)
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
   const int g = lane >> 4, c16 = lane & 15;
   const int pq = wv & 3, ch = wv >> 2;                     // pixel quarter (4 row segments), channel half (5 row tiles)
   char* xring = smem;                                      // input buffers first: their operand reads then fit ds_read's 16-bit offset field
-  char* wring = smem + 2 * CV_XBUF;
+  char* wring = smem + 2 * CV_XBUF;                        // three weight slots behind them
   const int nkc = p.Cin >> 5;
   const int Hs = p.H >> p.up2, Ws = p.W >> p.up2;
   const __amdgpu_buffer_rsrc_t w_srd = make_srd(p.w, (unsigned)((size_t)p.parts * nkc * 9 * CV_NT * FRAG));
@@ -151,15 +152,16 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
   const char* xp[3];                                       // this wave's three input pieces (wv, wv + 8, wv + 16) of the NEXT channel step
 #pragma unroll
   for (int i = 0; i < 3; ++i) xp[i] = in_ptr(tile, wv + CV_NW * i);
-  // prologue: kernel row 0 of channel step 0 and the whole input tile of channel step 0
+  // prologue: kernel rows 0 and 1 of channel step 0 and the whole input tile of channel step 0
   stage_w(part, 0, 0, 0);
+  stage_w(part, 0, 1, 1);
 #pragma unroll
   for (int i = 0; i < 3; ++i) { stage_x(xp[i], wv + CV_NW * i, 0); xp[i] += 64; }
 
   const size_t obytes = (size_t)p.B * p.H * p.W * p.Cout * sizeof(T);
   const __amdgpu_buffer_rsrc_t o_srd = make_srd(p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
   const __amdgpu_buffer_rsrc_t r_srd = make_srd(p.res ? p.res : p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
-  bool first_of_tile = false;                              // the step that follows an epilogue: 20 stores are younger than its DMAs
+  bool first_of_tile = true;                               // the first step of a tile drains the counter (the prologue; the epilogue's stores)
 
   while (true) {
     f32x4 acc[4][5];
@@ -171,24 +173,31 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
     const bool more = nit < p.items;
     if (more) item_tile(nit, ntile, npart);
 
-    // one step = one kernel row (3 taps) of one channel step. Slots are compile-time: two channel steps (6 steps) per trip.
-    auto step = [&](auto xb_tag, auto ws_tag, auto ky_tag, const int kc) __attribute__((always_inline)) {
-      constexpr int XB = decltype(xb_tag)::value, WS = decltype(ws_tag)::value, KY = decltype(ky_tag)::value;
-      if (first_of_tile) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // one step = one kernel row (3 taps) of one channel step; its weight slot is KY (3 steps per channel step), its input buffer
+    // kc & 1: compile-time with two channel steps (6 steps) per trip. Behind the MFMAs of its first tap a step issues the DMA of
+    // the kernel row TWO steps ahead (4 per wave) and — at KY = 0 — the three pieces of the next channel step's input tile, so the
+    // counted wait at the top of a step leaves the previous step's issue (7 or 4 DMAs) in flight.
+    auto step = [&](auto xb_tag, auto ky_tag, const int kc) __attribute__((always_inline)) {
+      constexpr int XB = decltype(xb_tag)::value, KY = decltype(ky_tag)::value, WS = KY;
+      const bool last_kc = kc + 1 == nkc;
+      if (first_of_tile || (last_kc && !more && KY > 0)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last steps of the last tile issue less)
+      else if (KY == 1) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       first_of_tile = false;
       __builtin_amdgcn_s_barrier();
-      // the next step's kernel row, and one piece of the next channel step's input tile
       auto stage_next = [&]() __attribute__((always_inline)) {
-        const bool last_kc = kc + 1 == nkc;
-        if (KY < 2) stage_w(part, kc, KY + 1, WS ^ 1);
-        else if (!last_kc) stage_w(part, kc + 1, 0, WS ^ 1);
-        else if (more) stage_w(npart, 0, 0, WS ^ 1);
-        if (!last_kc || more) {
-          if (last_kc) xp[KY] = in_ptr(ntile, wv + CV_NW * KY);
-          stage_x(xp[KY], wv + CV_NW * KY, XB ^ 1);
-          xp[KY] += 64;
+        constexpr int TS = (KY + 2) % 3;                   // slot of step s + 2: read last in step s - 1, which every wave has left
+        if (KY == 0 && (!last_kc || more)) {               // the input pieces FIRST: the wait of step KY = 2 counts only what is younger than its row
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            if (last_kc) xp[i] = in_ptr(ntile, wv + CV_NW * i);
+            stage_x(xp[i], wv + CV_NW * i, XB ^ 1);
+            xp[i] += 64;
+          }
         }
+        if (KY == 0) stage_w(part, kc, 2, TS);
+        else if (!last_kc) stage_w(part, kc + 1, KY - 1, TS);
+        else if (more) stage_w(npart, 0, KY - 1, TS);
       };
       if (CV_STAGE_AFTER_TAP < 0) stage_next();
       const char* xb = xring + XB * CV_XBUF;
@@ -228,12 +237,12 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
       using I0 = std::integral_constant<int, 0>;
       using I1 = std::integral_constant<int, 1>;
       using I2 = std::integral_constant<int, 2>;
-      step(I0{}, I0{}, I0{}, kc);
-      step(I0{}, I1{}, I1{}, kc);
-      step(I0{}, I0{}, I2{}, kc);
-      step(I1{}, I1{}, I0{}, kc + 1);
-      step(I1{}, I0{}, I1{}, kc + 1);
-      step(I1{}, I1{}, I2{}, kc + 1);
+      step(I0{}, I0{}, kc);
+      step(I0{}, I1{}, kc);
+      step(I0{}, I2{}, kc);
+      step(I1{}, I0{}, kc + 1);
+      step(I1{}, I1{}, kc + 1);
+      step(I1{}, I2{}, kc + 1);
     }
     // epilogue: lane (g, c) of tile t holds output channels 16 t + 4 g .. + 3 of pixel c (+ bias, + the residual tensor):
     // ALWAYS 20 stores of 8 bytes, issued behind every load of the epilogue
