@@ -32,27 +32,29 @@
 namespace {
 
 constexpr int CV_NW = 8;
-constexpr int CV_PART = 160;                  // output channels per workgroup
-constexpr int CV_NT = CV_PART / 16;           // 10 row tiles per part, 5 per wave
-constexpr int CV_WFR = 3 * CV_NT;             // 30 weight fragments per step (one kernel row)
-constexpr int CV_WPER = (CV_WFR + CV_NW - 1) / CV_NW;   // 4 weight DMAs per wave per step
-constexpr int CV_WSLOT = CV_WPER * CV_NW * FRAG;        // 32 KiB
+// NTW = row tiles (16 output channels) per wave: 5 (a workgroup owns 160 channels: the UNet's 320 / 640 / 1280) or 4 (128 channels:
+// the VAE decoder's 128 / 256 / 512)
+constexpr int cv_part(int ntw) { return 32 * ntw; }                       // output channels per workgroup
+constexpr int cv_nt(int ntw) { return 2 * ntw; }                          // row tiles per part
+constexpr int cv_wfr(int ntw) { return 3 * cv_nt(ntw); }                  // 30 / 24 weight fragments per step (one kernel row)
+constexpr int cv_wper(int ntw) { return (cv_wfr(ntw) + CV_NW - 1) / CV_NW; }   // 4 / 3 weight DMAs per wave per step
+constexpr int cv_wslot(int ntw) { return cv_wper(ntw) * CV_NW * FRAG; }   // 32 / 24 KiB
 constexpr int CV_XPIECES = 3 * CV_NW;         // 24 input DMA pieces of 16 pixels per channel step (one per wave per step)
 constexpr int CV_XBUF = CV_XPIECES * FRAG;    // 24 KiB
-constexpr int CV_LDS = 2 * CV_WSLOT + 2 * CV_XBUF;      // 112 KiB
+constexpr int cv_lds(int ntw) { return 2 * cv_wslot(ntw) + 2 * CV_XBUF; } // 112 / 96 KiB
 #ifndef CV_STAGE_AFTER_TAP
 #define CV_STAGE_AFTER_TAP 0                  // the next step's DMA is issued behind the MFMAs of this tap (not right behind the barrier,
 #endif                                        // where every wave of the workgroup would pay the issue cost with the matrix pipe idle)
 
 // conv weight (o, i, ky, kx) at o*so + i*si + ky*sy + kx*sx -> fragments [part][kc][ky][kx][tile t]: lane (g, c) holds
-// W[160 part + 16 t + c][32 kc + 8 g .. + 7][ky][kx]
+// W[16 nt part + 16 t + c][32 kc + 8 g .. + 7][ky][kx]      (nt = 10 or 8 row tiles per part)
 template <typename T>
 __global__ __launch_bounds__(64) void pack_conv_w_kernel(const T* __restrict__ w, long so, long si, long sy, long sx, T* __restrict__ packed,
-                                                         int nkc) {
-  const int fr = blockIdx.x;                   // (((part * nkc + kc) * 3 + ky) * 3 + kx) * 10 + t
-  const int t = fr % CV_NT, kx = (fr / CV_NT) % 3, ky = (fr / (3 * CV_NT)) % 3, kc = (fr / (9 * CV_NT)) % nkc, part = fr / (9 * CV_NT * nkc);
+                                                         int nkc, int nt) {
+  const int fr = blockIdx.x;                   // (((part * nkc + kc) * 3 + ky) * 3 + kx) * nt + t
+  const int t = fr % nt, kx = (fr / nt) % 3, ky = (fr / (3 * nt)) % 3, kc = (fr / (9 * nt)) % nkc, part = fr / (9 * nt * nkc);
   const int lane = threadIdx.x, g = lane >> 4, c = lane & 15;
-  const T* src = w + (size_t)(CV_PART * part + 16 * t + c) * so + (size_t)(32 * kc + 8 * g) * si + ky * sy + kx * sx;
+  const T* src = w + (size_t)(16 * nt * part + 16 * t + c) * so + (size_t)(32 * kc + 8 * g) * si + ky * sy + kx * sx;
   typename Tr<T>::V8 x;
 #pragma unroll
   for (int j = 0; j < 8; ++j) x[j] = src[j * si];
@@ -70,10 +72,11 @@ struct CV {
   int parts, tiles_x, tiles_per_img, items, xcd_map;
 };
 
-template <typename T, int TR, int TC>
+template <typename T, int TR, int TC, int NTW>
 __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
+  constexpr int CV_PART = cv_part(NTW), CV_NT = cv_nt(NTW), CV_WFR = cv_wfr(NTW), CV_WPER = cv_wper(NTW), CV_WSLOT = cv_wslot(NTW);
   // halo tile: (TR + 2) rows of TC + 2 pixels at a pitch of TC + 4 (a multiple of 4 with an odd quarter: the chunk swizzle of pixel
   // (row, xx) is then ((row + (xx >> 2)) & 1) << 1 — separable, so a lane needs 12 operand addresses instead of 36): 360 pixels
   constexpr int TWH = TC + 2, PITCH = TC + 4, NPX = (TR + 2) * PITCH;
@@ -159,14 +162,14 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
   const size_t obytes = (size_t)p.B * p.H * p.W * p.Cout * sizeof(T);
   const __amdgpu_buffer_rsrc_t o_srd = make_srd(p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
   const __amdgpu_buffer_rsrc_t r_srd = make_srd(p.res ? p.res : p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
-  bool first_of_tile = false;                              // the step that follows an epilogue: 20 stores are younger than its DMAs
+  bool first_of_tile = false;                              // the step that follows an epilogue: 4 NTW stores are younger than its DMAs
 
   while (true) {
-    f32x4 acc[4][5];
+    f32x4 acc[4][NTW];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-      for (int t = 0; t < 5; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < NTW; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     int nit = it + gridDim.x, ntile = 0, npart = 0;
     const bool more = nit < p.items;
     if (more) item_tile(nit, ntile, npart);
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
     // one step = one kernel row (3 taps) of one channel step. Slots are compile-time: two channel steps (6 steps) per trip.
     auto step = [&](auto xb_tag, auto ws_tag, auto ky_tag, const int kc) __attribute__((always_inline)) {
       constexpr int XB = decltype(xb_tag)::value, WS = decltype(ws_tag)::value, KY = decltype(ky_tag)::value;
-      if (first_of_tile) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+      if (first_of_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NTW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       first_of_tile = false;
       __builtin_amdgcn_s_barrier();
@@ -192,23 +195,23 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
       };
       if (CV_STAGE_AFTER_TAP < 0) stage_next();
       const char* xb = xring + XB * CV_XBUF;
-      const V8* wf = (const V8*)(wring + WS * CV_WSLOT + lane * 16) + (5 * ch) * 64;
+      const V8* wf = (const V8*)(wring + WS * CV_WSLOT + lane * 16) + (NTW * ch) * 64;
       // operands of tap kx + 1 are requested before the 20 MFMAs of tap kx (two register sets)
-      V8 a[5], b[4];
-      auto load_tap = [&](int kx, V8 (&aa)[5], V8 (&bb)[4]) __attribute__((always_inline)) {
+      V8 a[NTW], b[4];
+      auto load_tap = [&](int kx, V8 (&aa)[NTW], V8 (&bb)[4]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) bb[q] = *(const V8*)(xb + KY * PITCH * 64 + (KY & 1 ? seg_e[q][kx] ^ 32u : seg_e[q][kx]));
 #pragma unroll
-        for (int t = 0; t < 5; ++t) aa[t] = wf[(kx * CV_NT + t) * 64];
+        for (int t = 0; t < NTW; ++t) aa[t] = wf[(kx * CV_NT + t) * 64];
       };
       load_tap(0, a, b);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        V8 an[5], bn[4];
+        V8 an[NTW], bn[4];
         if (kx < 2) load_tap(kx + 1, an, bn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int t = 0; t < 5; ++t)
+        for (int t = 0; t < NTW; ++t)
 #pragma unroll
           for (int q = 0; q < 4; ++q) acc[q][t] = Tr<T>::mfma(a[t], b[q], acc[q][t]);
         __builtin_amdgcn_sched_barrier(0);
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
         }
         if (kx < 2) {
 #pragma unroll
-          for (int t = 0; t < 5; ++t) a[t] = an[t];
+          for (int t = 0; t < NTW; ++t) a[t] = an[t];
 #pragma unroll
           for (int q = 0; q < 4; ++q) b[q] = bn[q];
         }
@@ -236,16 +239,16 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
       step(I1{}, I1{}, I2{}, kc + 1);
     }
     // epilogue: lane (g, c) of tile t holds output channels 16 t + 4 g .. + 3 of pixel c (+ bias, + the residual tensor):
-    // ALWAYS 20 stores of 8 bytes, issued behind every load of the epilogue
+    // ALWAYS 4 NTW stores of 8 bytes, issued behind every load of the epilogue
     {
       const int b = tile / p.tiles_per_img, tt = tile - b * p.tiles_per_img;
       const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
-      float bs[5][4];
+      float bs[NTW][4];
 #pragma unroll
-      for (int t = 0; t < 5; ++t) {
+      for (int t = 0; t < NTW; ++t) {
         V4 bv = {};
-        if (p.bias) bv = *(const V4*)((const T*)p.bias + part * CV_PART + ch * 80 + 16 * t + 4 * g);
+        if (p.bias) bv = *(const V4*)((const T*)p.bias + part * CV_PART + ch * (16 * NTW) + 16 * t + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) bs[t][r] = (float)bv[r];
       }
@@ -254,15 +257,15 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
         const int gi = 4 * pq + q;
         const int ry = TC == 32 ? gi >> 1 : gi, x0 = TC == 32 ? (gi & 1) * 16 : 0;
         const size_t px = ((size_t)b * p.H + ty * TR + ry) * p.W + tx * TC + x0 + c16;
-        const unsigned base = (unsigned)((px * p.Cout + part * CV_PART + ch * 80 + 4 * g) * sizeof(T));
-        V4 rv[5];
+        const unsigned base = (unsigned)((px * p.Cout + part * CV_PART + ch * (16 * NTW) + 4 * g) * sizeof(T));
+        V4 rv[NTW];
         if (p.res) {
 #pragma unroll
-          for (int t = 0; t < 5; ++t)
+          for (int t = 0; t < NTW; ++t)
             rv[t] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b64(r_srd, base + (unsigned)(16 * t * sizeof(T)), 0, 0));
         }
 #pragma unroll
-        for (int t = 0; t < 5; ++t) {
+        for (int t = 0; t < NTW; ++t) {
           V4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (T)(acc[q][t][r] + bs[t][r] + (p.res ? (float)rv[t][r] : 0.f));
@@ -287,28 +290,31 @@ bool conv_geom(int H, int W, int& tr, int& tc) {
 
 extern "C" {
 
+static int conv_ntw(int Cout) { return Cout > 0 && Cout % 160 == 0 ? 5 : (Cout > 0 && Cout % 128 == 0 ? 4 : 0); }
+
 int sta_conv3x3_nhwc_supported(int B, int H, int W, int Cin, int Cout) {
   int tr, tc;
   if (B <= 0 || !conv_geom(H, W, tr, tc)) return 0;
-  if (Cin <= 0 || Cin % 64 || Cout <= 0 || Cout % CV_PART) return 0;
+  if (Cin <= 0 || Cin % 64 || conv_ntw(Cout) == 0) return 0;
   if ((size_t)B * H * W * (size_t)Cout * 2 >= 0xfffffff0ull) return 0;
   return 1;
 }
 
 size_t sta_conv3x3_packed_w_bytes(int Cin, int Cout) {
-  return (Cin > 0 && Cin % 64 == 0 && Cout > 0 && Cout % CV_PART == 0) ? (size_t)Cout * Cin * 9 * 2 : 0;
+  return (Cin > 0 && Cin % 64 == 0 && conv_ntw(Cout)) ? (size_t)Cout * Cin * 9 * 2 : 0;
 }
 
 int sta_conv3x3_pack_w(const void* w, long so, long si, long sy, long sx, void* packed, int Cin, int Cout, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!w || !packed) return sta_fail(STA_E_ARG, "null pointer");
-  if (sta_conv3x3_packed_w_bytes(Cin, Cout) == 0) return sta_fail(STA_E_UNSUP, "conv3x3: Cin %% 64 and Cout %% 160 must be 0 (Cin=%d Cout=%d)", Cin, Cout);
+  if (sta_conv3x3_packed_w_bytes(Cin, Cout) == 0)
+    return sta_fail(STA_E_UNSUP, "conv3x3: Cin %% 64 == 0 and Cout %% 160 == 0 or Cout %% 128 == 0 (Cin=%d Cout=%d)", Cin, Cout);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   hipStream_t st = (hipStream_t)stream;
-  const int nkc = Cin / 32;
-  const unsigned nfr = (unsigned)(Cout / CV_PART) * nkc * 9 * CV_NT;
-  if (dtype == STA_BF16) hipLaunchKernelGGL(pack_conv_w_kernel<__bf16>, dim3(nfr), dim3(64), 0, st, (const __bf16*)w, so, si, sy, sx, (__bf16*)packed, nkc);
-  else hipLaunchKernelGGL(pack_conv_w_kernel<_Float16>, dim3(nfr), dim3(64), 0, st, (const _Float16*)w, so, si, sy, sx, (_Float16*)packed, nkc);
+  const int nkc = Cin / 32, nt = cv_nt(conv_ntw(Cout));
+  const unsigned nfr = (unsigned)(Cout / (16 * nt)) * nkc * 9 * nt;
+  if (dtype == STA_BF16) hipLaunchKernelGGL(pack_conv_w_kernel<__bf16>, dim3(nfr), dim3(64), 0, st, (const __bf16*)w, so, si, sy, sx, (__bf16*)packed, nkc, nt);
+  else hipLaunchKernelGGL(pack_conv_w_kernel<_Float16>, dim3(nfr), dim3(64), 0, st, (const _Float16*)w, so, si, sy, sx, (_Float16*)packed, nkc, nt);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_conv_w launch: %s", hipGetErrorString(e));
 }
@@ -323,20 +329,28 @@ int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, con
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   int tr, tc;
   conv_geom(H, W, tr, tc);
+  const int ntw = conv_ntw(Cout);
   CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, bias, res, B, H, W, Cin, Cout, up2 ? 1 : 0,
-       Cout / CV_PART, W / tc, (H / tr) * (W / tc), 0, 0};
-  p.items = B * p.tiles_per_img * p.parts;
-  p.xcd_map = (B * p.tiles_per_img) % 8 == 0;
+       Cout / cv_part(ntw), W / tc, (H / tr) * (W / tc), 0, 0};
+  const long items = (long)B * p.tiles_per_img * p.parts;
+  if (items >= (1l << 30)) return sta_fail(STA_E_UNSUP, "conv3x3_nhwc: too many tiles");
+  p.items = (int)items;
+  p.xcd_map = ((long)B * p.tiles_per_img) % 8 == 0;
   const unsigned grid = (unsigned)(p.items < 256 ? p.items : 256);
   hipStream_t st = (hipStream_t)stream;
-  static StaLdsAttr attr[4];
-#define STA_CONV_LAUNCH(T, TR, TC, A)                                                                                              \
+  static StaLdsAttr attr[8];
+#define STA_CONV_LAUNCH(T, TR, TC, NTW, A)                                                                                         \
   do {                                                                                                                             \
-    if (!attr[A].ensure((const void*)conv3x3_nhwc_kernel<T, TR, TC>, CV_LDS)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(conv3x3) failed"); \
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, TR, TC>), dim3(grid), dim3(64 * CV_NW), CV_LDS, st, p);                            \
+    if (!attr[A].ensure((const void*)conv3x3_nhwc_kernel<T, TR, TC, NTW>, cv_lds(NTW))) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(conv3x3) failed"); \
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, TR, TC, NTW>), dim3(grid), dim3(64 * CV_NW), cv_lds(NTW), st, p);                   \
   } while (0)
-  if (dtype == STA_BF16) { if (tc == 32) STA_CONV_LAUNCH(__bf16, 8, 32, 0); else STA_CONV_LAUNCH(__bf16, 16, 16, 1); }
-  else { if (tc == 32) STA_CONV_LAUNCH(_Float16, 8, 32, 2); else STA_CONV_LAUNCH(_Float16, 16, 16, 3); }
+#define STA_CONV_GEOM(T, A)                                                                                                        \
+  do {                                                                                                                             \
+    if (tc == 32) { if (ntw == 5) STA_CONV_LAUNCH(T, 8, 32, 5, A); else STA_CONV_LAUNCH(T, 8, 32, 4, A + 1); }                     \
+    else { if (ntw == 5) STA_CONV_LAUNCH(T, 16, 16, 5, A + 2); else STA_CONV_LAUNCH(T, 16, 16, 4, A + 3); }                        \
+  } while (0)
+  if (dtype == STA_BF16) STA_CONV_GEOM(__bf16, 0); else STA_CONV_GEOM(_Float16, 4);
+#undef STA_CONV_GEOM
 #undef STA_CONV_LAUNCH
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "conv3x3_nhwc launch: %s", hipGetErrorString(e));

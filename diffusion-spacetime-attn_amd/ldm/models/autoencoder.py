@@ -33,6 +33,11 @@ class ResnetBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1)
 
     def forward(self, x):
+        if _fused.conv3x3_supported(x, self.conv1.weight):
+            # fixed-weight decode on an NHWC decoder: both convolutions on csrc/sta_conv.hip, the shortcut add in the second one's epilogue
+            h = _fused.conv3x3_module(self, self.conv1, _norm_silu(self.norm1, x), bias=self.conv1.bias)
+            skip = self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x
+            return _fused.conv3x3_module(self, self.conv2, _norm_silu(self.norm2, h), bias=self.conv2.bias, res=skip)
         h = self.conv1(_norm_silu(self.norm1, x))
         h = self.conv2(_norm_silu(self.norm2, h))
         return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
@@ -90,6 +95,8 @@ class _Up(nn.Module):
         self.conv = nn.Conv2d(channels, channels, 3, padding=1)
 
     def forward(self, x):
+        if _fused.conv3x3_supported(x, self.conv.weight, up2=True):
+            return _fused.conv3x3_module(self, self.conv, x, bias=self.conv.bias, up2=True)      # the upsampled tensor is never written
         return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 

@@ -17,26 +17,7 @@ from ldm.modules.diffusionmodules.util import checkpoint, normalization, timeste
 from sta import fused as _fused
 
 
-def _packed_conv(owner, conv):
-    """conv.weight as sta_conv3x3_nhwc streams it (sta.fused.pack_conv3x3_weight), repacked only when the weight tensor changes."""
-    w = conv.weight
-    key = (w.data_ptr(), w._version, w.dtype)
-    cache = owner.__dict__.setdefault("_sta_conv_cache", {})
-    hit = cache.get(id(conv))
-    if hit is None or hit[0] != key:
-        hit = cache[id(conv)] = (key, _fused.pack_conv3x3_weight(w))
-    return hit[1]
-
-
-def _conv3x3(owner, conv, x, bias=None, res=None, up2=False):
-    """conv(x) (+ bias + res) through the HIP convolution where it applies, the library convolution (+ the fused bias / residual pass)
-    elsewhere. `bias=None` means bias-free (the caller folds conv.bias into a later pass)."""
-    if _fused.conv3x3_supported(x, conv.weight, up2=up2) and (res is None or _fused.is_nhwc(res)):
-        return _fused.conv3x3_nhwc(x, _packed_conv(owner, conv), conv.weight.shape[0], up2=up2, bias=bias, res=res)
-    if up2:
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
-    h = F.conv2d(x, conv.weight, None, conv.stride, conv.padding)
-    return h if bias is None and res is None else _fused.add_bias_nchw(h if res is None else res, None if res is None else h, bias)
+_conv3x3 = _fused.conv3x3_module
 
 
 class TimestepBlock(nn.Module):

