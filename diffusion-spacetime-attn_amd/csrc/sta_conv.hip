@@ -39,9 +39,19 @@ constexpr int cv_nt(int ntw) { return 2 * ntw; }                          // row
 constexpr int cv_wfr(int ntw) { return 3 * cv_nt(ntw); }                  // 30 / 24 weight fragments per step (one kernel row)
 constexpr int cv_wper(int ntw) { return (cv_wfr(ntw) + CV_NW - 1) / CV_NW; }   // 4 / 3 weight DMAs per wave per step
 constexpr int cv_wslot(int ntw) { return cv_wper(ntw) * CV_NW * FRAG; }   // 32 / 24 KiB
-constexpr int CV_XPIECES = 3 * CV_NW;         // 24 input DMA pieces of 16 pixels per channel step (one per wave per step)
-constexpr int CV_XBUF = CV_XPIECES * FRAG;    // 24 KiB
-constexpr int cv_lds(int ntw) { return 2 * cv_wslot(ntw) + 2 * CV_XBUF; } // 112 / 96 KiB
+// Tile geometries. GEO 0: 8 rows x 32 columns; GEO 1: 16 x 16 (16-pixel-wide images): 256 pixels, four 16-pixel segments per wave.
+// GEO 2: TWO whole 8 x 8 images (the UNet's lowest level): 128 pixels, two segments (four image rows) per wave — at 64 images x 1280
+// channels that is 256 work items, one per CU, where 256-pixel tiles would leave half of the chip idle. The halo tile is stored at a
+// row pitch that keeps the chunk swizzle separable (see seg_e below): 36 / 20 / 16 pixels. XPW = input DMA pieces (16 pixels each)
+// per wave per channel step; NQ = pixel segments per wave.
+constexpr int cv_tr(int geo) { return geo == 0 ? 8 : geo == 1 ? 16 : 8; }
+constexpr int cv_tc(int geo) { return geo == 0 ? 32 : geo == 1 ? 16 : 8; }
+constexpr int cv_pitch(int geo) { return geo == 0 ? 36 : geo == 1 ? 20 : 16; }
+constexpr int cv_npx(int geo) { return geo == 2 ? 2 * 10 * 16 : (cv_tr(geo) + 2) * cv_pitch(geo); }    // 360 / 360 / 320 pixels
+constexpr int cv_nq(int geo) { return geo == 2 ? 2 : 4; }
+constexpr int cv_xpw(int geo) { return (cv_npx(geo) + 16 * CV_NW - 1) / (16 * CV_NW); }                   // 3
+constexpr int cv_xbuf(int geo) { return cv_xpw(geo) * CV_NW * FRAG; }                                      // 24 KiB
+constexpr int cv_lds(int ntw, int geo) { return 2 * cv_wslot(ntw) + 2 * cv_xbuf(geo); }                    // 112 / 96 KiB
 #ifndef CV_STAGE_AFTER_TAP
 #define CV_STAGE_AFTER_TAP 0                  // the next step's DMA is issued behind the MFMAs of this tap (not right behind the barrier,
 #endif                                        // where every wave of the workgroup would pay the issue cost with the matrix pipe idle)
@@ -72,15 +82,17 @@ struct CV {
   int parts, tiles_x, tiles_per_img, items, xcd_map;
 };
 
-template <typename T, int TR, int TC, int NTW>
+template <typename T, int GEO, int NTW>
 __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int CV_PART = cv_part(NTW), CV_NT = cv_nt(NTW), CV_WFR = cv_wfr(NTW), CV_WPER = cv_wper(NTW), CV_WSLOT = cv_wslot(NTW);
-  // halo tile: (TR + 2) rows of TC + 2 pixels at a pitch of TC + 4 (a multiple of 4 with an odd quarter: the chunk swizzle of pixel
-  // (row, xx) is then ((row + (xx >> 2)) & 1) << 1 — separable, so a lane needs 12 operand addresses instead of 36): 360 pixels
-  constexpr int TWH = TC + 2, PITCH = TC + 4, NPX = (TR + 2) * PITCH;
-  static_assert(NPX <= 16 * CV_XPIECES && (PITCH / 4) % 2 == 1, "halo tile geometry");
+  // halo tile: (TR + 2) rows of TC + 2 pixels at a pitch that is a multiple of 4: the chunk swizzle ((pixel index >> 2) & 1) << 1 of pixel
+  // (row, xx) is then ((row * (PITCH / 4) + (xx >> 2)) & 1) << 1 — separable in row and column, so a lane needs 12 operand addresses
+  // instead of 36 (PITCH / 4 odd: bit 5 of the address flips on odd kernel rows; even: it does not depend on the row at all)
+  constexpr int TR = cv_tr(GEO), TC = cv_tc(GEO), TWH = TC + 2, PITCH = cv_pitch(GEO), NPX = cv_npx(GEO), XPW = cv_xpw(GEO), CV_XBUF = cv_xbuf(GEO), NQ = cv_nq(GEO);
+  constexpr bool ROW_FLIPS = (PITCH / 4) % 2 == 1;
+  static_assert(PITCH % 4 == 0 && PITCH >= TWH, "halo tile geometry");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
@@ -108,13 +120,23 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
   // per-lane source pointer of input piece `pc` (pixels 16 pc .. + 15 of the halo tile, this lane: pixel 16 pc + (lane >> 2), LDS slot
   // lane & 3) at channel step 0
   auto in_ptr = [&](int tile, int pc) -> const char* {
-    const int b = tile / p.tiles_per_img, tt = tile - b * p.tiles_per_img;
-    const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
     const int pp = 16 * pc + (lane >> 2);
-    const int hy = pp / PITCH, hx = pp - hy * PITCH;
-    const int y = ty * TR - 1 + hy, x = tx * TC - 1 + hx;
     const int chunk = (lane & 3) ^ (((pp >> 2) & 1) << 1);
-    const bool ok = pp < NPX && hx < TWH && y >= 0 && y < p.H && x >= 0 && x < p.W;
+    int b, y, x, hx;
+    if (GEO == 2) {                                        // image 2 tile + pp / 160, halo row (pp % 160) / 16
+      const int im = pp / (10 * PITCH), rem = pp - im * (10 * PITCH);
+      const int hy = rem / PITCH;
+      hx = rem - hy * PITCH;
+      b = 2 * tile + im; y = hy - 1; x = hx - 1;
+    } else {
+      b = tile / p.tiles_per_img;
+      const int tt = tile - b * p.tiles_per_img;
+      const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
+      const int hy = pp / PITCH;
+      hx = pp - hy * PITCH;
+      y = ty * TR - 1 + hy; x = tx * TC - 1 + hx;
+    }
+    const bool ok = pp < NPX && hx < TWH && y >= 0 && y < p.H && x >= 0 && x < p.W && b < p.B;
     const size_t px = ((size_t)b * Hs + (y >> p.up2)) * Ws + (x >> p.up2);
     return ok ? p.x + px * (size_t)p.Cin * sizeof(T) + chunk * 16 : p.zeros + chunk * 16;
   };
@@ -133,17 +155,24 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
                                      (__attribute__((address_space(3))) void*)(xring + buf * CV_XBUF + pc * FRAG), 16, 0, 0);
   };
 
-  // this wave's four pixel segments: segment index gi = 4 pq + q -> (row, first column) inside the tile. Byte offset inside an input
-  // buffer of this lane's B operand chunk for tap (ky, kx): seg_e[q][kx] + ky * PITCH * 64, bit 5 flipped when ky is odd
-  unsigned seg_e[4][3];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  // this wave's NQ pixel segments: segment index gi = 4 pq + q -> (row, first column) inside the tile (GEO 2: image pq >> 1, rows
+  // 4 (pq & 1) + 2 q and the next, lane c -> (row + (c >> 3), c & 7)). Byte offset inside an input buffer of this lane's B operand chunk for tap (ky, kx):
+  // seg_e[q][kx] + ky * PITCH * 64, bit 5 flipped when ky is odd and ROW_FLIPS
+  auto seg_rc = [&](int q, int& ry, int& x0) {             // first halo row / column of the segment's lane-0 pixel at tap (0, 0)
     const int gi = 4 * pq + q;
-    const int ry = TC == 32 ? gi >> 1 : gi, x0 = TC == 32 ? (gi & 1) * 16 : 0;
+    if (GEO == 0) { ry = gi >> 1; x0 = (gi & 1) * 16 + c16; }
+    else if (GEO == 1) { ry = gi; x0 = c16; }
+    else { ry = 10 * (pq >> 1) + 4 * (pq & 1) + 2 * q + (c16 >> 3); x0 = c16 & 7; }
+  };
+  unsigned seg_e[NQ][3];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    int ry, x0;
+    seg_rc(q, ry, x0);
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const int xx = x0 + c16 + kx;
-      seg_e[q][kx] = (unsigned)((ry * PITCH + xx) * 64 + ((g ^ (((ry + (xx >> 2)) & 1) << 1)) << 4));
+      const int xx = x0 + kx;
+      seg_e[q][kx] = (unsigned)((ry * PITCH + xx) * 64 + ((g ^ (((ry * (PITCH / 4) + (xx >> 2)) & 1) << 1)) << 4));
     }
   }
 
@@ -151,13 +180,13 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
   if (it >= p.items) return;
   int tile, part;
   item_tile(it, tile, part);
-  const char* xp[3];                                       // this wave's three input pieces (wv, wv + 8, wv + 16) of the NEXT channel step
+  const char* xp[XPW];                                     // this wave's input pieces (wv, wv + 8, ...) of the NEXT channel step
 #pragma unroll
-  for (int i = 0; i < 3; ++i) xp[i] = in_ptr(tile, wv + CV_NW * i);
+  for (int i = 0; i < XPW; ++i) xp[i] = in_ptr(tile, wv + CV_NW * i);
   // prologue: kernel row 0 of channel step 0 and the whole input tile of channel step 0
   stage_w(part, 0, 0, 0);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { stage_x(xp[i], wv + CV_NW * i, 0); xp[i] += 64; }
+  for (int i = 0; i < XPW; ++i) { stage_x(xp[i], wv + CV_NW * i, 0); xp[i] += 64; }
 
   const size_t obytes = (size_t)p.B * p.H * p.W * p.Cout * sizeof(T);
   const __amdgpu_buffer_rsrc_t o_srd = make_srd(p.out, (unsigned)(obytes < 0xfffffff0ull ? obytes : 0xfffffff0ull));
@@ -165,9 +194,9 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
   bool first_of_tile = false;                              // the step that follows an epilogue: 4 NTW stores are younger than its DMAs
 
   while (true) {
-    f32x4 acc[4][NTW];
+    f32x4 acc[NQ][NTW];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < NQ; ++q)
 #pragma unroll
       for (int t = 0; t < NTW; ++t) acc[q][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     int nit = it + gridDim.x, ntile = 0, npart = 0;
@@ -177,7 +206,7 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
     // one step = one kernel row (3 taps) of one channel step. Slots are compile-time: two channel steps (6 steps) per trip.
     auto step = [&](auto xb_tag, auto ws_tag, auto ky_tag, const int kc) __attribute__((always_inline)) {
       constexpr int XB = decltype(xb_tag)::value, WS = decltype(ws_tag)::value, KY = decltype(ky_tag)::value;
-      if (first_of_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NTW) : "memory");
+      if (first_of_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * NTW) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       first_of_tile = false;
       __builtin_amdgcn_s_barrier();
@@ -188,32 +217,35 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
         else if (!last_kc) stage_w(part, kc + 1, 0, WS ^ 1);
         else if (more) stage_w(npart, 0, 0, WS ^ 1);
         if (!last_kc || more) {
-          if (last_kc) xp[KY] = in_ptr(ntile, wv + CV_NW * KY);
-          stage_x(xp[KY], wv + CV_NW * KY, XB ^ 1);
-          xp[KY] += 64;
+#pragma unroll
+          for (int i = KY; i < XPW; i += 3) {              // pieces KY, KY + 3 of this wave: one or two per step
+            if (last_kc) xp[i] = in_ptr(ntile, wv + CV_NW * i);
+            stage_x(xp[i], wv + CV_NW * i, XB ^ 1);
+            xp[i] += 64;
+          }
         }
       };
       if (CV_STAGE_AFTER_TAP < 0) stage_next();
       const char* xb = xring + XB * CV_XBUF;
       const V8* wf = (const V8*)(wring + WS * CV_WSLOT + lane * 16) + (NTW * ch) * 64;
       // operands of tap kx + 1 are requested before the 20 MFMAs of tap kx (two register sets)
-      V8 a[NTW], b[4];
-      auto load_tap = [&](int kx, V8 (&aa)[NTW], V8 (&bb)[4]) __attribute__((always_inline)) {
+      V8 a[NTW], b[NQ];
+      auto load_tap = [&](int kx, V8 (&aa)[NTW], V8 (&bb)[NQ]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bb[q] = *(const V8*)(xb + KY * PITCH * 64 + (KY & 1 ? seg_e[q][kx] ^ 32u : seg_e[q][kx]));
+        for (int q = 0; q < NQ; ++q) bb[q] = *(const V8*)(xb + KY * PITCH * 64 + ((KY & 1) && ROW_FLIPS ? seg_e[q][kx] ^ 32u : seg_e[q][kx]));
 #pragma unroll
         for (int t = 0; t < NTW; ++t) aa[t] = wf[(kx * CV_NT + t) * 64];
       };
       load_tap(0, a, b);
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
-        V8 an[NTW], bn[4];
+        V8 an[NTW], bn[NQ];
         if (kx < 2) load_tap(kx + 1, an, bn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < NTW; ++t)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q][t] = Tr<T>::mfma(a[t], b[q], acc[q][t]);
+          for (int q = 0; q < NQ; ++q) acc[q][t] = Tr<T>::mfma(a[t], b[q], acc[q][t]);
         __builtin_amdgcn_sched_barrier(0);
         if (kx == CV_STAGE_AFTER_TAP) {
           stage_next();
@@ -223,7 +255,7 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
 #pragma unroll
           for (int t = 0; t < NTW; ++t) a[t] = an[t];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) b[q] = bn[q];
+          for (int q = 0; q < NQ; ++q) b[q] = bn[q];
         }
       }
     };
@@ -239,9 +271,9 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
       step(I1{}, I1{}, I2{}, kc + 1);
     }
     // epilogue: lane (g, c) of tile t holds output channels 16 t + 4 g .. + 3 of pixel c (+ bias, + the residual tensor):
-    // ALWAYS 4 NTW stores of 8 bytes, issued behind every load of the epilogue
+    // ALWAYS NQ * NTW stores of 8 bytes, issued behind every load of the epilogue
     {
-      const int b = tile / p.tiles_per_img, tt = tile - b * p.tiles_per_img;
+      const int b = GEO == 2 ? 2 * tile + (pq >> 1) : tile / p.tiles_per_img, tt = GEO == 2 ? 0 : tile - b * p.tiles_per_img;
       const int ty = tt / p.tiles_x, tx = tt - ty * p.tiles_x;
       typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
       float bs[NTW][4];
@@ -253,23 +285,25 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
         for (int r = 0; r < 4; ++r) bs[t][r] = (float)bv[r];
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int gi = 4 * pq + q;
-        const int ry = TC == 32 ? gi >> 1 : gi, x0 = TC == 32 ? (gi & 1) * 16 : 0;
-        const size_t px = ((size_t)b * p.H + ty * TR + ry) * p.W + tx * TC + x0 + c16;
+      for (int q = 0; q < NQ; ++q) {
+        int ry, x0;
+        seg_rc(q, ry, x0);
+        if (GEO == 2) ry -= 10 * (pq >> 1);
+        const size_t px = ((size_t)b * p.H + ty * TR + ry) * p.W + tx * TC + x0;
+        const bool img_ok = b < p.B;                       // (GEO 2: the second image of the last tile of an odd batch does not exist)
         const unsigned base = (unsigned)((px * p.Cout + part * CV_PART + ch * (16 * NTW) + 4 * g) * sizeof(T));
         V4 rv[NTW];
         if (p.res) {
 #pragma unroll
           for (int t = 0; t < NTW; ++t)
-            rv[t] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b64(r_srd, base + (unsigned)(16 * t * sizeof(T)), 0, 0));
+            rv[t] = __builtin_bit_cast(V4, __builtin_amdgcn_raw_buffer_load_b64(r_srd, img_ok ? base + (unsigned)(16 * t * sizeof(T)) : 0xfffffff0u, 0, 0));
         }
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
           V4 o;
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (T)(acc[q][t][r] + bs[t][r] + (p.res ? (float)rv[t][r] : 0.f));
-          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), o_srd, base + (unsigned)(16 * t * sizeof(T)), 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), o_srd, img_ok ? base + (unsigned)(16 * t * sizeof(T)) : 0xfffffff0u, 0, 0);
         }
       }
     }
@@ -280,10 +314,11 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-bool conv_geom(int H, int W, int& tr, int& tc) {
-  if (W % 32 == 0 && H % 8 == 0) { tr = 8; tc = 32; return true; }
-  if (W == 16 && H % 16 == 0) { tr = 16; tc = 16; return true; }
-  return false;
+int conv_geo(int H, int W) {                  // tile geometry of an H x W image, -1: none
+  if (W % 32 == 0 && H % 8 == 0) return 0;
+  if (W == 16 && H % 16 == 0) return 1;
+  if (W == 8 && H == 8) return 2;
+  return -1;
 }
 
 }  // namespace
@@ -293,8 +328,7 @@ extern "C" {
 static int conv_ntw(int Cout) { return Cout > 0 && Cout % 160 == 0 ? 5 : (Cout > 0 && Cout % 128 == 0 ? 4 : 0); }
 
 int sta_conv3x3_nhwc_supported(int B, int H, int W, int Cin, int Cout) {
-  int tr, tc;
-  if (B <= 0 || !conv_geom(H, W, tr, tc)) return 0;
+  if (B <= 0 || conv_geo(H, W) < 0) return 0;
   if (Cin <= 0 || Cin % 64 || conv_ntw(Cout) == 0) return 0;
   if ((size_t)B * H * W * (size_t)Cout * 2 >= 0xfffffff0ull) return 0;
   return 1;
@@ -327,29 +361,31 @@ int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, con
     return sta_fail(STA_E_UNSUP, "conv3x3_nhwc: unsupported geometry B=%d H=%d W=%d Cin=%d Cout=%d", B, H, W, Cin, Cout);
   if (up2 && (H % 2 || W % 2)) return sta_fail(STA_E_ARG, "conv3x3_nhwc: up2 needs even H, W");
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
-  int tr, tc;
-  conv_geom(H, W, tr, tc);
-  const int ntw = conv_ntw(Cout);
+  const int geo = conv_geo(H, W), ntw = conv_ntw(Cout);
+  const int tr = cv_tr(geo), tc = cv_tc(geo);
   CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, bias, res, B, H, W, Cin, Cout, up2 ? 1 : 0,
        Cout / cv_part(ntw), W / tc, (H / tr) * (W / tc), 0, 0};
-  const long items = (long)B * p.tiles_per_img * p.parts;
+  const long tiles = geo == 2 ? (B + 1) / 2 : (long)B * p.tiles_per_img;
+  const long items = tiles * p.parts;
   if (items >= (1l << 30)) return sta_fail(STA_E_UNSUP, "conv3x3_nhwc: too many tiles");
   p.items = (int)items;
-  p.xcd_map = ((long)B * p.tiles_per_img) % 8 == 0;
+  p.xcd_map = tiles % 8 == 0;
   const unsigned grid = (unsigned)(p.items < 256 ? p.items : 256);
   hipStream_t st = (hipStream_t)stream;
-  static StaLdsAttr attr[8];
-#define STA_CONV_LAUNCH(T, TR, TC, NTW, A)                                                                                         \
+  static StaLdsAttr attr[12];
+#define STA_CONV_LAUNCH(T, GEO, NTW, A)                                                                                            \
   do {                                                                                                                             \
-    if (!attr[A].ensure((const void*)conv3x3_nhwc_kernel<T, TR, TC, NTW>, cv_lds(NTW))) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(conv3x3) failed"); \
-    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, TR, TC, NTW>), dim3(grid), dim3(64 * CV_NW), cv_lds(NTW), st, p);                   \
+    if (!attr[A].ensure((const void*)conv3x3_nhwc_kernel<T, GEO, NTW>, cv_lds(NTW, GEO)))                                          \
+      return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(conv3x3) failed");                                                        \
+    hipLaunchKernelGGL((conv3x3_nhwc_kernel<T, GEO, NTW>), dim3(grid), dim3(64 * CV_NW), cv_lds(NTW, GEO), st, p);                 \
   } while (0)
 #define STA_CONV_GEOM(T, A)                                                                                                        \
   do {                                                                                                                             \
-    if (tc == 32) { if (ntw == 5) STA_CONV_LAUNCH(T, 8, 32, 5, A); else STA_CONV_LAUNCH(T, 8, 32, 4, A + 1); }                     \
-    else { if (ntw == 5) STA_CONV_LAUNCH(T, 16, 16, 5, A + 2); else STA_CONV_LAUNCH(T, 16, 16, 4, A + 3); }                        \
+    if (geo == 0) { if (ntw == 5) STA_CONV_LAUNCH(T, 0, 5, A); else STA_CONV_LAUNCH(T, 0, 4, A + 1); }                             \
+    else if (geo == 1) { if (ntw == 5) STA_CONV_LAUNCH(T, 1, 5, A + 2); else STA_CONV_LAUNCH(T, 1, 4, A + 3); }                    \
+    else { if (ntw == 5) STA_CONV_LAUNCH(T, 2, 5, A + 4); else STA_CONV_LAUNCH(T, 2, 4, A + 5); }                                  \
   } while (0)
-  if (dtype == STA_BF16) STA_CONV_GEOM(__bf16, 0); else STA_CONV_GEOM(_Float16, 4);
+  if (dtype == STA_BF16) STA_CONV_GEOM(__bf16, 0); else STA_CONV_GEOM(_Float16, 6);
 #undef STA_CONV_GEOM
 #undef STA_CONV_LAUNCH
   const hipError_t e = hipGetLastError();

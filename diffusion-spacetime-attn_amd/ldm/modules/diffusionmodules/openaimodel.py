@@ -6,7 +6,7 @@ configs/stable-diffusion/v1-inference.yaml) with the reference's hook surface:
 state_dict (`input_blocks.N.M...`, `middle_block...`, `output_blocks...`, `time_embed`, `out`), so an
 SD-v1-4 checkpoint loads without key remapping. Outside autograd on an NHWC trunk the 3x3 convolutions of the
 ResBlocks and Upsample layers run on csrc/sta_conv.hip (implicit GEMM on the MFMAs; bias, skip add and the nearest-2x
-read folded in); stride-2, 1x1, conv_in / conv_out and the 8x8 level stay on MIOpen, as does everything under autograd.
+read folded in); stride-2, 1x1 and conv_in / conv_out stay on MIOpen, as does everything under autograd.
 """
 import torch
 import torch.nn.functional as F

@@ -95,7 +95,7 @@ int sta_ff_out_res_hfrag(const void* h_frag, const void* packed_w, const void* b
  *   o*so + i*si + ky*sy + kx*sx, strides in elements: any memory format of a [Cout][Cin][3][3] tensor);
  *   up2 = 1: the input is the nearest-neighbour 2x upsampling of x (Upsample.forward), read through (y >> 1, x >> 1) — the
  *   upsampled tensor never exists.
- * sta_conv3x3_nhwc_supported: W % 32 == 0 and H % 8 == 0, or W == 16 and H % 16 == 0; Cin % 64 == 0; Cout % 160 == 0 or
+ * sta_conv3x3_nhwc_supported: W % 32 == 0 and H % 8 == 0, or W == 16 and H % 16 == 0, or H == W == 8; Cin % 64 == 0; Cout % 160 == 0 or
  * Cout % 128 == 0 (a workgroup owns 160 or 128 output channels);
  * out below 4 GiB. Everything else stays with the library convolution.
  */

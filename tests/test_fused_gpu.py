@@ -385,6 +385,9 @@ def test_add_bias_tracked_gradient():
     (2, 128, 128, 64, 64, False),    # the VAE decoder's channel counts: a workgroup owns 128 output channels (4 row tiles per wave)
     (2, 64, 256, 16, 32, True),      # ... its Upsample convolution, two parts
     (4, 64, 512, 16, 16, False),     # ... on the 16 x 16 tile, four parts
+    (4, 64, 160, 8, 8, False),       # the 8 x 8 level: two whole images per tile, two pixel segments per wave
+    (3, 128, 320, 8, 8, False),      # ... odd batch: the last tile holds one image
+    (8, 64, 128, 8, 8, False),       # ... 128-channel parts
     (16, 640, 320, 64, 64, False),   # more items than workgroups: the persistent loop crosses tiles (512 items)
 ])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -431,13 +434,14 @@ def test_conv3x3_batch_split_below_the_descriptor_limit(monkeypatch):
 def test_conv3x3_unsupported_geometries_are_refused():
     from sta import fused, lib
     L = lib.load()
-    assert not L.sta_conv3x3_nhwc_supported(64, 8, 8, 1280, 1280)       # the 8 x 8 level stays with the library
+    assert not L.sta_conv3x3_nhwc_supported(64, 4, 4, 1280, 1280) and not L.sta_conv3x3_nhwc_supported(64, 12, 12, 320, 320)
     assert not L.sta_conv3x3_nhwc_supported(64, 64, 64, 4, 320)         # conv_in
     assert not L.sta_conv3x3_nhwc_supported(64, 64, 64, 320, 4)         # conv_out
     assert L.sta_conv3x3_nhwc_supported(64, 64, 64, 960, 320) and L.sta_conv3x3_nhwc_supported(64, 16, 16, 2560, 1280)
-    x = torch.zeros(64, 320, 8, 8, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    assert L.sta_conv3x3_nhwc_supported(64, 8, 8, 2560, 1280)
+    x = torch.zeros(64, 320, 12, 12, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     w = torch.zeros(320, 320, 3, 3, device="cuda", dtype=torch.float16)
     assert not fused.conv3x3_supported(x, w)
     z = torch.zeros(8192, dtype=torch.uint8, device="cuda")
-    assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), None, None, x.data_ptr(), 64, 8, 8, 320, 320, 0, 1, None) != 0
+    assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), None, None, x.data_ptr(), 64, 12, 12, 320, 320, 0, 1, None) != 0
     assert "unsupported geometry" in lib.last_error()

@@ -553,7 +553,7 @@ def test_bench_step_images_match_single_prompt():
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 def test_full_width_unet_hip_convolutions_match_library_convolutions(dtype, monkeypatch):
     """One CFG call of the FULL-width SD-v1 UNet (NHWC trunk, fixed weights) with the ResBlock / Upsample 3x3 convolutions on
-    csrc/sta_conv.hip (levels 0-2: 64x64, 32x32, 16x16; the bias, skip add and nearest-2x read folded in) against the same call with
+    csrc/sta_conv.hip (all four levels: 64x64, 32x32, 16x16, 8x8; the bias, skip add and nearest-2x read folded in) against the same call with
     every convolution on the library (what the reference-golden tests of the reduced-width UNet run, whose channel counts the HIP
     kernel does not take). Stated tolerance: 1 % of max |eps| per element, 0.3 % of mean |eps| on average — two 16-bit trunks with
     independent roundings (the library path itself moves by that much between its own algorithms)."""
@@ -580,9 +580,9 @@ def test_full_width_unet_hip_convolutions_match_library_convolutions(dtype, monk
         if hip:
             n_hip = len(calls)
     assert len(calls) == n_hip                      # the second pass took no HIP convolution
-    # 2 per ResBlock at levels 0-2 (2 + 2 + 2 down, 3 + 3 + 3 up = 15 blocks) + the three Upsample convolutions
-    assert n_hip == 33 and sum(1 for cc in calls if cc[-1]) == 3, (n_hip, calls)
-    assert {cc[2] for cc in calls} == {64, 32, 16, 8}, calls      # 8: the upsample from the 8x8 level into 16x16
+    # 2 per ResBlock (22 blocks: 2 + 2 + 2 + 2 down, 2 middle, 3 + 3 + 3 + 3 up) + the three Upsample convolutions
+    assert n_hip == 47 and sum(1 for cc in calls if cc[-1]) == 3, (n_hip, calls)
+    assert {cc[2] for cc in calls} == {64, 32, 16, 8}, calls
     ref, got = out[False], out[True]
     assert torch.isfinite(got).all() and ref.abs().max() > 1e-2
     e_max = ((got - ref).abs().max() / ref.abs().max()).item()

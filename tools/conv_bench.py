@@ -20,7 +20,8 @@ use_shipped_miopen_db()
 # (Cin, Cout, H = W, up2, how many per UNet call) — the 3x3 stride-1 convolutions of SD-v1's UNet at 512^2 the kernel takes
 SHAPES = [(320, 320, 64, 0, 7), (640, 320, 64, 0, 2), (960, 320, 64, 0, 1), (640, 640, 64, 1, 1),
           (320, 640, 32, 0, 1), (640, 640, 32, 0, 6), (960, 640, 32, 0, 1), (1280, 640, 32, 0, 1), (1920, 640, 32, 0, 1), (1280, 1280, 32, 1, 1),
-          (640, 1280, 16, 0, 1), (1280, 1280, 16, 0, 6), (1920, 1280, 16, 0, 1), (2560, 1280, 16, 0, 2), (1280, 1280, 16, 1, 1)]
+          (640, 1280, 16, 0, 1), (1280, 1280, 16, 0, 6), (1920, 1280, 16, 0, 1), (2560, 1280, 16, 0, 2), (1280, 1280, 16, 1, 1),
+          (1280, 1280, 8, 0, 11), (2560, 1280, 8, 0, 3)]
 
 
 def timed(fn, iters):
