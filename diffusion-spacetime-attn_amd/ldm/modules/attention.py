@@ -423,10 +423,20 @@ class SpatialTransformer(nn.Module):
         w_in, w_out = self.proj_in.weight[:, :, 0, 0], self.proj_out.weight[:, :, 0, 0]          # [out, in] views
         if _fused.is_nhwc(x):
             # channels_last: 'b c h w -> b (h w) c' IS the memory layout; both projections are plain GEMMs
-            t = F.linear(xn.permute(0, 2, 3, 1).reshape(b, h * w, c), w_in, self.proj_in.bias)
+            rows = xn.permute(0, 2, 3, 1).reshape(b, h * w, c)
+            if c <= 640 and _fused.linear_rows_supported(rows, w_in):
+                # short reductions over many rows: the HIP row GEMM (csrc/sta_gemm.hip; 134 vs 156 us at C = 320, 78 vs 91 at 640)
+                t = _fused.linear_rows(rows, _fused.packed_linear_weight(self, self.proj_in, w_in), inner, bias=self.proj_in.bias)
+            else:
+                t = F.linear(rows, w_in, self.proj_in.bias)
             for blk in self.transformer_blocks:
                 t = blk(t, context=context, time=time, text_index=text_index, coef=coef, bboxs_curr=bboxs_curr)
-            y = F.linear(t, w_out).view(b, h, w, c).permute(0, 3, 1, 2)                            # NHWC view of [b, hw, c]
+            if _fused.linear_rows_supported(t, w_out):
+                # proj_out, its bias and the residual `+ x_in` (attention.py:346) in the GEMM's epilogue: no separate residual pass
+                y = _fused.linear_rows(t, _fused.packed_linear_weight(self, self.proj_out, w_out), c, bias=self.proj_out.bias,
+                                       res=x.permute(0, 2, 3, 1).reshape(b, h * w, c))
+                return y.view(b, h, w, c).permute(0, 3, 1, 2)                                      # NHWC view of [b, hw, c]
+            y = F.linear(t, w_out).view(b, h, w, c).permute(0, 3, 1, 2)
             return _fused.add_bias_nchw(y, x, self.proj_out.bias)
         t = torch.bmm(xn.view(b, c, h * w).transpose(1, 2), w_in.t().unsqueeze(0).expand(b, c, inner))     # [b, hw, inner]
         for i, blk in enumerate(self.transformer_blocks):

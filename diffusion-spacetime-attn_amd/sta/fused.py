@@ -265,9 +265,7 @@ def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None):
     A launch addresses its output through one 32-bit buffer descriptor: batches whose output exceeds 4 GiB go in several launches."""
     B, Cin, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if up2 else (Hs, Ws)
-    z = _conv_zeros.get(x.device)
-    if z is None or z.numel() < 2 * Cin:
-        z = _conv_zeros[x.device] = torch.zeros(max(2 * Cin, 8192), dtype=torch.uint8, device=x.device)
+    z = _zeros_page(x.device, 2 * Cin)
     out = torch.empty((B, Cout, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     if res is not None:
         assert res.shape == out.shape and res.dtype == x.dtype and (is_nhwc(res) or res.is_contiguous(memory_format=torch.channels_last))
@@ -305,6 +303,80 @@ def conv3x3_module(owner, conv, x, bias=None, res=None, up2=False):
         x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
     h = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding)
     return h if bias is None and res is None else add_bias_nchw(h if res is None else res, None if res is None else h, bias)
+
+
+LINEAR_ROWS = True      # the HIP row GEMM for Linear layers / 1x1 convolutions outside autograd (csrc/sta_gemm.hip); False: library GEMM
+LINEAR_MIN_ROWS = 4096  # below this many rows the library GEMM stays (time-embedding, context projections)
+
+
+_retired_pages = []
+
+
+def _zeros_page(device, nbytes):
+    """The page of zeros the convolution / row GEMM kernels read their padding from. Captured hipGraphs hold its address: a page
+    that had to grow is kept alive, never freed."""
+    z = _conv_zeros.get(device)
+    if z is None or z.numel() < nbytes:
+        if z is not None:
+            _retired_pages.append(z)
+        z = _conv_zeros[device] = torch.zeros(max(nbytes, 16384), dtype=torch.uint8, device=device)
+    return z
+
+
+def linear_rows_supported(x, weight):
+    """The HIP row GEMM applies to dense 16-bit CUDA rows outside autograd: x [..., K] contiguous, weight [N, K] (or [N, K, 1, 1])
+    with K % 64 == 0 and N % 160 == 0 or N % 128 == 0, at least LINEAR_MIN_ROWS rows, output below 4 GiB."""
+    if not (LINEAR_ROWS and x.is_cuda and x.dtype in _DT and not torch.is_grad_enabled() and ENABLED and not _hold and weight.dtype == x.dtype):
+        return False
+    K = x.shape[-1]
+    R = x.numel() // K
+    return R >= LINEAR_MIN_ROWS and x.is_contiguous() and bool(lib.load().sta_linear_rows_supported(R, K, weight.shape[0]))
+
+
+def pack_linear_weight(weight):
+    """Linear weight [N, K] (or a 1x1 Conv2d weight [N, K, 1, 1], any memory format) -> the A-operand fragment image of sta_linear_rows."""
+    N, K = weight.shape[0], weight.shape[1]
+    L = lib.load()
+    n = L.sta_linear_rows_packed_w_bytes(K, N)
+    if n == 0 or not weight.is_cuda:
+        raise ValueError("linear_rows: a CUDA weight [N %% 160 == 0 or N %% 128 == 0, K %% 64 == 0]; got %s" % (tuple(weight.shape),))
+    w = weight.detach()
+    buf = torch.empty(n, dtype=torch.uint8, device=w.device)
+    lib.check(L.sta_linear_rows_pack_w(w.data_ptr(), w.stride(0), w.stride(1), buf.data_ptr(), K, N, _DT[w.dtype], _stream()), "sta_linear_rows_pack_w")
+    return buf
+
+
+def linear_rows(x, w_packed, N, bias=None, res=None):
+    """x @ W^T + bias + res over the rows of a contiguous [..., K] tensor; returns [..., N] (csrc/sta_gemm.hip)."""
+    K = x.shape[-1]
+    R = x.numel() // K
+    out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+    if res is not None:
+        assert res.numel() == out.numel() and res.dtype == x.dtype and res.is_contiguous()
+    if bias is not None:
+        bias = bias.to(x.dtype).contiguous()
+    z = _zeros_page(x.device, 2 * K)
+    lib.check(lib.load().sta_linear_rows(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), R, K, N,
+                                         _DT[x.dtype], _stream()), "sta_linear_rows")
+    return out
+
+
+def packed_linear_weight(owner, key_obj, weight):
+    """weight as sta_linear_rows streams it, cached on the owning module and repacked only when the weight tensor changes."""
+    key = (weight.data_ptr(), weight._version, weight.dtype)
+    cache = owner.__dict__.setdefault("_sta_linear_cache", {})
+    hit = cache.get(id(key_obj))
+    if hit is None or hit[0] != key:
+        hit = cache[id(key_obj)] = (key, pack_linear_weight(weight))
+    return hit[1]
+
+
+def linear_module(lin, x, res=None):
+    """lin(x) (+ res) for an nn.Linear outside autograd: the HIP row GEMM where it applies, the library GEMM elsewhere."""
+    if linear_rows_supported(x, lin.weight) and (res is None or res.is_contiguous()):
+        return linear_rows(x, packed_linear_weight(lin, lin, lin.weight), lin.weight.shape[0], bias=lin.bias, res=res)
+    y = torch.nn.functional.linear(x, lin.weight, lin.bias)
+    return y if res is None else y + res
 
 
 def add_bias_nchw(a, b=None, bias=None):

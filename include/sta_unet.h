@@ -106,6 +106,22 @@ int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, con
                      int W, int Cin, int Cout, int up2, int dtype, void* stream);
 
 /*
+ * The Linear layers / 1x1 convolutions of the transformer blocks and ResBlock skips as one row GEMM (csrc/sta_gemm.hip; reference
+ * CrossAttention.to_q / to_k / to_v / to_out attention.py:158-215, FeedForward :48-69, SpatialTransformer.proj_in / proj_out :322-333,
+ * ResBlock.skip_connection openaimodel.py:196-206):
+ *     out[r][n] = sum_k x[r][k] w[n][k] + bias[n] + res[r][n]
+ *   x: [R][K] dtype (tokens of a [B, N, C] tensor or NHWC pixels);  out, res: [R][N] dtype (res may be NULL, may not alias out);
+ *   bias: [N] dtype or NULL;  zeros: >= 2 * K bytes of zeros;  packed_w: sta_linear_rows_pack_w of the weight (element (n, k) at
+ *   n*sn + k*sk, strides in elements), once per model.
+ * Supported: K % 64 == 0; N % 160 == 0 or N % 128 == 0; out below 4 GiB. Outside autograd only.
+ */
+int sta_linear_rows_supported(long R, int K, int N);
+size_t sta_linear_rows_packed_w_bytes(int K, int N);
+int sta_linear_rows_pack_w(const void* w, long sn, long sk, void* packed, int K, int N, int dtype, void* stream);
+int sta_linear_rows(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, long R, int K,
+                    int N, int dtype, void* stream);
+
+/*
  * y = a + b + bias[c]  over NCHW tensors [B][C][HW] (HW % 8 == 0); b and/or bias may be NULL.
  * Replaces a convolution's separate bias pass plus the residual add that follows it
  * (`skip_connection(x) + out_layers(h)`, openaimodel.py ResBlock._forward; `proj_out(x) + x_in`, attention.py:346).

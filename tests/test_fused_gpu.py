@@ -445,3 +445,45 @@ def test_conv3x3_unsupported_geometries_are_refused():
     z = torch.zeros(8192, dtype=torch.uint8, device="cuda")
     assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), None, None, x.data_ptr(), 64, 12, 12, 320, 320, 0, 1, None) != 0
     assert "unsupported geometry" in lib.last_error()
+
+
+@pytest.mark.parametrize("R,K,N", [
+    (4096, 320, 320),        # 16 row tiles x 2 parts, five steps (odd: the ring slot parity alternates between tiles)
+    (8192, 640, 640),        # level-1 projection shape
+    (4096 + 48, 64, 160),    # one step; rows past R in the last tile
+    (20000, 960, 320),       # 15 steps, ragged rows, more items than a small grid in plain order
+    (70000, 320, 1280),      # 274 row tiles x 8 parts: the persistent loop crosses tiles with an odd step count
+    (4096, 1280, 256),       # 128-column parts
+])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("epi", [False, True])
+def test_linear_rows(R, K, N, dtype, epi):
+    """csrc/sta_gemm.hip against an fp32 product of the same 16-bit operands (Linear layers / 1x1 convolutions of the transformer
+    blocks: attention.py:158-215, :322-333): fp32 accumulation over K products, error = the 16-bit rounding of the result."""
+    from sta import fused
+    g = torch.Generator().manual_seed(R + K + N)
+    x = torch.randn(R, K, generator=g).to(dtype)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dtype)
+    bias = (0.5 * torch.randn(N, generator=g)).to(dtype) if epi else None
+    res = torch.randn(R, N, generator=g).to(dtype) if epi else None
+    ref = F.linear(x.float(), w.float(), None if bias is None else bias.float()) + (res.float() if epi else 0.0)
+    with torch.no_grad():
+        xd, wd = x.cuda(), w.cuda()
+        assert fused.linear_rows_supported(xd, wd)
+        got = fused.linear_rows(xd, fused.pack_linear_weight(wd), N, bias=None if bias is None else bias.cuda(), res=None if res is None else res.cuda())
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape
+    _close(got, ref, dtype, k=2.0)
+
+
+def test_linear_rows_conv1x1_weight_and_refusals():
+    from sta import fused, lib
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(4, 1024, 320, generator=g).half().cuda()
+    wc = (torch.randn(320, 320, 1, 1, generator=g) / 18.0).half().cuda().contiguous(memory_format=torch.channels_last)   # a 1x1 Conv2d weight
+    with torch.no_grad():
+        got = fused.linear_rows(x, fused.pack_linear_weight(wc[:, :, 0, 0]), 320)
+        assert not fused.linear_rows_supported(x[:, :8], wc[:, :, 0, 0])          # below LINEAR_MIN_ROWS
+        assert not fused.linear_rows_supported(x, torch.zeros(100, 320, device="cuda", dtype=torch.float16))
+    _close(got, F.linear(x.float().cpu(), wc[:, :, 0, 0].float().cpu()), torch.float16, k=2.0)
+    assert not lib.load().sta_linear_rows_supported(4096, 100, 320) and not lib.load().sta_linear_rows_supported(1 << 24, 320, 320)
