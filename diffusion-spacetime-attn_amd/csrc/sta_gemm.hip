@@ -48,7 +48,9 @@ __global__ __launch_bounds__(64) void pack_gemm_w_kernel(const T* __restrict__ w
 }
 
 struct GM {
-  const char* x;        // [R][K]
+  const char* x;        // [R][K], or [R][Ka] when xb is set
+  const char* xb;       // null, or [R][K - Ka]: the input is the column concatenation [x | xb], read in place (Ka % 64 == 0)
+  int Ka;
   const char* w;        // packed weights
   const char* zeros;    // >= 2 * K bytes of zeros (rows past R)
   void* out;            // [R][N]
@@ -85,11 +87,14 @@ __global__ __launch_bounds__(64 * GM_NW, 1) void gemm_rows_kernel(const GM p) {
     }
   };
   // input piece pc of a step: k-chunk pc >> 4, rows 16 (pc & 15) .. + 15 of the tile; this lane: row + (lane >> 2), LDS slot lane & 3
-  auto in_ptr = [&](long tile, int pc) -> const char* {
+  // (second = true: the first step that reads the second tensor of a concatenated input)
+  const int nsteps_a = p.xb ? p.Ka >> 6 : nsteps;
+  auto in_ptr = [&](long tile, int pc, bool second) -> const char* {
     const int rl = 16 * (pc & 15) + (lane >> 2);
     const long row = tile * GM_ROWS + rl;
     const int chunk = (lane & 3) ^ (((rl >> 2) & 1) << 1);
-    return row < p.R ? p.x + (size_t)row * p.K * sizeof(T) + (pc >> 4) * 64 + chunk * 16 : p.zeros + (pc >> 4) * 64 + chunk * 16;
+    const char* base = second ? p.xb + (size_t)row * (p.K - p.Ka) * sizeof(T) : p.x + (size_t)row * (p.xb ? p.Ka : p.K) * sizeof(T);
+    return row < p.R ? base + (pc >> 4) * 64 + chunk * 16 : p.zeros + (pc >> 4) * 64 + chunk * 16;
   };
   auto stage_w = [&](int part, int step, int slot) __attribute__((always_inline)) {
     const unsigned base = (unsigned)((part * nsteps + step) * WFR) * (unsigned)FRAG;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(64 * GM_NW, 1) void gemm_rows_kernel(const GM p) {
   item_tile(it, tile, part);
   const char* xp[GM_XPER];                                 // this wave's pieces (wv, wv + 8, wv + 16, wv + 24) of the NEXT step
 #pragma unroll
-  for (int i = 0; i < GM_XPER; ++i) xp[i] = in_ptr(tile, wv + GM_NW * i);
+  for (int i = 0; i < GM_XPER; ++i) xp[i] = in_ptr(tile, wv + GM_NW * i, false);
   stage_w(part, 0, 0);
 #pragma unroll
   for (int i = 0; i < GM_XPER; ++i) { stage_x(xp[i], wv + GM_NW * i, 0); xp[i] += 128; }
@@ -156,7 +161,8 @@ __global__ __launch_bounds__(64 * GM_NW, 1) void gemm_rows_kernel(const GM p) {
         if (!last || more) {
 #pragma unroll
           for (int i = 0; i < GM_XPER; ++i) {
-            if (last) xp[i] = in_ptr(ntile, wv + GM_NW * i);
+            if (last) xp[i] = in_ptr(ntile, wv + GM_NW * i, false);
+            else if (st + 1 == nsteps_a) xp[i] = in_ptr(tile, wv + GM_NW * i, true);      // the concatenated input's second tensor starts
             stage_x(xp[i], wv + GM_NW * i, SL ^ 1);
             xp[i] += 128;
           }
@@ -270,14 +276,15 @@ int sta_linear_rows_pack_w(const void* w, long sn, long sk, void* packed, int K,
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_gemm_w launch: %s", hipGetErrorString(e));
 }
 
-int sta_linear_rows(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, long R, int K, int N,
-                    int dtype, void* stream) {
+static int linear_rows_impl(const void* x, const void* xb, int Ka, const void* packed_w, const void* zeros, const void* bias, const void* res,
+                            void* out, long R, int K, int N, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!x || !packed_w || !zeros || !out) return sta_fail(STA_E_ARG, "null pointer");
+  if (xb && (Ka <= 0 || Ka >= K || Ka % 64)) return sta_fail(STA_E_ARG, "linear_rows_cat: Ka=%d of K=%d (need 0 < Ka < K, Ka %% 64 == 0)", Ka, K);
   if (!sta_linear_rows_supported(R, K, N)) return sta_fail(STA_E_UNSUP, "linear_rows: unsupported shape R=%ld K=%d N=%d", R, K, N);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   const int ntw = gemm_ntw(N);
-  GM p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, bias, res, R, K, N, N / gm_part(ntw), 0, 0, (R + GM_ROWS - 1) / GM_ROWS};
+  GM p{(const char*)x, (const char*)xb, Ka, (const char*)packed_w, (const char*)zeros, out, bias, res, R, K, N, N / gm_part(ntw), 0, 0, (R + GM_ROWS - 1) / GM_ROWS};
   const long items = p.tiles * p.parts;
   if (items >= (1l << 30)) return sta_fail(STA_E_UNSUP, "linear_rows: too many tiles");
   p.items = (int)items;
@@ -295,6 +302,17 @@ int sta_linear_rows(const void* x, const void* packed_w, const void* zeros, cons
 #undef STA_GEMM_LAUNCH
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "linear_rows launch: %s", hipGetErrorString(e));
+}
+
+int sta_linear_rows(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, long R, int K, int N,
+                    int dtype, void* stream) {
+  return linear_rows_impl(x, nullptr, 0, packed_w, zeros, bias, res, out, R, K, N, dtype, stream);
+}
+
+int sta_linear_rows_cat(const void* xa, const void* xb, int Ka, const void* packed_w, const void* zeros, const void* bias, const void* res,
+                        void* out, long R, int K, int N, int dtype, void* stream) {
+  if (!xb) { g_sta_err[0] = 0; return sta_fail(STA_E_ARG, "null pointer"); }
+  return linear_rows_impl(xa, xb, Ka, packed_w, zeros, bias, res, out, R, K, N, dtype, stream);
 }
 
 }  // extern "C"

@@ -149,7 +149,7 @@ constexpr int GN_NT = 512;          // threads per workgroup: C / 8 <= 512 colum
 constexpr int GN_MAXG = 64;
 
 template <typename T>
-__global__ __launch_bounds__(GN_NT) void gn_nhwc_stats_kernel(const T* __restrict__ x, const float* __restrict__ add,
+__global__ __launch_bounds__(GN_NT) void gn_nhwc_stats_kernel(const T* __restrict__ x, const T* __restrict__ xb, int Ca, const float* __restrict__ add,
                                                              float* __restrict__ part, int C, int HW, int G, int chunk_px) {
   using V8 = typename V8T<T>::type;
   __shared__ float acc[2 * GN_MAXG];
@@ -167,8 +167,12 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_stats_kernel(const T* __restric
       q[e] = 0.f;
     }
     const int p1 = min(HW, (chunk + 1) * chunk_px);
+    // (xb: the input is the channel concatenation [x | xb] of two tensors with Ca and C - Ca channels, read in place)
+    const bool second = xb && col * 8 >= Ca;
+    const T* src = second ? xb + (col * 8 - Ca) : x + col * 8;
+    const int ld = xb ? (second ? C - Ca : Ca) : C;
     for (int p = chunk * chunk_px + row; p < p1; p += R) {
-      const V8 v = *(const V8*)(x + ((size_t)b * HW + p) * C + col * 8);
+      const V8 v = *(const V8*)(src + ((size_t)b * HW + p) * ld);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float t = (float)v[e] + a[e];
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_stats_kernel(const T* __restric
 }
 
 template <typename T>
-__global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restrict__ x, const float* __restrict__ add,
+__global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restrict__ x, const T* __restrict__ xb, int Ca, const float* __restrict__ add,
                                                              const T* __restrict__ gamma, const T* __restrict__ beta,
                                                              const float* __restrict__ part, T* __restrict__ y, int C, int HW,
                                                              int G, int chunk_px, float eps, int silu) {
@@ -230,9 +234,12 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restric
     bt[e] = (float)beta[c] + (a - mean_s[g]) * gm[e];
   }
   const int p1 = min(HW, (chunk + 1) * chunk_px);
+  const bool second = xb && col * 8 >= Ca;
+  const T* src = second ? xb + (col * 8 - Ca) : x + col * 8;
+  const int ld = xb ? (second ? C - Ca : Ca) : C;
   for (int p = chunk * chunk_px + row; p < p1; p += R) {
     const size_t off = ((size_t)b * HW + p) * C + col * 8;
-    const V8 v = *(const V8*)(x + off);
+    const V8 v = *(const V8*)(src + ((size_t)b * HW + p) * ld);
     V8 o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -617,28 +624,40 @@ size_t sta_groupnorm_nhwc_workspace_bytes(int B, int HW, int G) {
   return (size_t)B * gn_nhwc_chunks(HW) * 2 * G * sizeof(float);
 }
 
-int sta_groupnorm_silu_nhwc(const void* x, const float* add, const void* gamma, const void* beta, void* y,
-                            void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
+static int groupnorm_silu_nhwc_impl(const void* x, const void* xb, int Ca, const float* add, const void* gamma, const void* beta, void* y,
+                                    void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!x || !gamma || !beta || !y || !workspace) return sta_fail(STA_E_ARG, "null pointer");
   if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || G > GN_MAXG || C % G || C % 8 || (C / G < 8 && C / G != 4) || C / 8 > GN_NT)
     return sta_fail(STA_E_ARG, "groupnorm nhwc: B=%d C=%d HW=%d G=%d (need C %% 8 == 0, C/G >= 8 or == 4, C <= %d, G <= %d)", B, C, HW,
                     G, 8 * GN_NT, GN_MAXG);
+  if (xb && (Ca <= 0 || Ca >= C || Ca % 8)) return sta_fail(STA_E_ARG, "groupnorm nhwc cat: Ca=%d of C=%d (need 0 < Ca < C, Ca %% 8 == 0)", Ca, C);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   const int nchunk = gn_nhwc_chunks(HW), chunk_px = (HW + nchunk - 1) / nchunk;
   const dim3 grid(nchunk, B);
   hipStream_t st = (hipStream_t)stream;
   float* part = (float*)workspace;
   if (dtype == STA_BF16) {
-    hipLaunchKernelGGL(gn_nhwc_stats_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, add, part, C, HW, G, chunk_px);
-    hipLaunchKernelGGL(gn_nhwc_apply_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, add, (const __bf16*)gamma,
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, (const __bf16*)xb, Ca, add, part, C, HW, G, chunk_px);
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, (const __bf16*)xb, Ca, add, (const __bf16*)gamma,
                        (const __bf16*)beta, part, (__bf16*)y, C, HW, G, chunk_px, eps, silu);
   } else {
-    hipLaunchKernelGGL(gn_nhwc_stats_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, add, part, C, HW, G, chunk_px);
-    hipLaunchKernelGGL(gn_nhwc_apply_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, add, (const _Float16*)gamma,
+    hipLaunchKernelGGL(gn_nhwc_stats_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, (const _Float16*)xb, Ca, add, part, C, HW, G, chunk_px);
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, (const _Float16*)xb, Ca, add, (const _Float16*)gamma,
                        (const _Float16*)beta, part, (_Float16*)y, C, HW, G, chunk_px, eps, silu);
   }
   return launched("groupnorm_silu_nhwc");
+}
+
+int sta_groupnorm_silu_nhwc(const void* x, const float* add, const void* gamma, const void* beta, void* y,
+                            void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
+  return groupnorm_silu_nhwc_impl(x, nullptr, 0, add, gamma, beta, y, workspace, B, C, HW, G, eps, silu, dtype, stream);
+}
+
+int sta_groupnorm_silu_nhwc_cat(const void* xa, const void* xb, int Ca, const float* add, const void* gamma, const void* beta, void* y,
+                                void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
+  if (!xb) return sta_fail(STA_E_ARG, "null pointer");
+  return groupnorm_silu_nhwc_impl(xa, xb, Ca, add, gamma, beta, y, workspace, B, C, HW, G, eps, silu, dtype, stream);
 }
 
 int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, long rows, int C, int dtype, void* stream) {

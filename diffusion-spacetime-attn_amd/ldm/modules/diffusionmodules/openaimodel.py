@@ -28,6 +28,16 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
     """Feeds each child what it understands (reference openaimodel.py:74-88)."""
 
     def forward(self, x, emb, context=None, time=None, text_index=None, coef=None, bboxs_curr=None):
+        if isinstance(x, tuple):      # (h, skip) of an output block, not concatenated: its first layer reads both in place
+            x = self[0].forward_cat(x[0], x[1], emb)
+            for layer in list(self)[1:]:
+                if isinstance(layer, SpatialTransformer):
+                    x = layer(x, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
+                elif isinstance(layer, TimestepBlock):
+                    x = layer(x, emb)
+                else:
+                    x = layer(x)
+            return x
         for layer in self:
             if isinstance(layer, SpatialTransformer):
                 x = layer(x, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
@@ -101,6 +111,29 @@ class ResBlock(TimestepBlock):
         h = self.in_layers(x)
         h = h + self.emb_layers(emb).type(h.dtype)[:, :, None, None]
         return self.skip_connection(x) + self.out_layers(h)
+
+    def cat_supported(self, xa, xb):
+        sc = self.skip_connection
+        return (isinstance(sc, nn.Conv2d) and sc.kernel_size == (1, 1) and not self.use_checkpoint
+                and _fused.cat_supported(xa, xb, self.in_layers[0].num_groups, sc.weight))
+
+    def forward_cat(self, xa, xb, emb):
+        """_forward_fused of cat([xa, xb], dim=1) without the concatenated tensor (the output blocks' `th.cat([h, hs.pop()], dim=1)`,
+        reference openaimodel.py:740): the first GroupNorm reads both tensors and writes the normalised concatenation, the 1x1 skip
+        convolution is one row GEMM over both."""
+        gn1, _, conv1 = self.in_layers
+        gn2, _, _, conv2 = self.out_layers
+        sc = self.skip_connection
+        b, ca, hh, ww = xa.shape
+        h = _fused.groupnorm_silu_cat(xa, xb, gn1.weight, gn1.bias, gn1.num_groups, gn1.eps)
+        h = _conv3x3(self, conv1, h)
+        add = self.emb_layers(emb).float() + conv1.bias.float()
+        h = _fused.groupnorm_silu(h, gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, add=add)
+        w_sc = sc.weight[:, :, 0, 0]
+        skip = _fused.linear_rows_cat(xa.permute(0, 2, 3, 1).reshape(b, hh * ww, ca), xb.permute(0, 2, 3, 1).reshape(b, hh * ww, xb.shape[1]),
+                                      _fused.packed_linear_weight(self, sc, w_sc), w_sc.shape[0])
+        skip = skip.view(b, hh, ww, -1).permute(0, 3, 1, 2)                            # NHWC view of [b, hw, c]
+        return _conv3x3(self, conv2, h, bias=conv2.bias + sc.bias, res=skip)
 
     def _forward_tracked(self, x, emb):
         """Tracked epochs on an NHWC trunk (opt-in, sta.fused.TRACKED): the op structure of _forward_fused with every glue pass an
@@ -215,7 +248,11 @@ class UNetModel(nn.Module):
             skips.append(h)
         h = self.middle_block(h, emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
         for module in self.output_blocks:
-            h = module(torch.cat([h, skips.pop()], dim=1), emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
+            sk = skips.pop()
+            if isinstance(module[0], ResBlock) and module[0].cat_supported(h, sk):
+                h = module((h, sk), emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)      # the concatenation is read in place
+            else:
+                h = module(torch.cat([h, sk], dim=1), emb, context, time, text_index, coef=coef, bboxs_curr=bboxs_curr)
         if _fused.usable(h):
             gn, _, conv = self.out
             h = _fused.groupnorm_silu(h, gn.weight, gn.bias, gn.num_groups, gn.eps)

@@ -305,6 +305,51 @@ def conv3x3_module(owner, conv, x, bias=None, res=None, up2=False):
     return h if bias is None and res is None else add_bias_nchw(h if res is None else res, None if res is None else h, bias)
 
 
+CAT_IN_PLACE = True     # output blocks read `cat([h, skip])` in place (GroupNorm and the 1x1 skip GEMM take both tensors); False: torch.cat
+
+
+def groupnorm_silu_cat(xa, xb, weight, bias, groups, eps, silu=True):
+    """act(GroupNorm(cat([xa, xb], dim=1))) for two NHWC activations, the concatenation read in place (csrc/sta_unet.hip);
+    returns the normalised concatenated tensor. Callers check cat_supported first."""
+    B, Ca = xa.shape[0], xa.shape[1]
+    C = Ca + xb.shape[1]
+    HW = xa.numel() // (B * Ca)
+    L = lib.load()
+    y = torch.empty((B, C) + tuple(xa.shape[2:]), dtype=xa.dtype, device=xa.device, memory_format=torch.channels_last)
+    ws = torch.empty(L.sta_groupnorm_nhwc_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=xa.device)
+    lib.check(L.sta_groupnorm_silu_nhwc_cat(xa.data_ptr(), xb.data_ptr(), Ca, None, weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
+                                            ws.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[xa.dtype], _stream()),
+              "sta_groupnorm_silu_nhwc_cat")
+    return y
+
+
+def cat_supported(xa, xb, groups, skip_weight):
+    """Both halves NHWC 16-bit outside autograd, channel counts the in-place GroupNorm and the in-place 1x1 skip GEMM take."""
+    if not (CAT_IN_PLACE and usable(xa) and is_nhwc(xa) and is_nhwc(xb) and xa.dtype == xb.dtype and xa.shape[0] == xb.shape[0]
+            and xa.shape[2:] == xb.shape[2:]):
+        return False
+    Ca, C = xa.shape[1], xa.shape[1] + xb.shape[1]
+    if Ca % 64 or C % 8 or C % groups or (C // groups < 8 and C // groups != 4) or C > 4096 or groups > 64:
+        return False
+    rows = xa.numel() // Ca
+    return (LINEAR_ROWS and rows >= LINEAR_MIN_ROWS and skip_weight.dtype == xa.dtype
+            and bool(lib.load().sta_linear_rows_supported(rows, C, skip_weight.shape[0])))
+
+
+def linear_rows_cat(xa, xb, w_packed, N, bias=None, res=None):
+    """cat([xa, xb], dim=-1) @ W^T + bias + res over row tensors [..., Ka] and [..., Kb], the concatenation read in place."""
+    Ka, Kb = xa.shape[-1], xb.shape[-1]
+    R = xa.numel() // Ka
+    assert xa.is_contiguous() and xb.is_contiguous() and xb.numel() // Kb == R and Ka % 64 == 0
+    out = torch.empty(xa.shape[:-1] + (N,), dtype=xa.dtype, device=xa.device)
+    if bias is not None:
+        bias = bias.to(xa.dtype).contiguous()
+    z = _zeros_page(xa.device, 2 * (Ka + Kb))
+    lib.check(lib.load().sta_linear_rows_cat(xa.data_ptr(), xb.data_ptr(), Ka, w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res),
+                                             out.data_ptr(), R, Ka + Kb, N, _DT[xa.dtype], _stream()), "sta_linear_rows_cat")
+    return out
+
+
 LINEAR_ROWS = True      # the HIP row GEMM for Linear layers / 1x1 convolutions outside autograd (csrc/sta_gemm.hip); False: library GEMM
 LINEAR_MIN_ROWS = 4096  # below this many rows the library GEMM stays (time-embedding, context projections)
 

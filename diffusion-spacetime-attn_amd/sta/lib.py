@@ -80,6 +80,8 @@ SYMBOLS = {
     "sta_linear_rows_packed_w_bytes": (_sz, [_i, _i]),
     "sta_linear_rows_pack_w": (_i, [_vp, _l, _l, _vp, _i, _i, _i, _vp]),
     "sta_linear_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "sta_linear_rows_cat": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "sta_groupnorm_silu_nhwc_cat": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "sta_add_bias_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sta_groupnorm_nhwc_workspace_bytes": (_sz, [_i, _i, _i]),
     "sta_groupnorm_silu_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),

@@ -120,6 +120,10 @@ size_t sta_linear_rows_packed_w_bytes(int K, int N);
 int sta_linear_rows_pack_w(const void* w, long sn, long sk, void* packed, int K, int N, int dtype, void* stream);
 int sta_linear_rows(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, long R, int K,
                     int N, int dtype, void* stream);
+/* ... with x the column concatenation [xa | xb] of two row tensors ([R][Ka] and [R][K - Ka], Ka % 64 == 0) read in place — the 1x1
+ * skip convolution over `torch.cat([h, skip], dim=1)` of the UNet's output blocks (openaimodel.py:740) without the concatenated tensor */
+int sta_linear_rows_cat(const void* xa, const void* xb, int Ka, const void* packed_w, const void* zeros, const void* bias, const void* res,
+                        void* out, long R, int K, int N, int dtype, void* stream);
 
 /*
  * y = a + b + bias[c]  over NCHW tensors [B][C][HW] (HW % 8 == 0); b and/or bias may be NULL.
@@ -139,6 +143,10 @@ int sta_add_bias_nchw(const void* a, const void* b, const void* bias, void* y, i
 size_t sta_groupnorm_nhwc_workspace_bytes(int B, int HW, int G);
 int sta_groupnorm_silu_nhwc(const void* x, const float* add, const void* gamma, const void* beta, void* y,
                             void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
+/* ... of the channel concatenation [xa | xb] (Ca and C - Ca channels, Ca % 8 == 0) read in place: y is the normalised concatenated
+ * tensor [B][HW][C]; `torch.cat([h, skip], dim=1)` in front of an output block's first GroupNorm never exists */
+int sta_groupnorm_silu_nhwc_cat(const void* xa, const void* xb, int Ca, const float* add, const void* gamma, const void* beta, void* y,
+                                void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
 
 /* y = a + b + bias (row-broadcast) over [rows][C] tensors (NHWC activations / token tensors); b, bias may be NULL. */
 int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, long rows, int C, int dtype, void* stream);

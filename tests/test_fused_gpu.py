@@ -487,3 +487,43 @@ def test_linear_rows_conv1x1_weight_and_refusals():
         assert not fused.linear_rows_supported(x, torch.zeros(100, 320, device="cuda", dtype=torch.float16))
     _close(got, F.linear(x.float().cpu(), wc[:, :, 0, 0].float().cpu()), torch.float16, k=2.0)
     assert not lib.load().sta_linear_rows_supported(4096, 100, 320) and not lib.load().sta_linear_rows_supported(1 << 24, 320, 320)
+
+
+@pytest.mark.parametrize("B,Ca,Cb,H,G", [(2, 640, 320, 32, 32), (2, 320, 320, 64, 32), (3, 1280, 640, 16, 32), (2, 64, 64, 8, 32), (2, 1280, 1280, 8, 32)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_groupnorm_silu_of_a_concatenation_read_in_place(B, Ca, Cb, H, G, dtype):
+    """GroupNorm + SiLU of cat([xa, xb], dim=1) (the UNet's output blocks, reference openaimodel.py:740 + ResBlock.in_layers) with both
+    tensors read in place, against the same kernel on the materialised concatenation (groups may straddle the seam: 960 / 32) to one
+    ulp (the statistics go through LDS atomics: the summation order is not reproducible) and against the fp32 chain."""
+    from sta import fused
+    g = torch.Generator().manual_seed(Ca + Cb + H)
+    xa = (torch.randn(B, Ca, H, H, generator=g) * 1.3 + 0.2).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    xb = (torch.randn(B, Cb, H, H, generator=g) * 0.7 - 0.4).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    w = (1.0 + 0.2 * torch.randn(Ca + Cb, generator=g)).to(dtype).cuda()
+    b = (0.2 * torch.randn(Ca + Cb, generator=g)).to(dtype).cuda()
+    with torch.no_grad():
+        got = fused.groupnorm_silu_cat(xa, xb, w, b, G, 1e-5)
+        ref = fused.groupnorm_silu(torch.cat([xa, xb], dim=1), w, b, G, 1e-5)
+    assert got.shape == ref.shape and got.is_contiguous(memory_format=torch.channels_last)
+    _close(got, ref.float().cpu(), dtype, k=2.0)
+    ref32 = F.silu(F.group_norm(torch.cat([xa, xb], dim=1).float().cpu(), G, w.float().cpu(), b.float().cpu(), 1e-5))
+    _close(got, ref32, dtype, k=3.0)
+
+
+@pytest.mark.parametrize("R,Ka,Kb,N", [(4096, 320, 320, 320), (8192, 640, 320, 320), (5000, 1280, 640, 640), (4096, 64, 64, 160), (4096, 1280, 1280, 1280)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_linear_rows_of_a_concatenation_read_in_place(R, Ka, Kb, N, dtype):
+    """The 1x1 skip convolution over cat([h, skip]) as one row GEMM over both tensors: bit-identical to the same kernel on the
+    materialised concatenation (same products in the same order)."""
+    from sta import fused
+    g = torch.Generator().manual_seed(R + Ka + N)
+    xa = torch.randn(R, Ka, generator=g).to(dtype).cuda()
+    xb = torch.randn(R, Kb, generator=g).to(dtype).cuda()
+    w = (torch.randn(N, Ka + Kb, generator=g) / (Ka + Kb) ** 0.5).to(dtype).cuda()
+    bias = (0.3 * torch.randn(N, generator=g)).to(dtype).cuda()
+    with torch.no_grad():
+        wp = fused.pack_linear_weight(w)
+        got = fused.linear_rows_cat(xa, xb, wp, N, bias=bias)
+        ref = fused.linear_rows(torch.cat([xa, xb], dim=1), wp, N, bias=bias)
+    assert torch.equal(got, ref)
+    _close(got, F.linear(torch.cat([xa, xb], dim=1).float().cpu(), w.float().cpu(), bias.float().cpu()), dtype, k=2.0)

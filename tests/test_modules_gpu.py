@@ -592,6 +592,39 @@ def test_full_width_unet_hip_convolutions_match_library_convolutions(dtype, monk
     assert e_max < tol[0] and e_mean < tol[1], (e_max, e_mean)
 
 
+def test_full_width_unet_output_blocks_read_the_concatenation_in_place(monkeypatch):
+    """The twelve output blocks of the full-width UNet with `cat([h, skip])` read in place (GroupNorm over both tensors, one row GEMM
+    for the 1x1 skip convolution; reference openaimodel.py:740) against the same call through torch.cat: fp16, within 0.5 % of
+    max |eps| per element (the skip convolution changes from the library's to the row GEMM's summation order)."""
+    from sta import fused, prompt_state
+    from sta.pipeline import build_sd_v1, use_shipped_miopen_db
+    use_shipped_miopen_db(0)
+    dev, dtype = torch.device("cuda", 0), torch.float16
+    model = build_sd_v1(dev, dtype, with_vae=False, init_weights=True, seed=0, channels_last=True)
+    unet = model.model.diffusion_model
+    c, local_ctx, x = gi.unet_inputs(2, 6, lat=64)
+    ctx = torch.cat([gi.load_uncond(), c]).to(dev, dtype)
+    xin = x.expand(2, -1, -1, -1).contiguous().to(dev)
+    t = torch.tensor([981, 981], device=dev)
+    coef = torch.tensor([2.5, 2.5], device=dev)
+    calls = []
+    real = fused.groupnorm_silu_cat
+    monkeypatch.setattr(fused, "groupnorm_silu_cat", lambda *a, **k: (calls.append(a[0].shape[1] + a[1].shape[1]), real(*a, **k))[1])
+    monkeypatch.setattr(fused, "LINEAR_MIN_ROWS", 128)      # batch 2: 128 rows at the 8 x 8 level (the bench batch has 4096)
+    out = {}
+    for inplace in (True, False):
+        monkeypatch.setattr(fused, "CAT_IN_PLACE", inplace)
+        prompt_state.begin_prompt([l.to(dev) for l in local_ctx], first_timestep=981)
+        with torch.no_grad():
+            out[inplace] = unet(xin, 0, t, context=ctx, coef=coef, bboxs_curr=[[0.3, 0.4], [0.7, 0.6]]).float()
+        if inplace:
+            n_in_place = len(calls)
+    assert len(calls) == n_in_place == 12 and sorted(set(calls)) == [640, 960, 1280, 1920, 2560], calls
+    e_max = ((out[True] - out[False]).abs().max() / out[False].abs().max()).item()
+    print("full-width UNet, concatenation in place vs torch.cat: max %.5f (relative)" % e_max)
+    assert e_max < 0.005, e_max
+
+
 def test_vae_decoder_hip_convolutions_match_library_convolutions(monkeypatch):
     """The NHWC KL-VAE decoder (fixed-weight decode) with its 128 / 256 / 512-channel 3x3 convolutions on csrc/sta_conv.hip against the
     same decoder on the library convolutions, and against the NCHW decoder: 2 latents -> 512 x 512 images, fp16. Stated tolerance:
