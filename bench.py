@@ -241,6 +241,16 @@ def source_sha(names=("sta_xattn_proj3.hip", "sta_xattn_proj3.h", "sta_xattn_dev
     return h.hexdigest()[:16]
 
 
+def _trunk_kernels(a):
+    """Which of the trunk's operations run on own HIP kernels in this run (sta.fused switches; the tracked epochs keep the library's
+    differentiable convolutions / GEMMs)."""
+    from sta import fused
+    nhwc = (a.channels_last or a.opt_epochs == 0) and not a.nchw
+    return {"conv3x3": "csrc/sta_conv.hip" if fused.CONV3X3 and nhwc else "MIOpen",
+            "proj_out+residual, skip 1x1 over cat": "csrc/sta_gemm.hip" if fused.LINEAR_ROWS and nhwc else "hipBLASLt / MIOpen",
+            "cat([h, skip]) of the output blocks": "read in place" if fused.CAT_IN_PLACE and fused.LINEAR_ROWS and nhwc else "torch.cat"}
+
+
 def roofline_leg(model, dev, dt, dtype_name, I, K, lat, rec, centres):
     """`roofline` of the JSON line: per-launch times of the cross-attention forward kernels on the tensors of real CFG UNet
     calls of `model` (measure_xattn), the dominant launch against the HBM and MFMA peaks, the 16-launch aggregate beside it."""
@@ -563,6 +573,7 @@ def main():
                    "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt; step j of rank r takes prompts ((j * %d + r) * %d + i) %% 64" % (world, I),
                    "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
                    "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
+                   "trunk_kernels": _trunk_kernels(a),
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,
                    "peak_hbm_gib": round(peak_gb, 1), **({"recompute": ckpt_mode} if a.opt_epochs > 1 else {})},
     }
