@@ -56,6 +56,8 @@ def category(n):
         return "sta xattn (ours)"
     if "selfattn_fwd" in n:
         return "sta self-attention (ours)"
+    if "gemm_rows_kernel" in n or "pack_gemm_w" in n:
+        return "sta row GEMM: proj_in / proj_out + residual, skip 1x1 over the concatenation (ours)"
     if "conv3x3_nhwc_kernel" in n or "pack_conv_w" in n:
         return "sta 3x3 convolution (ours)"
     if "to_out_ln_ofrag" in n or "ff_geglu_qfrag" in n or "ff_out_res_hfrag" in n or "add_layernorm_qfrag" in n or "pack_w" in n:
