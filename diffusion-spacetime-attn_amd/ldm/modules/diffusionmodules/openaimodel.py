@@ -60,6 +60,8 @@ class Upsample(nn.Module):
         if self.use_conv and _fused.conv3x3_supported(x, self.conv.weight, up2=True):
             return _conv3x3(self, self.conv, x, bias=self.conv.bias, up2=True)      # the upsampled tensor is never written
         x = F.interpolate(x, scale_factor=2, mode="nearest")
+        if self.use_conv and _fused.conv3x3_tracked_supported(x, self.conv.weight):
+            return _fused.add_bias_tracked(_fused.conv3x3_tracked(self, self.conv, x), None, self.conv.bias)
         return self.conv(x) if self.use_conv else x
 
 
@@ -140,11 +142,13 @@ class ResBlock(TimestepBlock):
         autograd Function whose backward is one HIP input-gradient kernel (csrc/sta_unet_bwd.hip); convolutions through MIOpen."""
         gn1, _, conv1 = self.in_layers
         gn2, _, _, conv2 = self.out_layers
+        conv = lambda cv, t: (_fused.conv3x3_tracked(self, cv, t) if _fused.conv3x3_tracked_supported(t, cv.weight)
+                              else F.conv2d(t, cv.weight, None, cv.stride, cv.padding))      # forward + input gradient on csrc/sta_conv.hip
         h = _fused.groupnorm_silu_tracked(x, gn1.weight, gn1.bias, gn1.num_groups, gn1.eps)
-        h = F.conv2d(h, conv1.weight, None, conv1.stride, conv1.padding)
+        h = conv(conv1, h)
         add = (self.emb_layers(emb).float() + conv1.bias.float()).detach()            # no path from the blend weights to the embedding
         h = _fused.groupnorm_silu_tracked(h, gn2.weight, gn2.bias, gn2.num_groups, gn2.eps, add=add)
-        h = F.conv2d(h, conv2.weight, None, conv2.stride, conv2.padding)
+        h = conv(conv2, h)
         skip, bias = x, conv2.bias
         if not isinstance(self.skip_connection, nn.Identity):
             sc = self.skip_connection

@@ -564,6 +564,47 @@ class AddBiasFn(torch.autograd.Function):
         return dy, (dy if ctx.has_b else None), None
 
 
+class Conv3x3Fn(torch.autograd.Function):
+    """conv2d(x, w, padding=1) without bias on an NHWC activation with FROZEN weights: forward and input gradient are both
+    csrc/sta_conv.hip — the input gradient of a 3x3 / stride-1 / padding-1 convolution is the same convolution with the weight's
+    channel axes exchanged and its taps mirrored (packed once per model next to the forward image)."""
+
+    @staticmethod
+    def forward(ctx, x, wp_fwd, wp_bwd, cin, cout):
+        ctx.wp_bwd, ctx.cin = wp_bwd, cin
+        return conv3x3_nhwc(x, wp_fwd, cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not is_nhwc(dy):
+            dy = dy.contiguous(memory_format=torch.channels_last)
+        return conv3x3_nhwc(dy, ctx.wp_bwd, ctx.cin), None, None, None, None
+
+
+def conv3x3_tracked_supported(x, weight):
+    """The differentiable HIP convolution applies while autograd records (tracked epochs, fused.TRACKED) to NHWC 16-bit activations
+    and frozen 3x3 weights whose forward AND mirrored images both fit the kernel's channel rules."""
+    if not (CONV3X3 and tracked_usable(x) and x.dim() == 4 and is_nhwc(x) and weight.dtype == x.dtype and not weight.requires_grad
+            and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    B, Cin, H, W = x.shape
+    L = lib.load()
+    Cout = weight.shape[0]
+    return bool(L.sta_conv3x3_nhwc_supported(1, H, W, Cin, Cout) and L.sta_conv3x3_nhwc_supported(1, H, W, Cout, Cin))
+
+
+def conv3x3_tracked(owner, conv, x):
+    """conv(x) WITHOUT its bias for a frozen 3x3 nn.Conv2d under autograd (callers fold the bias into the pass that follows)."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.dtype)
+    cache = owner.__dict__.setdefault("_sta_conv_bwd_cache", {})
+    hit = cache.get(id(conv))
+    if hit is None or hit[0] != key:
+        with torch.no_grad():
+            hit = cache[id(conv)] = (key, pack_conv3x3_weight(w.detach().permute(1, 0, 2, 3).flip(2, 3)))
+    return Conv3x3Fn.apply(x, packed_conv_weight(owner, conv), hit[1], w.shape[1], w.shape[0])
+
+
 def add_bias_tracked(a, b=None, bias=None):
     if not is_nhwc(a) or a.shape[1] % 8 or (b is not None and not is_nhwc(b)):
         t = a if b is None else a + b

@@ -527,3 +527,32 @@ def test_linear_rows_of_a_concatenation_read_in_place(R, Ka, Kb, N, dtype):
         ref = fused.linear_rows(torch.cat([xa, xb], dim=1), wp, N, bias=bias)
     assert torch.equal(got, ref)
     _close(got, F.linear(torch.cat([xa, xb], dim=1).float().cpu(), w.float().cpu(), bias.float().cpu()), dtype, k=2.0)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 320, 320, 32, 32), (2, 640, 320, 16, 16), (1, 128, 320, 64, 64), (4, 320, 640, 8, 8), (2, 960, 320, 16, 32)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv3x3_tracked_gradient(B, Cin, Cout, H, W, dtype):
+    """The differentiable form for the tracked epochs (frozen weights): forward and INPUT GRADIENT both on csrc/sta_conv.hip (the
+    gradient is the convolution with the channel axes exchanged and the taps mirrored) against fp32 autograd of the same operands."""
+    from sta import fused
+    g = torch.Generator().manual_seed(Cin + Cout + H + 7)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dtype)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dtype)
+    dy = torch.randn(B, Cout, H, W, generator=g).to(dtype)
+    xr = x.float().requires_grad_(True)
+    ref = F.conv2d(xr, w.float(), None, 1, 1)
+    ref.backward(dy.float())
+    conv = torch.nn.Conv2d(Cin, Cout, 3, padding=1).to("cuda", dtype)
+    with torch.no_grad():
+        conv.weight.copy_(w)
+    for p_ in conv.parameters():
+        p_.requires_grad_(False)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    with fused.tracked():
+        assert fused.conv3x3_tracked_supported(xg, conv.weight)
+        y = fused.conv3x3_tracked(conv, conv, xg)
+    assert y.grad_fn is not None and "Conv3x3Fn" in type(y.grad_fn).__name__
+    y.backward(dy.cuda())                                     # an NCHW gradient: made NHWC inside
+    torch.cuda.synchronize()
+    _close(y.detach(), ref.detach(), dtype, k=2.0)
+    _close(xg.grad, xr.grad, dtype, k=2.0)
