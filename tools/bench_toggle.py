@@ -11,7 +11,12 @@ from sta import fused  # noqa: E402
 
 for kv in sys.argv[1:sep]:
     k, v = kv.split("=")
-    assert hasattr(fused, k), k
-    setattr(fused, k, type(getattr(fused, k))(int(v)))
+    mod = fused
+    if "." in k:                      # e.g. pipeline.VAE_NHWC_TRACKED=0
+        import importlib
+        mname, k = k.split(".")
+        mod = importlib.import_module("sta." + mname)
+    assert hasattr(mod, k), k
+    setattr(mod, k, type(getattr(mod, k))(int(v)))
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[sep + 1:]
 runpy.run_path(sys.argv[0], run_name="__main__")
