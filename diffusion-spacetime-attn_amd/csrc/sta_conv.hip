@@ -71,6 +71,15 @@ __global__ __launch_bounds__(64) void pack_conv_w_kernel(const T* __restrict__ w
   *(typename Tr<T>::V8*)(packed + (size_t)fr * (FRAG / 2) + lane * 8) = x;
 }
 
+// sum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane: xor 1, xor 2, half-row mirror, row mirror
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));   // row_half_mirror
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));   // row_mirror
+  return x;
+}
+
 struct CV {
   const char* x;        // [B][Hs][Ws][Cin] (Hs = H >> up2)
   const char* w;        // packed weights
@@ -78,6 +87,8 @@ struct CV {
   void* out;            // [B][H][W][Cout]
   const void* bias;     // [Cout] or null
   const void* res;      // [B][H][W][Cout] or null: out = conv + bias + res
+  float* stats;         // null, or [B + 1][stats_slots][Cout][2] fp32: per (image, slot) partial sums / sums of squares of the STORED values
+  int stats_slots;
   int B, H, W, Cin, Cout, up2;
   int parts, tiles_x, tiles_per_img, items, xcd_map;
 };
@@ -206,8 +217,10 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
     // one step = one kernel row (3 taps) of one channel step. Slots are compile-time: two channel steps (6 steps) per trip.
     auto step = [&](auto xb_tag, auto ws_tag, auto ky_tag, const int kc) __attribute__((always_inline)) {
       constexpr int XB = decltype(xb_tag)::value, WS = decltype(ws_tag)::value, KY = decltype(ky_tag)::value;
-      if (first_of_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * NTW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (first_of_tile) {                                 // the epilogue's stores (and statistics atomics) are younger than this step's DMAs
+        if (p.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * NTW + 2 * NTW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * NTW) : "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       first_of_tile = false;
       __builtin_amdgcn_s_barrier();
       // the next step's kernel row, and one piece of the next channel step's input tile
@@ -284,6 +297,11 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
 #pragma unroll
         for (int r = 0; r < 4; ++r) bs[t][r] = (float)bv[r];
       }
+      float ssum[NTW][4], ssq[NTW][4];                     // GroupNorm statistics of the stored values, per output channel
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         int ry, x0;
@@ -304,6 +322,32 @@ __global__ __launch_bounds__(64 * CV_NW, 1) void conv3x3_nhwc_kernel(const CV p)
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (T)(acc[q][t][r] + bs[t][r] + (p.res ? (float)rv[t][r] : 0.f));
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), o_srd, img_ok ? base + (unsigned)(16 * t * sizeof(T)) : 0xfffffff0u, 0, 0);
+          if (p.stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = img_ok ? (float)o[r] : 0.f;
+              ssum[t][r] += v;
+              ssq[t][r] += v * v;
+            }
+          }
+        }
+      }
+      // the consumer's GroupNorm statistics from here (sta_stats_finalize -> sta_groupnorm_silu_nhwc_cstats): sum over the wave's 16 pixel
+      // lanes, then lane c16 == 0 stores the wave's partial sums of its 4 x NTW channels into the slot (tile of the image, pixel quarter)
+      // — plain stores, no atomics (2.6 M atomics per level-0 convolution cost 18 % of it), ALWAYS 2 NTW store instructions per wave
+      if (p.stats) {
+        const int slot = GEO == 2 ? (pq & 1) : tt * 4 + pq;
+        const int bb = b < p.B ? b : p.B;                  // a nonexistent image (GEO 2, odd batch) writes the spare image slot
+        float* dst = p.stats + (((size_t)bb * p.stats_slots + slot) * p.Cout + part * CV_PART + ch * (16 * NTW) + 4 * g) * 2;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          f32x4 lo, hi;
+          lo[0] = row16_sum(ssum[t][0]); lo[1] = row16_sum(ssq[t][0]); lo[2] = row16_sum(ssum[t][1]); lo[3] = row16_sum(ssq[t][1]);
+          hi[0] = row16_sum(ssum[t][2]); hi[1] = row16_sum(ssq[t][2]); hi[2] = row16_sum(ssum[t][3]); hi[3] = row16_sum(ssq[t][3]);
+          if (c16 == 0) {
+            *(f32x4*)(dst + 32 * t) = lo;
+            *(f32x4*)(dst + 32 * t + 4) = hi;
+          }
         }
       }
     }
@@ -334,6 +378,11 @@ int sta_conv3x3_nhwc_supported(int B, int H, int W, int Cin, int Cout) {
   return 1;
 }
 
+int sta_conv3x3_stats_slots(int H, int W) {
+  const int geo = conv_geo(H, W);
+  return geo < 0 ? 0 : geo == 2 ? 2 : 4 * (H / cv_tr(geo)) * (W / cv_tc(geo));
+}
+
 size_t sta_conv3x3_packed_w_bytes(int Cin, int Cout) {
   return (Cin > 0 && Cin % 64 == 0 && conv_ntw(Cout)) ? (size_t)Cout * Cin * 9 * 2 : 0;
 }
@@ -353,8 +402,8 @@ int sta_conv3x3_pack_w(const void* w, long so, long si, long sy, long sx, void* 
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "pack_conv_w launch: %s", hipGetErrorString(e));
 }
 
-int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, int B, int H, int W,
-                     int Cin, int Cout, int up2, int dtype, void* stream) {
+int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, float* stats, int B,
+                     int H, int W, int Cin, int Cout, int up2, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!x || !packed_w || !zeros || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (!sta_conv3x3_nhwc_supported(B, H, W, Cin, Cout))
@@ -363,8 +412,9 @@ int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, con
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   const int geo = conv_geo(H, W), ntw = conv_ntw(Cout);
   const int tr = cv_tr(geo), tc = cv_tc(geo);
-  CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, bias, res, B, H, W, Cin, Cout, up2 ? 1 : 0,
+  CV p{(const char*)x, (const char*)packed_w, (const char*)zeros, out, bias, res, stats, 0, B, H, W, Cin, Cout, up2 ? 1 : 0,
        Cout / cv_part(ntw), W / tc, (H / tr) * (W / tc), 0, 0};
+  p.stats_slots = geo == 2 ? 2 : 4 * p.tiles_per_img;
   const long tiles = geo == 2 ? (B + 1) / 2 : (long)B * p.tiles_per_img;
   const long items = tiles * p.parts;
   if (items >= (1l << 30)) return sta_fail(STA_E_UNSUP, "conv3x3_nhwc: too many tiles");

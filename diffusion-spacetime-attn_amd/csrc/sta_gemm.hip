@@ -47,6 +47,14 @@ __global__ __launch_bounds__(64) void pack_gemm_w_kernel(const T* __restrict__ w
   *(typename Tr<T>::V8*)(packed + (size_t)fr * (FRAG / 2) + lane * 8) = x;
 }
 
+__device__ __forceinline__ float gm_row16_sum(float x) {     // sum over the 16 lanes of a DPP row, result in every lane
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xf, 0xf, true));
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xf, 0xf, true));
+  return x;
+}
+
 struct GM {
   const char* x;        // [R][K], or [R][Ka] when xb is set
   const char* xb;       // null, or [R][K - Ka]: the input is the column concatenation [x | xb], read in place (Ka % 64 == 0)
@@ -56,6 +64,8 @@ struct GM {
   void* out;            // [R][N]
   const void* bias;     // [N] or null
   const void* res;      // [R][N] or null
+  float* stats;         // null, or [R / rows_img + 1][rows_img / 256 * 4][N][2] fp32: per (image, slot) partial sums / sums of squares of the stored values
+  long rows_img;
   long R;
   int K, N, parts, items, xcd_map;
   long tiles;
@@ -150,8 +160,10 @@ __global__ __launch_bounds__(64 * GM_NW, 1) void gemm_rows_kernel(const GM p) {
 
     auto step = [&](auto slot_tag, const int st) __attribute__((always_inline)) {
       constexpr int SL = decltype(slot_tag)::value;
-      if (first_of_tile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NTW) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (first_of_tile) {
+        if (p.stats) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NTW + 2 * NTW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NTW) : "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       first_of_tile = false;
       __builtin_amdgcn_s_barrier();
       const bool last = st + 1 == nsteps;
@@ -221,6 +233,11 @@ __global__ __launch_bounds__(64 * GM_NW, 1) void gemm_rows_kernel(const GM p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bs[t][r] = (float)bv[r];
       }
+      float ssum[NTW][4], ssq[NTW][4];
+#pragma unroll
+      for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ssum[t][r] = 0.f; ssq[t][r] = 0.f; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const long row = tile * GM_ROWS + 64 * pq + 16 * q + c16;
@@ -238,6 +255,32 @@ __global__ __launch_bounds__(64 * GM_NW, 1) void gemm_rows_kernel(const GM p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = (T)(acc[q][t][r] + bs[t][r] + (p.res ? (float)rv[t][r] : 0.f));
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), o_srd, ok ? base + (unsigned)(16 * t * sizeof(T)) : 0xfffffff0u, 0, 0);
+          if (p.stats) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = ok ? (float)o[r] : 0.f;
+              ssum[t][r] += v;
+              ssq[t][r] += v * v;
+            }
+          }
+        }
+      }
+      if (p.stats) {                                       // partial sums of this wave's 4 x NTW columns: ALWAYS 2 NTW stores per wave
+        const long row0 = tile * GM_ROWS;
+        const bool live = row0 < p.R;
+        const long img = live ? row0 / p.rows_img : p.R / p.rows_img;          // (a tile past R writes the spare image slot)
+        const int slot = live ? (int)((row0 - img * p.rows_img) / GM_ROWS) * 4 + pq : pq;
+        const int slots = (int)(p.rows_img / GM_ROWS) * 4;
+        float* dst = p.stats + (((size_t)img * slots + slot) * p.N + part * PART + ch * (16 * NTW) + 4 * g) * 2;
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+          f32x4 lo, hi;
+          lo[0] = gm_row16_sum(ssum[t][0]); lo[1] = gm_row16_sum(ssq[t][0]); lo[2] = gm_row16_sum(ssum[t][1]); lo[3] = gm_row16_sum(ssq[t][1]);
+          hi[0] = gm_row16_sum(ssum[t][2]); hi[1] = gm_row16_sum(ssq[t][2]); hi[2] = gm_row16_sum(ssum[t][3]); hi[3] = gm_row16_sum(ssq[t][3]);
+          if (c16 == 0) {
+            *(f32x4*)(dst + 32 * t) = lo;
+            *(f32x4*)(dst + 32 * t + 4) = hi;
+          }
         }
       }
     }
@@ -277,14 +320,15 @@ int sta_linear_rows_pack_w(const void* w, long sn, long sk, void* packed, int K,
 }
 
 static int linear_rows_impl(const void* x, const void* xb, int Ka, const void* packed_w, const void* zeros, const void* bias, const void* res,
-                            void* out, long R, int K, int N, int dtype, void* stream) {
+                            void* out, long R, int K, int N, int dtype, void* stream, float* stats = nullptr, long rows_img = 0) {
   g_sta_err[0] = 0;
   if (!x || !packed_w || !zeros || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (xb && (Ka <= 0 || Ka >= K || Ka % 64)) return sta_fail(STA_E_ARG, "linear_rows_cat: Ka=%d of K=%d (need 0 < Ka < K, Ka %% 64 == 0)", Ka, K);
   if (!sta_linear_rows_supported(R, K, N)) return sta_fail(STA_E_UNSUP, "linear_rows: unsupported shape R=%ld K=%d N=%d", R, K, N);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   const int ntw = gemm_ntw(N);
-  GM p{(const char*)x, (const char*)xb, Ka, (const char*)packed_w, (const char*)zeros, out, bias, res, R, K, N, N / gm_part(ntw), 0, 0, (R + GM_ROWS - 1) / GM_ROWS};
+  if (stats && (rows_img <= 0 || rows_img % GM_ROWS || R % rows_img)) return sta_fail(STA_E_ARG, "linear_rows_stats: rows_per_image=%ld (need a multiple of 256 dividing R=%ld)", rows_img, R);
+  GM p{(const char*)x, (const char*)xb, Ka, (const char*)packed_w, (const char*)zeros, out, bias, res, stats, rows_img, R, K, N, N / gm_part(ntw), 0, 0, (R + GM_ROWS - 1) / GM_ROWS};
   const long items = p.tiles * p.parts;
   if (items >= (1l << 30)) return sta_fail(STA_E_UNSUP, "linear_rows: too many tiles");
   p.items = (int)items;
@@ -307,6 +351,12 @@ static int linear_rows_impl(const void* x, const void* xb, int Ka, const void* p
 int sta_linear_rows(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, long R, int K, int N,
                     int dtype, void* stream) {
   return linear_rows_impl(x, nullptr, 0, packed_w, zeros, bias, res, out, R, K, N, dtype, stream);
+}
+
+int sta_linear_rows_stats(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, float* stats,
+                          long rows_per_image, long R, int K, int N, int dtype, void* stream) {
+  if (!stats) { g_sta_err[0] = 0; return sta_fail(STA_E_ARG, "null pointer"); }
+  return linear_rows_impl(x, nullptr, 0, packed_w, zeros, bias, res, out, R, K, N, dtype, stream, stats, rows_per_image);
 }
 
 int sta_linear_rows_cat(const void* xa, const void* xb, int Ka, const void* packed_w, const void* zeros, const void* bias, const void* res,

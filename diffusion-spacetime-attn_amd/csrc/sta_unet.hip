@@ -204,6 +204,7 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_stats_kernel(const T* __restric
 
 template <typename T>
 __global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restrict__ x, const T* __restrict__ xb, int Ca, const float* __restrict__ add,
+                                                             const float* __restrict__ cs_a, const float* __restrict__ cs_b,
                                                              const T* __restrict__ gamma, const T* __restrict__ beta,
                                                              const float* __restrict__ part, T* __restrict__ y, int C, int HW,
                                                              int G, int chunk_px, float eps, int silu) {
@@ -214,6 +215,17 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restric
   const int row = threadIdx.x / CV, col = threadIdx.x - row * CV;
   if (threadIdx.x < G) {
     float s = 0.f, q = 0.f;
+    if (cs_a) {
+      // statistics accumulated per CHANNEL by the producing kernel (sum S_c, sum of squares Q_c of the stored values; csrc/sta_conv.hip,
+      // sta_gemm.hip): with the per-(b, c) pre-add a, sum (x + a) = S + HW a and sum (x + a)^2 = Q + 2 a S + HW a^2
+      const int Cb = C - Ca;
+      for (int c = threadIdx.x * Cg; c < (threadIdx.x + 1) * Cg; ++c) {
+        const float* st = (cs_b && c >= Ca) ? cs_b + ((size_t)b * Cb + (c - Ca)) * 2 : cs_a + ((size_t)b * (cs_b ? Ca : C) + c) * 2;
+        const float a = add ? add[(size_t)b * C + c] : 0.f;
+        s += st[0] + (float)HW * a;
+        q += st[1] + 2.f * a * st[0] + (float)HW * a * a;
+      }
+    } else
     for (int k = 0; k < nchunk; ++k) {
       s += part[((size_t)b * nchunk + k) * 2 * G + 2 * threadIdx.x];
       q += part[((size_t)b * nchunk + k) * 2 * G + 2 * threadIdx.x + 1];
@@ -249,6 +261,16 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restric
     }
     *(V8*)(y + off) = o;
   }
+}
+
+// partial[b][slot][c][2] (the epilogues of csrc/sta_conv.hip / sta_gemm.hip) -> stats[b][c][2]: fixed summation order, no atomics
+__global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int slots, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (i >= 2 * C) return;
+  const float* src = partial + (size_t)b * slots * 2 * C + i;
+  float s = 0.f;
+  for (int k = 0; k < slots; ++k) s += src[(size_t)k * 2 * C];
+  stats[(size_t)b * 2 * C + i] = s;
 }
 
 // y = a + b + bias[c] over [rows][C] (NHWC activations or token tensors)
@@ -639,11 +661,11 @@ static int groupnorm_silu_nhwc_impl(const void* x, const void* xb, int Ca, const
   float* part = (float*)workspace;
   if (dtype == STA_BF16) {
     hipLaunchKernelGGL(gn_nhwc_stats_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, (const __bf16*)xb, Ca, add, part, C, HW, G, chunk_px);
-    hipLaunchKernelGGL(gn_nhwc_apply_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, (const __bf16*)xb, Ca, add, (const __bf16*)gamma,
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)x, (const __bf16*)xb, Ca, add, (const float*)nullptr, (const float*)nullptr, (const __bf16*)gamma,
                        (const __bf16*)beta, part, (__bf16*)y, C, HW, G, chunk_px, eps, silu);
   } else {
     hipLaunchKernelGGL(gn_nhwc_stats_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, (const _Float16*)xb, Ca, add, part, C, HW, G, chunk_px);
-    hipLaunchKernelGGL(gn_nhwc_apply_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, (const _Float16*)xb, Ca, add, (const _Float16*)gamma,
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)x, (const _Float16*)xb, Ca, add, (const float*)nullptr, (const float*)nullptr, (const _Float16*)gamma,
                        (const _Float16*)beta, part, (_Float16*)y, C, HW, G, chunk_px, eps, silu);
   }
   return launched("groupnorm_silu_nhwc");
@@ -658,6 +680,37 @@ int sta_groupnorm_silu_nhwc_cat(const void* xa, const void* xb, int Ca, const fl
                                 void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream) {
   if (!xb) return sta_fail(STA_E_ARG, "null pointer");
   return groupnorm_silu_nhwc_impl(xa, xb, Ca, add, gamma, beta, y, workspace, B, C, HW, G, eps, silu, dtype, stream);
+}
+
+int sta_stats_finalize(const float* partial, float* stats, int B, int slots, int C, void* stream) {
+  g_sta_err[0] = 0;
+  if (!partial || !stats) return sta_fail(STA_E_ARG, "null pointer");
+  if (B <= 0 || slots <= 0 || C <= 0) return sta_fail(STA_E_ARG, "stats_finalize: B=%d slots=%d C=%d", B, slots, C);
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((2 * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, partial, stats, slots, C);
+  return launched("stats_finalize");
+}
+
+int sta_groupnorm_silu_nhwc_cstats(const void* xa, const void* xb, int Ca, const float* stats_a, const float* stats_b, const float* add,
+                                   const void* gamma, const void* beta, void* y, int B, int C, int HW, int G, float eps, int silu, int dtype,
+                                   void* stream) {
+  g_sta_err[0] = 0;
+  if (!xa || !stats_a || !gamma || !beta || !y || (xb && !stats_b)) return sta_fail(STA_E_ARG, "null pointer");
+  if (B <= 0 || C <= 0 || HW <= 0 || G <= 0 || G > GN_MAXG || C % G || C % 8 || (C / G < 8 && C / G != 4) || C / 8 > GN_NT)
+    return sta_fail(STA_E_ARG, "groupnorm nhwc: B=%d C=%d HW=%d G=%d (need C %% 8 == 0, C/G >= 8 or == 4, C <= %d, G <= %d)", B, C, HW,
+                    G, 8 * GN_NT, GN_MAXG);
+  if (xb && (Ca <= 0 || Ca >= C || Ca % 8)) return sta_fail(STA_E_ARG, "groupnorm nhwc cat: Ca=%d of C=%d (need 0 < Ca < C, Ca %% 8 == 0)", Ca, C);
+  if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
+  const int nchunk = gn_nhwc_chunks(HW), chunk_px = (HW + nchunk - 1) / nchunk;
+  const dim3 grid(nchunk, B);
+  hipStream_t st = (hipStream_t)stream;
+  if (!xb) Ca = C;
+  if (dtype == STA_BF16)
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<__bf16>, grid, dim3(GN_NT), 0, st, (const __bf16*)xa, (const __bf16*)xb, Ca, add, stats_a, stats_b,
+                       (const __bf16*)gamma, (const __bf16*)beta, (const float*)nullptr, (__bf16*)y, C, HW, G, chunk_px, eps, silu);
+  else
+    hipLaunchKernelGGL(gn_nhwc_apply_kernel<_Float16>, grid, dim3(GN_NT), 0, st, (const _Float16*)xa, (const _Float16*)xb, Ca, add, stats_a, stats_b,
+                       (const _Float16*)gamma, (const _Float16*)beta, (const float*)nullptr, (_Float16*)y, C, HW, G, chunk_px, eps, silu);
+  return launched("groupnorm_silu_nhwc_cstats");
 }
 
 int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, long rows, int C, int dtype, void* stream) {

@@ -434,8 +434,11 @@ class SpatialTransformer(nn.Module):
             if _fused.linear_rows_supported(t, w_out):
                 # proj_out, its bias and the residual `+ x_in` (attention.py:346) in the GEMM's epilogue: no separate residual pass
                 y = _fused.linear_rows(t, _fused.packed_linear_weight(self, self.proj_out, w_out), c, bias=self.proj_out.bias,
-                                       res=x.permute(0, 2, 3, 1).reshape(b, h * w, c))
-                return y.view(b, h, w, c).permute(0, 3, 1, 2)                                      # NHWC view of [b, hw, c]
+                                       res=x.permute(0, 2, 3, 1).reshape(b, h * w, c), stats_rows=h * w if _fused.GN_STATS_FROM_PRODUCER else None)
+                out = y.view(b, h, w, c).permute(0, 3, 1, 2)                                       # NHWC view of [b, hw, c]
+                if hasattr(y, "_sta_stats"):
+                    out._sta_stats = y._sta_stats          # the next GroupNorm's statistics, accumulated by the GEMM's epilogue
+                return out
             y = F.linear(t, w_out).view(b, h, w, c).permute(0, 3, 1, 2)
             return _fused.add_bias_nchw(y, x, self.proj_out.bias)
         t = torch.bmm(xn.view(b, c, h * w).transpose(1, 2), w_in.t().unsqueeze(0).expand(b, c, inner))     # [b, hw, inner]

@@ -84,6 +84,13 @@ def groupnorm_silu(x, weight, bias, groups, eps, add=None, silu=True):
         L = lib.load()
         if C % 8 or (C // groups < 8 and C // groups != 4) or C > 4096 or groups > 64:
             return eager()
+        st = getattr(x, "_sta_stats", None) if GN_STATS_FROM_PRODUCER else None
+        if st is not None:
+            # the kernel that wrote x accumulated every channel's sum and sum of squares (sta_conv3x3_nhwc / sta_linear_rows_stats): one pass
+            lib.check(L.sta_groupnorm_silu_nhwc_cstats(x.data_ptr(), None, C, st.data_ptr(), None, _ptr(add), weight.data_ptr(), bias.data_ptr(),
+                                                       y.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()),
+                      "sta_groupnorm_silu_nhwc_cstats")
+            return y
         ws = torch.empty(L.sta_groupnorm_nhwc_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=x.device)
         lib.check(L.sta_groupnorm_silu_nhwc(x.data_ptr(), _ptr(add), weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                             ws.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[x.dtype], _stream()),
@@ -228,9 +235,17 @@ def ff_out_res_hfrag(x, h_frag, w_packed, bias):
     return out
 
 
+GN_STATS_FROM_PRODUCER = True   # convolutions / row GEMMs accumulate the consumer GroupNorm's statistics in their epilogue (no statistics pass)
 CONV3X3 = True          # the HIP implicit-GEMM 3x3 convolution for the NHWC trunk (csrc/sta_conv.hip); False: library convolution
 _conv_zeros = {}
 CONV_MAX_BYTES = 0xfffffff0 - 1     # output bytes one launch addresses (32-bit buffer descriptor)
+
+
+def _finalize_stats(part, B, slots, C):
+    """[B + 1, slots, C, 2] partial sums of a convolution / row GEMM epilogue -> [B, C, 2] (fixed order, no atomics)."""
+    st = torch.empty((B, C, 2), dtype=torch.float32, device=part.device)
+    lib.check(lib.load().sta_stats_finalize(part.data_ptr(), st.data_ptr(), B, slots, C, _stream()), "sta_stats_finalize")
+    return st
 
 
 def conv3x3_supported(x, weight, up2=False):
@@ -259,10 +274,12 @@ def pack_conv3x3_weight(weight):
     return buf
 
 
-def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None):
+def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None, stats=False):
     """conv2d(x, w, bias, padding=1) + res on an NHWC activation (logical shape [B, Cin, H, W], channels_last strides);
     up2: of the nearest-neighbour 2x upsampling of x, which is never written. Returns [B, Cout, H', W'] channels_last.
-    A launch addresses its output through one 32-bit buffer descriptor: batches whose output exceeds 4 GiB go in several launches."""
+    A launch addresses its output through one 32-bit buffer descriptor: batches whose output exceeds 4 GiB go in several launches.
+    stats: the kernel also accumulates every output channel's sum / sum of squares; they ride on the result as `_sta_stats`
+    ([B, Cout, 2] fp32) for the GroupNorm that consumes it (groupnorm_silu skips its statistics pass)."""
     B, Cin, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if up2 else (Hs, Ws)
     z = _zeros_page(x.device, 2 * Cin)
@@ -275,11 +292,17 @@ def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None):
     per_img = H * W * Cout * esz
     nb = max(1, min(B, CONV_MAX_BYTES // per_img))
     L = lib.load()
+    slots = L.sta_conv3x3_stats_slots(H, W) if stats else 0
+    part = torch.empty((B + 1, slots, Cout, 2), dtype=torch.float32, device=x.device) if slots else None
     for b0 in range(0, B, nb):
         n = min(nb, B - b0)
+        # (a chunk's spare image slot is the next chunk's first image, written later; the last chunk's is the tensor's spare slot)
         lib.check(L.sta_conv3x3_nhwc(x.data_ptr() + b0 * Hs * Ws * Cin * esz, w_packed.data_ptr(), z.data_ptr(), _ptr(bias),
-                                     0 if res is None else res.data_ptr() + b0 * per_img, out.data_ptr() + b0 * per_img, n, H, W, Cin, Cout,
+                                     0 if res is None else res.data_ptr() + b0 * per_img, out.data_ptr() + b0 * per_img,
+                                     0 if part is None else part.data_ptr() + b0 * slots * Cout * 8, n, H, W, Cin, Cout,
                                      int(bool(up2)), _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
+    if part is not None:
+        out._sta_stats = _finalize_stats(part, B, slots, Cout)
     return out
 
 
@@ -298,7 +321,7 @@ def conv3x3_module(owner, conv, x, bias=None, res=None, up2=False):
     """conv(x) (+ bias + res) for a 3x3 nn.Conv2d outside autograd: the HIP convolution where it applies, the library convolution
     (+ the fused bias / residual pass) elsewhere. `bias=None` means bias-free (the caller folds conv.bias into a later pass)."""
     if conv3x3_supported(x, conv.weight, up2=up2) and (res is None or is_nhwc(res)):
-        return conv3x3_nhwc(x, packed_conv_weight(owner, conv), conv.weight.shape[0], up2=up2, bias=bias, res=res)
+        return conv3x3_nhwc(x, packed_conv_weight(owner, conv), conv.weight.shape[0], up2=up2, bias=bias, res=res, stats=GN_STATS_FROM_PRODUCER)
     if up2:
         x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
     h = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding)
@@ -316,6 +339,12 @@ def groupnorm_silu_cat(xa, xb, weight, bias, groups, eps, silu=True):
     HW = xa.numel() // (B * Ca)
     L = lib.load()
     y = torch.empty((B, C) + tuple(xa.shape[2:]), dtype=xa.dtype, device=xa.device, memory_format=torch.channels_last)
+    sa, sb = (getattr(xa, "_sta_stats", None), getattr(xb, "_sta_stats", None)) if GN_STATS_FROM_PRODUCER else (None, None)
+    if sa is not None and sb is not None:
+        lib.check(L.sta_groupnorm_silu_nhwc_cstats(xa.data_ptr(), xb.data_ptr(), Ca, sa.data_ptr(), sb.data_ptr(), None, weight.data_ptr(),
+                                                   bias.data_ptr(), y.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[xa.dtype],
+                                                   _stream()), "sta_groupnorm_silu_nhwc_cstats")
+        return y
     ws = torch.empty(L.sta_groupnorm_nhwc_workspace_bytes(B, HW, groups) // 4, dtype=torch.float32, device=xa.device)
     lib.check(L.sta_groupnorm_silu_nhwc_cat(xa.data_ptr(), xb.data_ptr(), Ca, None, weight.data_ptr(), bias.data_ptr(), y.data_ptr(),
                                             ws.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[xa.dtype], _stream()),
@@ -391,8 +420,9 @@ def pack_linear_weight(weight):
     return buf
 
 
-def linear_rows(x, w_packed, N, bias=None, res=None):
-    """x @ W^T + bias + res over the rows of a contiguous [..., K] tensor; returns [..., N] (csrc/sta_gemm.hip)."""
+def linear_rows(x, w_packed, N, bias=None, res=None, stats_rows=None):
+    """x @ W^T + bias + res over the rows of a contiguous [..., K] tensor; returns [..., N] (csrc/sta_gemm.hip).
+    stats_rows = rows per image (a multiple of 256): per-image, per-column sum / sum of squares ride on the result as `_sta_stats`."""
     K = x.shape[-1]
     R = x.numel() // K
     out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
@@ -401,6 +431,13 @@ def linear_rows(x, w_packed, N, bias=None, res=None):
     if bias is not None:
         bias = bias.to(x.dtype).contiguous()
     z = _zeros_page(x.device, 2 * K)
+    if stats_rows and stats_rows % 256 == 0 and R % stats_rows == 0:
+        n_img, slots = R // stats_rows, stats_rows // 64
+        part = torch.empty((n_img + 1, slots, N, 2), dtype=torch.float32, device=x.device)
+        lib.check(lib.load().sta_linear_rows_stats(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(),
+                                                   part.data_ptr(), stats_rows, R, K, N, _DT[x.dtype], _stream()), "sta_linear_rows_stats")
+        out._sta_stats = _finalize_stats(part, n_img, slots, N)
+        return out
     lib.check(lib.load().sta_linear_rows(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), R, K, N,
                                          _DT[x.dtype], _stream()), "sta_linear_rows")
     return out

@@ -75,11 +75,15 @@ SYMBOLS = {
     "sta_conv3x3_nhwc_supported": (_i, [_i, _i, _i, _i, _i]),
     "sta_conv3x3_packed_w_bytes": (_sz, [_i, _i]),
     "sta_conv3x3_pack_w": (_i, [_vp, _l, _l, _l, _l, _vp, _i, _i, _i, _vp]),
-    "sta_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sta_conv3x3_nhwc": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sta_linear_rows_supported": (_i, [_l, _i, _i]),
     "sta_linear_rows_packed_w_bytes": (_sz, [_i, _i]),
     "sta_linear_rows_pack_w": (_i, [_vp, _l, _l, _vp, _i, _i, _i, _vp]),
     "sta_linear_rows": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
+    "sta_conv3x3_stats_slots": (_i, [_i, _i]),
+    "sta_stats_finalize": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sta_linear_rows_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _l, _i, _i, _i, _vp]),
+    "sta_groupnorm_silu_nhwc_cstats": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "sta_linear_rows_cat": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _vp]),
     "sta_groupnorm_silu_nhwc_cat": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "sta_add_bias_nchw": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -91,6 +91,9 @@ int sta_ff_out_res_hfrag(const void* h_frag, const void* packed_w, const void* b
  *     out = conv(x) + bias + res            (`skip_connection(x) + out_layers(h)` of ResBlock._forward in the epilogue)
  *   x: [B][H >> up2][W >> up2][Cin] dtype;  out: [B][H][W][Cout] dtype;  zeros: >= 2 * Cin bytes of zeros (the padding halo);
  *   bias: [Cout] dtype or NULL;  res: [B][H][W][Cout] dtype or NULL (may not alias out);
+ *   stats: NULL, or [B + 1][sta_conv3x3_stats_slots(H, W)][Cout][2] fp32: every wave stores the partial sum and sum of squares of the values it
+ *   writes, per output channel (plain stores, fixed slots; the spare image absorbs a half-empty tile); sta_stats_finalize folds them into
+ *   [B][Cout][2] — the statistics of the GroupNorm that consumes `out` (sta_groupnorm_silu_nhwc_cstats), whose own statistics pass drops;
  *   packed_w: the weight re-laid out once per model by sta_conv3x3_pack_w (element (o, i, ky, kx) of the source at
  *   o*so + i*si + ky*sy + kx*sx, strides in elements: any memory format of a [Cout][Cin][3][3] tensor);
  *   up2 = 1: the input is the nearest-neighbour 2x upsampling of x (Upsample.forward), read through (y >> 1, x >> 1) — the
@@ -100,10 +103,12 @@ int sta_ff_out_res_hfrag(const void* h_frag, const void* packed_w, const void* b
  * out below 4 GiB. Everything else stays with the library convolution.
  */
 int sta_conv3x3_nhwc_supported(int B, int H, int W, int Cin, int Cout);
+int sta_conv3x3_stats_slots(int H, int W);
+int sta_stats_finalize(const float* partial, float* stats, int B, int slots, int C, void* stream);
 size_t sta_conv3x3_packed_w_bytes(int Cin, int Cout);
 int sta_conv3x3_pack_w(const void* w, long so, long si, long sy, long sx, void* packed, int Cin, int Cout, int dtype, void* stream);
-int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, int B, int H,
-                     int W, int Cin, int Cout, int up2, int dtype, void* stream);
+int sta_conv3x3_nhwc(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, float* stats, int B,
+                     int H, int W, int Cin, int Cout, int up2, int dtype, void* stream);
 
 /*
  * The Linear layers / 1x1 convolutions of the transformer blocks and ResBlock skips as one row GEMM (csrc/sta_gemm.hip; reference
@@ -120,6 +125,10 @@ size_t sta_linear_rows_packed_w_bytes(int K, int N);
 int sta_linear_rows_pack_w(const void* w, long sn, long sk, void* packed, int K, int N, int dtype, void* stream);
 int sta_linear_rows(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, long R, int K,
                     int N, int dtype, void* stream);
+/* ... storing per-(image, slot) partial sums / sums of squares of the stored values to stats [R / rows_per_image + 1][rows_per_image / 64][N][2]
+ * fp32 as sta_conv3x3_nhwc does (fold with sta_stats_finalize): rows_per_image % 256 == 0 (every 256-row tile inside one image) */
+int sta_linear_rows_stats(const void* x, const void* packed_w, const void* zeros, const void* bias, const void* res, void* out, float* stats,
+                          long rows_per_image, long R, int K, int N, int dtype, void* stream);
 /* ... with x the column concatenation [xa | xb] of two row tensors ([R][Ka] and [R][K - Ka], Ka % 64 == 0) read in place — the 1x1
  * skip convolution over `torch.cat([h, skip], dim=1)` of the UNet's output blocks (openaimodel.py:740) without the concatenated tensor */
 int sta_linear_rows_cat(const void* xa, const void* xb, int Ka, const void* packed_w, const void* zeros, const void* bias, const void* res,
@@ -147,6 +156,11 @@ int sta_groupnorm_silu_nhwc(const void* x, const float* add, const void* gamma, 
  * tensor [B][HW][C]; `torch.cat([h, skip], dim=1)` in front of an output block's first GroupNorm never exists */
 int sta_groupnorm_silu_nhwc_cat(const void* xa, const void* xb, int Ca, const float* add, const void* gamma, const void* beta, void* y,
                                 void* workspace, int B, int C, int HW, int G, float eps, int silu, int dtype, void* stream);
+/* ... with the statistics ALREADY accumulated per channel by the producing kernel (stats_a [B][Ca][2], stats_b [B][C - Ca][2] or NULL
+ * with xb; fp32 sum and sum of squares over the HW pixels): one pass instead of two. xb = NULL, Ca = C: a single input tensor. */
+int sta_groupnorm_silu_nhwc_cstats(const void* xa, const void* xb, int Ca, const float* stats_a, const float* stats_b, const float* add,
+                                   const void* gamma, const void* beta, void* y, int B, int C, int HW, int G, float eps, int silu, int dtype,
+                                   void* stream);
 
 /* y = a + b + bias (row-broadcast) over [rows][C] tensors (NHWC activations / token tensors); b, bias may be NULL. */
 int sta_add_bias_rows(const void* a, const void* b, const void* bias, void* y, long rows, int C, int dtype, void* stream);

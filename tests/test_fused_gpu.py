@@ -443,7 +443,7 @@ def test_conv3x3_unsupported_geometries_are_refused():
     w = torch.zeros(320, 320, 3, 3, device="cuda", dtype=torch.float16)
     assert not fused.conv3x3_supported(x, w)
     z = torch.zeros(8192, dtype=torch.uint8, device="cuda")
-    assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), None, None, x.data_ptr(), 64, 12, 12, 320, 320, 0, 1, None) != 0
+    assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), None, None, x.data_ptr(), None, 64, 12, 12, 320, 320, 0, 1, None) != 0
     assert "unsupported geometry" in lib.last_error()
 
 
@@ -556,3 +556,52 @@ def test_conv3x3_tracked_gradient(B, Cin, Cout, H, W, dtype):
     torch.cuda.synchronize()
     _close(y.detach(), ref.detach(), dtype, k=2.0)
     _close(xg.grad, xr.grad, dtype, k=2.0)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,up2", [(2, 64, 320, 32, 32, False), (3, 128, 160, 16, 16, False), (5, 64, 160, 8, 8, False), (2, 64, 256, 16, 32, True),
+                                               (16, 320, 320, 64, 64, False)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv3x3_epilogue_statistics_feed_the_groupnorm(B, Cin, Cout, H, W, up2, dtype):
+    """The convolution's epilogue accumulates every output channel's sum / sum of squares of the values it stores (fp32 atomics); the
+    GroupNorm that consumes the tensor takes them instead of running its statistics pass (ResBlock: conv -> GroupNorm, openaimodel.py
+    in_layers / out_layers). Statistics against torch sums of the stored tensor; the one-pass GroupNorm (with and without the
+    per-(b, c) pre-add) against the two-pass kernel on the same tensor, to two ulps."""
+    from sta import fused
+    g = torch.Generator().manual_seed(B + Cin + Cout + H)
+    Hs, Ws = (H // 2, W // 2) if up2 else (H, W)
+    x = torch.randn(B, Cin, Hs, Ws, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5).to(dtype).cuda()
+    bias = (0.5 * torch.randn(Cout, generator=g)).to(dtype).cuda()
+    res = torch.randn(B, Cout, H, W, generator=g).to(dtype).cuda().contiguous(memory_format=torch.channels_last)
+    gw = (1.0 + 0.2 * torch.randn(Cout, generator=g)).to(dtype).cuda()
+    gb = (0.2 * torch.randn(Cout, generator=g)).to(dtype).cuda()
+    add = torch.randn(B, Cout, generator=g).cuda()
+    with torch.no_grad():
+        wp = fused.pack_conv3x3_weight(w)
+        y = fused.conv3x3_nhwc(x, wp, Cout, up2=up2, bias=bias, res=res, stats=True)
+        plain = fused.conv3x3_nhwc(x, wp, Cout, up2=up2, bias=bias, res=res)
+        assert torch.equal(y, plain) and not hasattr(plain, "_sta_stats")
+        st = y._sta_stats
+        yf = y.float()
+        ref = torch.stack([yf.sum(dim=(2, 3)), (yf * yf).sum(dim=(2, 3))], dim=-1)
+        assert st.shape == (B, Cout, 2)
+        assert ((st - ref).abs() <= 2e-3 * ref.abs() + 2e-2).all(), (st - ref).abs().max().item()
+        for a_ in (None, add):
+            one = fused.groupnorm_silu(y, gw, gb, 32, 1e-5, add=a_)
+            two = fused.groupnorm_silu(plain, gw, gb, 32, 1e-5, add=a_)
+            _close(one, two.float().cpu(), dtype, k=2.0)
+
+
+def test_linear_rows_epilogue_statistics():
+    from sta import fused
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 1024, 320, generator=g).half().cuda()
+    w = (torch.randn(320, 320, generator=g) / 18.0).half().cuda()
+    with torch.no_grad():
+        wp = fused.pack_linear_weight(w)
+        y = fused.linear_rows(x, wp, 320, stats_rows=1024)
+        assert torch.equal(y, fused.linear_rows(x, wp, 320))
+        yf = y.float()
+        ref = torch.stack([yf.sum(dim=1), (yf * yf).sum(dim=1)], dim=-1)
+        assert ((y._sta_stats - ref).abs() <= 2e-3 * ref.abs() + 2e-2).all()
+        assert not hasattr(fused.linear_rows(x, wp, 320, stats_rows=100), "_sta_stats")      # not a multiple of 256: no statistics

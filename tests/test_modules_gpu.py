@@ -625,6 +625,37 @@ def test_full_width_unet_output_blocks_read_the_concatenation_in_place(monkeypat
     assert e_max < 0.005, e_max
 
 
+def test_full_width_unet_groupnorm_statistics_from_the_producers(monkeypatch):
+    """The full-width UNet with every GroupNorm's statistics accumulated in the epilogue of the kernel that wrote its input (3x3
+    convolutions, proj_out row GEMMs; both halves of the output blocks' concatenations) against the same call with the statistics
+    passes: fp16, within 0.3 % of max |eps| (statistics of the same stored values, summed in another order)."""
+    from sta import fused, prompt_state
+    from sta.pipeline import build_sd_v1, use_shipped_miopen_db
+    use_shipped_miopen_db(0)
+    dev, dtype = torch.device("cuda", 0), torch.float16
+    model = build_sd_v1(dev, dtype, with_vae=False, init_weights=True, seed=0, channels_last=True)
+    unet = model.model.diffusion_model
+    c, local_ctx, x = gi.unet_inputs(2, 7, lat=64)
+    ctx = torch.cat([gi.load_uncond(), c]).to(dev, dtype)
+    xin = x.expand(2, -1, -1, -1).contiguous().to(dev)
+    t = torch.tensor([981, 981], device=dev)
+    coef = torch.tensor([2.5, 2.5], device=dev)
+    monkeypatch.setattr(fused, "LINEAR_MIN_ROWS", 128)
+    n = {"one": 0, "two": 0}
+    L = fused.lib.load()
+    real_c, real_t = L.sta_groupnorm_silu_nhwc_cstats, L.sta_groupnorm_silu_nhwc
+    out = {}
+    for on in (True, False):
+        monkeypatch.setattr(fused, "GN_STATS_FROM_PRODUCER", on)
+        prompt_state.begin_prompt([l.to(dev) for l in local_ctx], first_timestep=981)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            out[on] = unet(xin, 0, t, context=ctx, coef=coef, bboxs_curr=[[0.3, 0.4], [0.7, 0.6]]).float()
+    e_max = ((out[True] - out[False]).abs().max() / out[False].abs().max()).item()
+    print("full-width UNet, GroupNorm statistics from the producers vs statistics passes: max %.5f (relative)" % e_max)
+    assert torch.isfinite(out[True]).all() and e_max < 0.003, e_max
+
+
 def test_vae_decoder_hip_convolutions_match_library_convolutions(monkeypatch):
     """The NHWC KL-VAE decoder (fixed-weight decode) with its 128 / 256 / 512-channel 3x3 convolutions on csrc/sta_conv.hip against the
     same decoder on the library convolutions, and against the NCHW decoder: 2 latents -> 512 x 512 images, fp16. Stated tolerance:
