@@ -62,7 +62,7 @@ def category(n):
         return "sta 3x3 convolution (ours)"
     if "to_out_ln_ofrag" in n or "ff_geglu_qfrag" in n or "ff_out_res_hfrag" in n or "add_layernorm_qfrag" in n or "pack_w" in n:
         return "sta level-0 chain: to_out+LN, GEGLU projection, ff output, fragment LayerNorm (ours)"
-    if "gn_silu_kernel" in n or "geglu_kernel" in n or "add_layernorm_kernel" in n or "add_bias_nchw_kernel" in n or "gn_nhwc_" in n or "add_bias_rows_kernel" in n:
+    if "stats_finalize_kernel" in n or "gn_silu_kernel" in n or "geglu_kernel" in n or "add_layernorm_kernel" in n or "add_bias_nchw_kernel" in n or "gn_nhwc_" in n or "add_bias_rows_kernel" in n:
         return "sta trunk glue: GroupNorm/GEGLU/LayerNorm/residual (ours)"
     if "attn_fwd" in n or "attention" in n.lower():
         return "SDPA self-attention (d = 160 levels)"
