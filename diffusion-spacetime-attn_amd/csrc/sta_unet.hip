@@ -263,14 +263,26 @@ __global__ __launch_bounds__(GN_NT) void gn_nhwc_apply_kernel(const T* __restric
   }
 }
 
-// partial[b][slot][c][2] (the epilogues of csrc/sta_conv.hip / sta_gemm.hip) -> stats[b][c][2]: fixed summation order, no atomics
+// partial[b][slot][c][2] (the epilogues of csrc/sta_conv.hip / sta_gemm.hip) -> stats[b][c][2]: fixed summation order, no atomics.
+// A workgroup folds 64 consecutive floats of one image: 16 lanes x float4 across, 16 slot groups down (slots k = sg, sg + 16, ...),
+// then a 16-way tree through LDS — 16-byte loads, at most slots / 16 of them in a thread's chain.
 __global__ __launch_bounds__(256) void stats_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stats, int slots, int C) {
-  const int i = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-  if (i >= 2 * C) return;
-  const float* src = partial + (size_t)b * slots * 2 * C + i;
-  float s = 0.f;
-  for (int k = 0; k < slots; ++k) s += src[(size_t)k * 2 * C];
-  stats[(size_t)b * 2 * C + i] = s;
+  typedef __attribute__((ext_vector_type(4))) float f4;
+  __shared__ f4 red[16][16];
+  const int col = threadIdx.x & 15, sg = threadIdx.x >> 4, b = blockIdx.y;
+  const int i = (blockIdx.x * 16 + col) * 4;                 // first of this lane's four floats inside the 2 C of an image
+  f4 s = {0.f, 0.f, 0.f, 0.f};
+  if (i < 2 * C) {
+    const float* src = partial + (size_t)b * slots * 2 * C + i;
+    for (int k = sg; k < slots; k += 16) s += *(const f4*)(src + (size_t)k * 2 * C);
+  }
+  red[sg][col] = s;
+  __syncthreads();
+  if (sg == 0 && i < 2 * C) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][col];
+    *(f4*)(stats + (size_t)b * 2 * C + i) = s;
+  }
 }
 
 // y = a + b + bias[c] over [rows][C] (NHWC activations or token tensors)
@@ -685,8 +697,8 @@ int sta_groupnorm_silu_nhwc_cat(const void* xa, const void* xb, int Ca, const fl
 int sta_stats_finalize(const float* partial, float* stats, int B, int slots, int C, void* stream) {
   g_sta_err[0] = 0;
   if (!partial || !stats) return sta_fail(STA_E_ARG, "null pointer");
-  if (B <= 0 || slots <= 0 || C <= 0) return sta_fail(STA_E_ARG, "stats_finalize: B=%d slots=%d C=%d", B, slots, C);
-  hipLaunchKernelGGL(stats_finalize_kernel, dim3((2 * C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, partial, stats, slots, C);
+  if (B <= 0 || slots <= 0 || C <= 0 || C % 2) return sta_fail(STA_E_ARG, "stats_finalize: B=%d slots=%d C=%d (C even)", B, slots, C);
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((2 * C + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, partial, stats, slots, C);
   return launched("stats_finalize");
 }
 
