@@ -6,18 +6,24 @@
 //   out[b][y][x][o] = sum_{ky, kx, i} w[o][i][ky][kx] * in[b][y + ky - 1][x + kx - 1][i]          (zero outside the image)
 //
 // Pixels are the MFMA columns: Out^T[o][px] = sum over (tap, 32-channel step) of W_tap[o][i] . X_tap^T[i][px]  (v_mfma_f32_16x16x32).
-//   * A workgroup (8 waves) owns an output tile of 256 pixels (8 rows x 32 columns, or 16 x 16 for 16-pixel-wide images) and 160
-//     output channels; a wave owns 64 of the pixels (four 16-pixel row segments) and 80 of the channels: 20 accumulator tiles.
+//   * A workgroup (8 waves) owns an output tile of 256 pixels (8 rows x 32 columns, 16 x 16 for 16-pixel-wide images, or two whole
+//     8 x 8 images = 128 pixels) and 160 output channels (128 for the VAE decoder's 128 / 256 / 512); a wave owns 64 of the pixels
+//     (four 16-pixel row segments) and 80 (64) of the channels: 20 (16) accumulator tiles.
 //   * The input tile WITH its one-pixel halo ((8+2) x (32+2) pixels x 32 channels = 21.25 KiB per channel step) is copied to LDS
 //     once per channel step by LDS-DMA with per-lane source addresses (pixels outside the image read a page of zeros), double
 //     buffered; all nine taps read their B operands from it: one ds_read_b128 per (tap, pixel segment), with the four 16-byte
 //     channel chunks of a pixel stored at slot g ^ 2 ((p >> 2) & 1) so that the read is bank-conflict-free at every tap offset.
 //   * The weights are re-laid out once per model into 1-KiB A-operand fragments [part][channel step][ky][kx][tile] and streamed
 //     through a 2-slot LDS ring, one kernel row (3 taps x 10 tiles = 30 KiB) per step; a step is 60 MFMAs per wave behind
-//     27 operand reads, one barrier per step, the next step's DMA issued right behind the barrier.
+//     27 operand reads (those of tap kx + 1 requested before the MFMAs of tap kx), one barrier per step, the next step's DMA issued
+//     behind the first tap's MFMAs (at the barrier every wave would pay its issue cost with the matrix pipe idle).
 //   * Workgroups are persistent; the (tile, part) -> workgroup map keeps the parts of one pixel tile on one XCD (shared L2).
 //   * `up2`: the input is the nearest-neighbour 2x upsampling of a half-resolution tensor (Upsample.forward, :107-120): the
 //     halo copy reads pixel (y >> 1, x >> 1) of the small tensor, so the upsampled tensor never exists in HBM.
+//   * Epilogue: + bias + residual tensor (ResBlock's `skip_connection(x) + out_layers(h)`), and — `stats` — the partial sums / sums of
+//     squares per output channel of the values it stores: the statistics of the GroupNorm that consumes the result.
+//   * The input gradient of this convolution is the same convolution with the weight's channel axes exchanged and its taps mirrored:
+//     the tracked epochs run forward and backward on this kernel (sta.fused.Conv3x3Fn).
 //
 // Roofline: MFMA (2 * 9 * Cin * Cout flop per pixel against 2 (Cin + Cout) bytes: 1440 flop/B at 320 -> 320).
 

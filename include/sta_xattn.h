@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STA_VERSION 0x000300 /* 0.3.0: fragment-order entry points (round 4) */
+#define STA_VERSION 0x000400 /* 0.4.0: fragment-order entry points, trunk convolution / row GEMM / producer-side GroupNorm statistics (round 4) */
 
 enum { STA_BF16 = 0, STA_F16 = 1 };
 

@@ -551,7 +551,7 @@ def test_autograd_function_roundtrip():
 def test_error_convention():
     from sta import lib, ops
     L = lib.load()
-    assert L.sta_version() == 0x000300
+    assert L.sta_version() == 0x000400
     assert L.sta_xattn_packed_kv_bytes(4, 8, 41) == 0          # d % 8 != 0
     x = torch.zeros(2, 16, 8 * 168, device="cuda", dtype=torch.bfloat16)
     rc = L.sta_xattn_fwd(x.data_ptr(), x.data_ptr(), 0, 0, x.data_ptr(), 0, 1, 16, 8 * 168, 8, 77, 0, 1.0, 0, 0)
