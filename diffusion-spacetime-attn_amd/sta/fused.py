@@ -236,6 +236,8 @@ def ff_out_res_hfrag(x, h_frag, w_packed, bias):
 
 
 GN_STATS_FROM_PRODUCER = True   # convolutions / row GEMMs accumulate the consumer GroupNorm's statistics in their epilogue (no statistics pass)
+CONV_MIN_ITEMS = 64     # (tile, channel part) work items below which the library convolution is the faster one (a launch feeds 256 CUs:
+                        # at one prompt per step the 16 x 16 / 8 x 8 levels have 16 items and lose 2 - 3 x: tools/conv_bench.py --batch 2)
 CONV3X3 = True          # the HIP implicit-GEMM 3x3 convolution for the NHWC trunk (csrc/sta_conv.hip); False: library convolution
 _conv_zeros = {}
 CONV_MAX_BYTES = 0xfffffff0 - 1     # output bytes one launch addresses (32-bit buffer descriptor)
@@ -257,7 +259,14 @@ def conv3x3_supported(x, weight, up2=False):
     B, Cin, H, W = x.shape
     if up2:
         H, W = 2 * H, 2 * W
-    return bool(lib.load().sta_conv3x3_nhwc_supported(1, H, W, Cin, weight.shape[0]))
+    return bool(lib.load().sta_conv3x3_nhwc_supported(1, H, W, Cin, weight.shape[0])) and conv3x3_work_items(B, H, W, weight.shape[0]) >= CONV_MIN_ITEMS
+
+
+def conv3x3_work_items(B, H, W, Cout):
+    """(pixel tile, output-channel part) items of one sta_conv3x3_nhwc launch: what its 256 persistent workgroups share."""
+    slots = lib.load().sta_conv3x3_stats_slots(H, W)
+    tiles = (B + 1) // 2 if (H, W) == (8, 8) else B * slots // 4
+    return tiles * (Cout // 160 if Cout % 160 == 0 else Cout // 128)
 
 
 def pack_conv3x3_weight(weight):
@@ -627,7 +636,8 @@ def conv3x3_tracked_supported(x, weight):
     B, Cin, H, W = x.shape
     L = lib.load()
     Cout = weight.shape[0]
-    return bool(L.sta_conv3x3_nhwc_supported(1, H, W, Cin, Cout) and L.sta_conv3x3_nhwc_supported(1, H, W, Cout, Cin))
+    return (bool(L.sta_conv3x3_nhwc_supported(1, H, W, Cin, Cout) and L.sta_conv3x3_nhwc_supported(1, H, W, Cout, Cin))
+            and min(conv3x3_work_items(B, H, W, Cout), conv3x3_work_items(B, H, W, Cin)) >= CONV_MIN_ITEMS)
 
 
 def conv3x3_tracked(owner, conv, x):

@@ -6,6 +6,13 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _kernels_at_every_size(monkeypatch):
+    """The product routes launches with few work items to the library (sta.fused.CONV_MIN_ITEMS); the kernel tests cover small shapes too."""
+    from sta import fused
+    monkeypatch.setattr(fused, "CONV_MIN_ITEMS", 1)
+
 EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
 
 
@@ -442,6 +449,13 @@ def test_conv3x3_unsupported_geometries_are_refused():
     x = torch.zeros(64, 320, 12, 12, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
     w = torch.zeros(320, 320, 3, 3, device="cuda", dtype=torch.float16)
     assert not fused.conv3x3_supported(x, w)
+    with torch.no_grad():      # few work items: the library is faster there (tools/conv_bench.py --batch 2)
+        x2 = torch.zeros(2, 1280, 16, 16, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+        w2 = torch.zeros(1280, 1280, 3, 3, device="cuda", dtype=torch.float16)
+        assert fused.conv3x3_supported(x2, w2)
+        fused.CONV_MIN_ITEMS = 64
+        assert not fused.conv3x3_supported(x2, w2) and fused.conv3x3_work_items(2, 16, 16, 1280) == 16
+        assert fused.conv3x3_supported(torch.zeros(64, 1280, 16, 16, device="cuda", dtype=torch.float16).contiguous(memory_format=torch.channels_last), w2)
     z = torch.zeros(8192, dtype=torch.uint8, device="cuda")
     assert L.sta_conv3x3_nhwc(x.data_ptr(), w.data_ptr(), z.data_ptr(), None, None, x.data_ptr(), None, 64, 12, 12, 320, 320, 0, 1, None) != 0
     assert "unsupported geometry" in lib.last_error()

@@ -568,6 +568,7 @@ def test_full_width_unet_hip_convolutions_match_library_convolutions(dtype, monk
     xin = x.expand(2, -1, -1, -1).contiguous().to(dev)
     t = torch.tensor([981, 981], device=dev)
     coef = torch.tensor([2.5, 2.5], device=dev)
+    monkeypatch.setattr(fused, "CONV_MIN_ITEMS", 1)      # batch 2: the deep levels have 16 work items (the product would take the library there)
     calls = []
     real = fused.conv3x3_nhwc
     monkeypatch.setattr(fused, "conv3x3_nhwc", lambda *a, **k: (calls.append(tuple(a[0].shape) + (k.get("up2", False),)), real(*a, **k))[1])
@@ -611,6 +612,7 @@ def test_full_width_unet_output_blocks_read_the_concatenation_in_place(monkeypat
     real = fused.groupnorm_silu_cat
     monkeypatch.setattr(fused, "groupnorm_silu_cat", lambda *a, **k: (calls.append(a[0].shape[1] + a[1].shape[1]), real(*a, **k))[1])
     monkeypatch.setattr(fused, "LINEAR_MIN_ROWS", 128)      # batch 2: 128 rows at the 8 x 8 level (the bench batch has 4096)
+    monkeypatch.setattr(fused, "CONV_MIN_ITEMS", 1)
     out = {}
     for inplace in (True, False):
         monkeypatch.setattr(fused, "CAT_IN_PLACE", inplace)
@@ -642,6 +644,7 @@ def test_full_width_unet_groupnorm_statistics_from_the_producers(monkeypatch):
     t = torch.tensor([981, 981], device=dev)
     coef = torch.tensor([2.5, 2.5], device=dev)
     monkeypatch.setattr(fused, "LINEAR_MIN_ROWS", 128)
+    monkeypatch.setattr(fused, "CONV_MIN_ITEMS", 1)
     n = {"one": 0, "two": 0}
     L = fused.lib.load()
     real_c, real_t = L.sta_groupnorm_silu_nhwc_cstats, L.sta_groupnorm_silu_nhwc
