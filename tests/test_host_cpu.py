@@ -452,3 +452,35 @@ def test_fp16_loss_scale_follows_the_loss_value():
     assert s._loss_scale(11.18) == 1.0
     s.loss_scale = 128.0
     assert s._loss_scale(11.18) == 128.0
+
+
+def test_trunk_kernel_host_entry_points():
+    """Host-only logic of include/sta_unet.h's convolution / row GEMM entry points (geometry rules, sizes, argument checks): no GPU work."""
+    from sta import fused, lib
+    L = lib.load()
+    # 3x3 convolution: 8 x 32 tiles, 16 x 16 tiles, whole 8 x 8 images; Cin % 64; 160- or 128-channel parts; one launch below 4 GiB
+    assert L.sta_conv3x3_nhwc_supported(64, 64, 64, 960, 320) and L.sta_conv3x3_nhwc_supported(64, 16, 16, 2560, 1280)
+    assert L.sta_conv3x3_nhwc_supported(64, 8, 8, 1280, 1280) and L.sta_conv3x3_nhwc_supported(32, 512, 512, 128, 128)
+    assert not L.sta_conv3x3_nhwc_supported(64, 64, 64, 4, 320) and not L.sta_conv3x3_nhwc_supported(64, 64, 64, 320, 4)
+    assert not L.sta_conv3x3_nhwc_supported(64, 48, 48, 640, 640) and not L.sta_conv3x3_nhwc_supported(64, 12, 12, 1280, 1280)
+    assert not L.sta_conv3x3_nhwc_supported(32, 512, 512, 256, 256)                     # 4.3 GB of output: the Python side splits the batch
+    assert L.sta_conv3x3_packed_w_bytes(320, 320) == 320 * 320 * 9 * 2 and L.sta_conv3x3_packed_w_bytes(320, 100) == 0
+    assert L.sta_conv3x3_stats_slots(64, 64) == 4 * 16 and L.sta_conv3x3_stats_slots(16, 16) == 4 and L.sta_conv3x3_stats_slots(8, 8) == 2
+    assert L.sta_conv3x3_stats_slots(12, 12) == 0
+    assert fused.conv3x3_work_items(64, 64, 64, 320) == 64 * 16 * 2 and fused.conv3x3_work_items(2, 16, 16, 1280) == 16
+    assert fused.conv3x3_work_items(3, 8, 8, 1280) == 2 * 8 and fused.conv3x3_work_items(2, 64, 64, 128) == 32
+    assert L.sta_conv3x3_nhwc(0, 0, 0, 0, 0, 0, 0, 64, 64, 64, 320, 320, 0, 1, 0) == -1 and b"null" in L.sta_last_error()
+    assert L.sta_conv3x3_pack_w(8, 1, 1, 1, 1, 8, 100, 320, 1, 0) != 0 and b"Cin" in L.sta_last_error()
+    # row GEMM
+    assert L.sta_linear_rows_supported(262144, 320, 320) and L.sta_linear_rows_supported(4096, 2560, 1280) and L.sta_linear_rows_supported(100, 64, 128)
+    assert not L.sta_linear_rows_supported(4096, 100, 320) and not L.sta_linear_rows_supported(4096, 320, 100)
+    assert not L.sta_linear_rows_supported(1 << 24, 320, 320)                           # 10.7 GB of output
+    assert L.sta_linear_rows_packed_w_bytes(640, 5120) == 640 * 5120 * 2
+    assert L.sta_linear_rows(0, 0, 0, 0, 0, 0, 4096, 320, 320, 1, 0) == -1 and b"null" in L.sta_last_error()
+    assert L.sta_linear_rows_cat(8, 8, 100, 8, 8, 0, 0, 8, 4096, 640, 320, 1, 0) != 0 and b"Ka" in L.sta_last_error()
+    assert L.sta_linear_rows_stats(8, 8, 8, 0, 0, 8, 8, 100, 4096, 320, 320, 1, 0) != 0 and b"rows_per_image" in L.sta_last_error()
+    assert L.sta_groupnorm_silu_nhwc_cstats(0, 0, 320, 0, 0, 0, 0, 0, 0, 2, 320, 4096, 32, 1e-5, 1, 1, 0) == -1
+    assert L.sta_groupnorm_silu_nhwc_cat(8, 8, 100, 0, 8, 8, 8, 8, 2, 640, 4096, 32, 1e-5, 1, 1, 0) != 0 and b"Ca" in L.sta_last_error()
+    assert L.sta_stats_finalize(0, 0, 2, 4, 320, 0) == -1
+    # the product's switches exist with their production values
+    assert fused.CONV3X3 and fused.LINEAR_ROWS and fused.CAT_IN_PLACE and fused.GN_STATS_FROM_PRODUCER and fused.CONV_MIN_ITEMS == 64
