@@ -109,13 +109,14 @@ def test_bench_starts_its_own_ranks_dry_launch():
     """`python bench.py --gpus 2` (the way the driver calls it: no torch.distributed environment) starts two ranks itself; with
     --dry-launch they form the group (gloo here, RCCL on GPUs), move rank 0's weights to rank 1 in scatter + all-gather buckets,
     verify them and stop before the first sampler kernel. ONE JSON line, rc 0."""
-    r, lines = _run_bench("--gpus", "2", "--dry-launch")
+    r, lines = _run_bench("--gpus", "2", "--dry-launch", "--images-per-step", "32")
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["dry_launch"] and out["n_gpus"] == 2 and out["backend"] == "gloo"
     assert out["weights_identical_on_every_rank"] and out["weight_broadcast_bytes"] > 0
-    assert out["global_batch"] == 64 and out["first_prompts_of_step0"] == [0, 1, 32, 33]      # disjoint prompt slices per rank
+    # 2 x 32 prompts = the 64-prompt set of BASELINE configs[3] in disjoint slices (the default, 64 per rank, walks the set once per rank)
+    assert out["global_batch"] == 64 and out["first_prompts_of_step0"] == [0, 1, 32, 33]
 
 
 def test_bench_strong_scaling_split_and_world_mismatch():
