@@ -119,15 +119,14 @@ __device__ __forceinline__ void load_k(KFr<T>& kf, const char* kb, const char* k
 // builtins hipcc let LDS reads stand in for the 2 wait states a swap needs after the VALU write of its operands, and the second
 // swap of every context but the first then read stale registers on gfx950 (tools/p3_debug2.py) — the s_nop are inside the string.
 //
-// FRAGILE BY MEASUREMENT (round 4, profiles/r04_level0.md section 5): this kernel sits on code-generation hazards of hipcc 7.2
-// for gfx950 that its hazard recogniser does not pad — (a) the "=&v" temporaries below may be given the registers of the A operand
-// of an MFMA scheduled right in front of the block, (b) the compiler itself writes blend temporaries (v_fma_f32) into the registers
-// of a chain's intermediate accumulator one wait state behind the MFMA that reads them as its C operand. Whether either pattern is
-// emitted, and whether it lands on live data, depends on the instantiation and on unrelated edits: the fp16 and bf16 row-major and
-// query-fragment instantiations and the fp16 out-fragment one of THIS text are verified against the oracle (tests/test_kernel_gpu.py,
-// tools/dbg_pair.py); the bf16 out-fragment one is wrong (tile 1, registers 0 and 1 of local contexts) and is refused by forward().
-// Every attempted source-level cure (in-out temporaries, copies outside the asm, asm-only swaps in the reductions, nop shields behind
-// the MFMA clusters) moved the failure into other instantiations. Any edit of this file needs tools/dbg_pair.py on the GPU.
+// What round 4 took for a "code-generation hazard around this statement" (profiles/r04_level0.md section 5: the bf16 out-fragment
+// instantiation wrong in registers 0 and 1 of a tile, every source-level cure moving the failure elsewhere) is a hardware rule hipcc
+// 7.2 does not know (profiles/r05_hazard_table.md, tools/hazard_probe.py): an MFMA that reads as C the result of an MFMA of ANOTHER
+// shape (the k = 16 tail of a chain behind its k = 32 steps) fewer than 5 wait states after it, with no third MFMA between them, takes
+// registers 0 and 1 of the tile before they are written. hipcc pads that pair with nothing when the destination is the same, so
+// whether a chain was hit depended on what the scheduler happened to put between the two MFMAs (one v_xor in the bf16 out-fragment
+// instantiation: wrong; three vector instructions in eight others: right by one state). sta.lib.build() compiles every source to
+// assembly, runs sta/isa_lint.py over it and pads what it finds (csrc/.isa_lint.log); all six instantiations are then oracle-exact.
 __device__ __forceinline__ float bcast_row2(float x) {
   unsigned t0, t1;
   asm volatile("s_nop 1\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\t"
@@ -557,9 +556,7 @@ int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* m
   if (qfrag) {      // y in query-fragment order (sta_add_layernorm_qfrag): 1-KiB coalesced loads, no hand-over
     if (N % 16) return sta_fail(STA_E_UNSUP, "query-fragment order needs N %% 16 == 0 (N=%d)", N);
     if (ofrag) {
-      // bf16: hipcc 7.2 miscompiles that instantiation (a write-after-read hazard around the PV MFMAs it does not pad, see bcast_row2)
-      if (dtype == STA_BF16) return sta_fail(STA_E_UNSUP, "out-fragment order: fp16 only (the bf16 instantiation is miscompiled by hipcc 7.2 and refused)");
-      return launch_p3<_Float16, 10, 2, true>(p, n_img, st);
+      return dtype == STA_BF16 ? launch_p3<__bf16, 10, 2, true>(p, n_img, st) : launch_p3<_Float16, 10, 2, true>(p, n_img, st);
     }
     if (C == 320) return dtype == STA_BF16 ? launch_p3<__bf16, 10, 2>(p, n_img, st) : launch_p3<_Float16, 10, 2>(p, n_img, st);
     return dtype == STA_BF16 ? launch_p3<__bf16, 5, 2>(p, n_img, st) : launch_p3<_Float16, 5, 2>(p, n_img, st);

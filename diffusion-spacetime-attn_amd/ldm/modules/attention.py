@@ -276,7 +276,8 @@ class BasicTransformerBlock(nn.Module):
             x = x if s is None else s
             fused_q = cache.packed_proj is not None and not self.keep_maps
             # the GEGLU projection of the feed-forward as one pass over norm3's output in query-fragment order (csrc/sta_ffgemm.hip)
-            ffq = _fused.rowgemm_worthwhile(x) and self._ff_fusable(x)
+            # (oversize batches — the [rows, inner] GEGLU output beyond what a launch addresses — take the row-major path)
+            ffq = self._ff_fusable(x) and _fused.rowgemm_worthwhile(x, self.ff.net[0].proj.out_features // 2)
             # norm2's output has ONE consumer when to_q runs inside the attention kernel: the pass then writes it in the MFMA
             # operand order that kernel loads (query-fragment order, 1-KiB coalesced loads) instead of row-major
             qfrag = fused_q and cache.qfrag
@@ -291,7 +292,7 @@ class BasicTransformerBlock(nn.Module):
                 x, y = _fused.add_layernorm(x, a1(y), None, n2.weight, n2.bias, n2.eps, qfrag=qfrag)
             if fused_q:
                 # to_q runs INSIDE the attention kernel: no [2I, N, C] query round trip through HBM
-                ofrag = qfrag and cache.ofrag and isinstance(self.attn2.to_out[0], nn.Linear)
+                ofrag = qfrag and cache.ofrag and isinstance(self.attn2.to_out[0], nn.Linear) and _fused.rows_addressable(x)
                 blended = _ops.xattn_forward_proj(y, self._wq_fragments(), cache.packed_proj, cache.mask, c, self.attn2.scale, qfrag=qfrag, ofrag=ofrag)
                 if ofrag:
                     # ... and to_out + the residual + norm3 are ONE pass over the kernel's out-fragment output: to_out's [2I, N, C]

@@ -84,7 +84,7 @@ def groupnorm_silu(x, weight, bias, groups, eps, add=None, silu=True):
         L = lib.load()
         if C % 8 or (C // groups < 8 and C // groups != 4) or C > 4096 or groups > 64:
             return eager()
-        st = getattr(x, "_sta_stats", None) if GN_STATS_FROM_PRODUCER else None
+        st = _producer_stats(x) if GN_STATS_FROM_PRODUCER else None
         if st is not None:
             # the kernel that wrote x accumulated every channel's sum and sum of squares (sta_conv3x3_nhwc / sta_linear_rows_stats): one pass
             lib.check(L.sta_groupnorm_silu_nhwc_cstats(x.data_ptr(), None, C, st.data_ptr(), None, _ptr(add), weight.data_ptr(), bias.data_ptr(),
@@ -179,8 +179,27 @@ def to_out_add_layernorm_ofrag(x, blended_ofrag, wo_packed, bias, ln_weight, ln_
 ROWGEMM_MIN_ROWS = 65536
 
 
-def rowgemm_worthwhile(x):
-    return x.numel() // x.shape[-1] >= ROWGEMM_MIN_ROWS
+def _producer_stats(x):
+    """The per-channel sums the producing kernel left on `x` — only while x still holds what that kernel wrote (an in-place update
+    since then bumps the tensor's version and the sums are ignored: the consumer then takes its own statistics pass)."""
+    st = getattr(x, "_sta_stats", None)
+    return st[1] if st is not None and st[0] == x._version else None
+
+
+ROWGEMM_MAX_BYTES = 0xfffffff0 - 1     # what one launch of these passes addresses per tensor (32-bit buffer offsets)
+
+
+def rows_addressable(x, width=None):
+    """The row passes of csrc/sta_rowgemm.hip / sta_ffgemm.hip address every [rows, width] tensor of a launch through one 32-bit
+    buffer descriptor and refuse rows * width * itemsize >= 4 GiB (`width`: the widest tensor of the chain, default x's own — the
+    GEGLU output is [rows, 1280] at C = 320: 205 prompts per step at 512^2, 52 at 1024^2). The gate belongs in FRONT of the chain:
+    once a producer has written fragment order there is no row-major fallback for its consumer."""
+    rows = x.numel() // x.shape[-1]
+    return rows * max(x.shape[-1], width or 0) * x.element_size() <= ROWGEMM_MAX_BYTES
+
+
+def rowgemm_worthwhile(x, width=None):
+    return x.numel() // x.shape[-1] >= ROWGEMM_MIN_ROWS and rows_addressable(x, width)
 
 
 def pack_geglu_weight(weight):
@@ -311,7 +330,7 @@ def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None, stats=False)
                                      0 if part is None else part.data_ptr() + b0 * slots * Cout * 8, n, H, W, Cin, Cout,
                                      int(bool(up2)), _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
     if part is not None:
-        out._sta_stats = _finalize_stats(part, B, slots, Cout)
+        out._sta_stats = (out._version, _finalize_stats(part, B, slots, Cout))
     return out
 
 
@@ -348,7 +367,7 @@ def groupnorm_silu_cat(xa, xb, weight, bias, groups, eps, silu=True):
     HW = xa.numel() // (B * Ca)
     L = lib.load()
     y = torch.empty((B, C) + tuple(xa.shape[2:]), dtype=xa.dtype, device=xa.device, memory_format=torch.channels_last)
-    sa, sb = (getattr(xa, "_sta_stats", None), getattr(xb, "_sta_stats", None)) if GN_STATS_FROM_PRODUCER else (None, None)
+    sa, sb = (_producer_stats(xa), _producer_stats(xb)) if GN_STATS_FROM_PRODUCER else (None, None)
     if sa is not None and sb is not None:
         lib.check(L.sta_groupnorm_silu_nhwc_cstats(xa.data_ptr(), xb.data_ptr(), Ca, sa.data_ptr(), sb.data_ptr(), None, weight.data_ptr(),
                                                    bias.data_ptr(), y.data_ptr(), B, C, HW, groups, float(eps), int(bool(silu)), _DT[xa.dtype],
@@ -445,7 +464,7 @@ def linear_rows(x, w_packed, N, bias=None, res=None, stats_rows=None):
         part = torch.empty((n_img + 1, slots, N, 2), dtype=torch.float32, device=x.device)
         lib.check(lib.load().sta_linear_rows_stats(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(),
                                                    part.data_ptr(), stats_rows, R, K, N, _DT[x.dtype], _stream()), "sta_linear_rows_stats")
-        out._sta_stats = _finalize_stats(part, n_img, slots, N)
+        out._sta_stats = (out._version, _finalize_stats(part, n_img, slots, N))
         return out
     lib.check(lib.load().sta_linear_rows(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), R, K, N,
                                          _DT[x.dtype], _stream()), "sta_linear_rows")

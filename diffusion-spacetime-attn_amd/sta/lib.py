@@ -109,8 +109,45 @@ def _stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+LINT_LOG = os.path.join(CSRC, ".isa_lint.log")
+_LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise StaLibraryError("build step failed: %s\n%s" % (" ".join(cmd), r.stdout + r.stderr))
+
+
+def _compile_checked(hipcc, base, flags, src, obj, workdir, verbose):
+    """One translation unit: device code to ASSEMBLY, the hazard lint + its s_nop cure on that text (sta/isa_lint.py: the table
+    measured by tools/hazard_probe.py, which knows one pair hipcc 7.2 does not pad — an MFMA accumulating into the result of an MFMA
+    of another shape), then assembler -> lld -> bundle -> host compile with that device image: the steps `hipcc -c` runs itself,
+    with the text pass in the middle. -> [(line, wait states inserted, rule)]"""
+    from . import isa_lint
+    stem = os.path.join(workdir, os.path.basename(src))
+    if verbose:
+        print(" ".join(base + flags + ["--cuda-device-only", "-S", src]))
+    _run(base + flags + ["--cuda-device-only", "-S", src, "-o", stem + ".s"])
+    with open(stem + ".s") as fh:
+        text = fh.read()
+    fixed, log = isa_lint.fix_text(text)
+    left = isa_lint.lint_text(fixed)
+    if left:
+        raise StaLibraryError("hazard lint of %s not clean after the s_nop pass:\n%s" % (src, isa_lint.format_findings(left)))
+    with open(stem + ".fixed.s", "w") as fh:
+        fh.write(fixed)
+    _run([_LLVM_BIN + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", stem + ".fixed.s", "-o", stem + ".dev.o"])
+    _run([_LLVM_BIN + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", stem + ".dev.o", "-o", stem + ".dev.out"])
+    _run([_LLVM_BIN + "/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950",
+          "-input=/dev/null", "-input=" + stem + ".dev.out", "-output=" + stem + ".hipfb"])
+    _run(base + flags + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb", "-o", obj])
+    return log
+
+
 def build(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into csrc/libsta_xattn.so (cross-compiles without a GPU)."""
+    """Compile csrc/*.hip for gfx950 into csrc/libsta_xattn.so (cross-compiles without a GPU). Every kernel's assembly passes the
+    hazard lint (and its deterministic cure) on the way: csrc/.isa_lint.log lists what was padded."""
     if not force and not _stale():
         return LIB_PATH
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -118,26 +155,31 @@ def build(force=False, verbose=False):
         raise StaLibraryError("hipcc not found; cannot build %s" % LIB_PATH)
     base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE, "-I", CSRC,
             *os.environ.get("STA_HIPCC_FLAGS", "").split()]           # env: experiments only (tools/)
-    objs, procs = [], []
-    for src in SOURCES:                 # one hipcc per source, side by side
-        obj = os.path.join(CSRC, "." + os.path.basename(src) + ".o")
-        cmd = base + PER_SOURCE_FLAGS.get(os.path.basename(src), []) + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
-    for cmd, pr in procs:
-        out, _ = pr.communicate()
-        if pr.returncode != 0:
-            raise StaLibraryError("hipcc failed: %s\n%s" % (" ".join(cmd), out))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    for o in objs:
-        if os.path.exists(o):
-            os.remove(o)
-    if r.returncode != 0:
-        raise StaLibraryError("link failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    workdir = tempfile.mkdtemp(prefix="sta_build_")
+    objs = [os.path.join(workdir, os.path.basename(src) + ".o") for src in SOURCES]
+    try:
+        with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:      # one pipeline per source, side by side
+            futs = [ex.submit(_compile_checked, hipcc, base, PER_SOURCE_FLAGS.get(os.path.basename(src), []), src, obj, workdir, verbose)
+                    for src, obj in zip(SOURCES, objs)]
+            logs = [f.result() for f in futs]
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise StaLibraryError("link failed:\n" + r.stdout + r.stderr)
+        os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    finally:
+        shutil.rmtree(workdir, ignore_errors=True)
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    with open(LINT_LOG, "w") as fh:
+        fh.write("# %s\n" % (ver[0] if ver else "hipcc ?"))
+        for src, log in zip(SOURCES, logs):
+            fh.write("%s: %d site(s) padded\n" % (os.path.basename(src), len(log)))
+            for ln, states, rule in sorted(log):
+                fh.write("    line %d: +%d wait state(s): %s\n" % (ln, states, rule))
+    if verbose:
+        print(open(LINT_LOG).read())
     return LIB_PATH
 
 

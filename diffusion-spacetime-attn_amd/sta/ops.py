@@ -301,8 +301,8 @@ def to_ofrag(x):
 
 def proj_ofrag_supported(C, heads, dtype=torch.float16):
     """Shapes whose blended output the attention kernel can leave in out-fragment order for sta.fused.to_out_add_layernorm_ofrag:
-    C = 320 with 8 heads, fp16 (the bf16 instantiation of that kernel is miscompiled by hipcc 7.2 and refused by the library)."""
-    return dtype == torch.float16 and bool(_lib.load().sta_to_out_ln_packed_wo_bytes(C, heads))
+    C = 320 with 8 heads, fp16 and bf16."""
+    return bool(_lib.load().sta_to_out_ln_packed_wo_bytes(C, heads))
 
 
 def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofrag=False):

@@ -595,7 +595,7 @@ def test_conv3x3_epilogue_statistics_feed_the_groupnorm(B, Cin, Cout, H, W, up2,
         y = fused.conv3x3_nhwc(x, wp, Cout, up2=up2, bias=bias, res=res, stats=True)
         plain = fused.conv3x3_nhwc(x, wp, Cout, up2=up2, bias=bias, res=res)
         assert torch.equal(y, plain) and not hasattr(plain, "_sta_stats")
-        st = y._sta_stats
+        st = fused._producer_stats(y)
         yf = y.float()
         ref = torch.stack([yf.sum(dim=(2, 3)), (yf * yf).sum(dim=(2, 3))], dim=-1)
         assert st.shape == (B, Cout, 2)
@@ -617,5 +617,7 @@ def test_linear_rows_epilogue_statistics():
         assert torch.equal(y, fused.linear_rows(x, wp, 320))
         yf = y.float()
         ref = torch.stack([yf.sum(dim=1), (yf * yf).sum(dim=1)], dim=-1)
-        assert ((y._sta_stats - ref).abs() <= 2e-3 * ref.abs() + 2e-2).all()
+        assert ((fused._producer_stats(y) - ref).abs() <= 2e-3 * ref.abs() + 2e-2).all()
+        y.add_(1.0)                                     # an in-place update: the producer's sums no longer describe y and are ignored
+        assert fused._producer_stats(y) is None
         assert not hasattr(fused.linear_rows(x, wp, 320, stats_rows=100), "_sta_stats")      # not a multiple of 256: no statistics

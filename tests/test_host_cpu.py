@@ -484,3 +484,15 @@ def test_trunk_kernel_host_entry_points():
     assert L.sta_stats_finalize(0, 0, 2, 4, 320, 0) == -1
     # the product's switches exist with their production values
     assert fused.CONV3X3 and fused.LINEAR_ROWS and fused.CAT_IN_PLACE and fused.GN_STATS_FROM_PRODUCER and fused.CONV_MIN_ITEMS == 64
+
+
+def test_fused_row_passes_are_gated_by_what_a_launch_addresses():
+    """the fragment-order chain of level 0 refuses rows * width * 2 >= 4 GiB inside the C-ABI, where no row-major fallback
+    is left; the Python gate in front of the chain must say no first (205 prompts per step at 512^2 for the [rows, 1280] GEGLU output)."""
+    from sta import fused
+    mk = lambda prompts, n=4096: torch.empty(2 * prompts, n, 320, dtype=torch.float16, device="meta")
+    assert fused.rowgemm_worthwhile(mk(64)) and fused.rowgemm_worthwhile(mk(64), 1280)
+    assert fused.rowgemm_worthwhile(mk(204), 1280) and not fused.rowgemm_worthwhile(mk(205), 1280)      # 2 * 205 * 4096 * 1280 * 2 B > 4 GiB - 16
+    assert fused.rows_addressable(mk(205)) and fused.rows_addressable(mk(819)) and not fused.rows_addressable(mk(820))
+    assert fused.rowgemm_worthwhile(mk(51, 16384), 1280) and not fused.rowgemm_worthwhile(mk(52, 16384), 1280)  # 1024^2: N = 16384
+    assert not fused.rowgemm_worthwhile(mk(7))                                       # too few rows to fill the chip: library GEMMs

@@ -86,11 +86,12 @@ def test_block_projection_fused_path_vs_reference_golden(dtype, pair, monkeypatc
     assert calls, "the projection-fused kernel was not taken"
     assert [kw.get("qfrag", False) for kw in calls] == [pair], "query-fragment order is taken exactly by the head-pair launches"
     # C = 320 with 8 heads: the pair launch also hands its output over in out-fragment order to the fused to_out + norm3 pass
-    assert [kw.get("ofrag", False) for kw in calls] == [pair and C == 320 and heads == 8 and dtype == torch.float16]
+    # (both 16-bit types since round 5: the bf16 instantiation is right once sta/isa_lint.py has padded its mixed-shape MFMA chain)
+    assert [kw.get("ofrag", False) for kw in calls] == [pair and C == 320 and heads == 8]
     # the fused to_out + residual + LayerNorm pass: always behind attn1 at this shape (its y in query-fragment order exactly when the pair
     # kernel consumes it), and behind attn2 when the attention kernel wrote out fragments
     # (y_qfrag of the second one: its consumer is the fused GEGLU projection)
-    assert tails == ([True] + ([True] if dtype == torch.float16 else []) if pair else [])
+    assert tails == ([True, True] if pair else [])
     assert ffs == ([1, 2] if pair else [])          # both halves of the feed-forward as fused passes
     ref = g["out"]
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
@@ -820,3 +821,63 @@ def test_full_width_tracked_chain_vs_fp32_oracle_chain():
           % (S, loss_gpu, loss_ref, time.perf_counter() - t0, torch.get_num_threads(), e_max, g_gpu.tolist(), g_ref.tolist()))
     assert abs(loss_gpu - loss_ref) <= 0.01 * abs(loss_ref), (loss_gpu, loss_ref)
     assert e_max <= 0.05, e_max
+
+
+def test_full_width_fixed_weight_unet_call_at_the_bench_batch_vs_fp32_oracle(monkeypatch):
+    """What every timed UNet call of bench.py runs, held to the oracle once at ITS OWN size: one CFG call of the
+    full-width SD-v1 UNet (859.5 M parameters, synthetic weights) on 64 prompts (batch 128), fp16, NHWC trunk, no autograd — i.e.
+    every sta.fused switch in its product state: the HIP 3x3 convolutions, row GEMMs, the in-place concatenation, GroupNorm
+    statistics from the producers, the level-0 chain of private fragment layouts around the projection-fused head-pair kernel
+    (256 workgroups x 16 tiles), the LDS-resident kernel at levels 1 / 2 / mid, the HIP self-attention — against the SAME modules
+    with the same (fp16-rounded) weights in fp32 on the host cores with the ORACLE's fused op (tests.cpu_backend.oracle_ops: the
+    combination the CPU suite pins to the reference's goldens), for images 0 and 63.  The reduced-width golden UNet (G4) cannot take
+    the C = 320 chain or sta_conv; this is the full-width counterpart with G4's stated tolerance: max |eps - ref| <= 24 eps max |ref|,
+    mean <= 12 eps mean |ref| (eps = 2^-11).  Slow: two fp32 UNet calls on the host."""
+    import time
+    from sta import fused, prompt_state
+    from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, use_shipped_miopen_db
+    from tests.cpu_backend import oracle_ops
+    use_shipped_miopen_db(0)
+    dev, dt, K, I = torch.device("cuda", 0), torch.float16, 2, 64
+    model = build_sd_v1(dev, dt, with_vae=False, init_weights=True, seed=0, channels_last=True)
+    recs = load_prompts(64)[:I]
+    names = [(r["objects"] + ["object"] * K)[:K] for r in recs]
+    conds = [conditionings(model, r["prompt"], nm, dt) for r, nm in zip(recs, names)]
+    centres = [list(c) for c in DEFAULT_CENTRES[:K]]
+    x = torch.randn([I, 4, 64, 64], generator=torch.Generator(device=dev).manual_seed(1), device=dev)
+    pair = lambda u, c: torch.stack([u, c], dim=1).reshape(2 * u.shape[0], *u.shape[1:])
+    uncond = torch.cat([c[0] for c in conds])
+    cond = torch.cat([c[1] for c in conds])
+    c_in = pair(uncond, cond).to(dt)
+    t = torch.full((2 * I,), 981, device=dev, dtype=torch.long)
+    coef = torch.full((I, K), 2.5, device=dev)
+    launches = []
+    real_conv = fused.conv3x3_nhwc
+    monkeypatch.setattr(fused, "conv3x3_nhwc", lambda *a, **k: (launches.append("conv"), real_conv(*a, **k))[1])
+    prompt_state.begin_prompt([c[2] for c in conds], first_timestep=981)
+    with torch.no_grad():
+        eps = model.apply_model_extra(pair(x, x), 0, t, c_in, coef=coef, bboxs_curr=[centres] * I).float().cpu()
+    assert launches.count("conv") == 47                 # the fixed-weight trunk ran on csrc/sta_conv.hip
+    assert eps.shape == (2 * I, 4, 64, 64) and torch.isfinite(eps).all()
+    sd = {k_: (v.detach().float().cpu().contiguous() if v.dtype.is_floating_point else v.detach().cpu()) for k_, v in model.state_dict().items()}
+    xs, cs = x.float().cpu(), [(uc_.float().cpu(), c_.float().cpu(), [l.float().cpu() for l in loc_]) for uc_, c_, loc_ in conds]
+    del model
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    host = build_sd_v1("cpu", torch.float32, with_vae=False, init_weights=False)
+    missing, _ = host.load_state_dict(sd, strict=False)
+    assert not [m for m in missing if m.startswith("model.")], missing[:5]
+    e = 2.0 ** -11
+    for i in (0, I - 1):
+        uc, c, loc = cs[i]
+        prompt_state.begin_prompt(loc, first_timestep=981)
+        with torch.no_grad(), oracle_ops():
+            ref = host.apply_model_extra(pair(xs[i:i + 1], xs[i:i + 1]), 0, torch.full((2,), 981, dtype=torch.long), pair(uc, c),
+                                         coef=torch.full((1, K), 2.5), bboxs_curr=centres)
+        err = (eps[2 * i:2 * i + 2] - ref).abs()
+        print("image %d of 64, full-width fixed-weight UNet call vs the fp32 oracle chain: max %.2f eps of max|ref|, mean %.2f eps of mean|ref| (%.0f s so far)"
+              % (i, (err.max() / (e * ref.abs().max())).item(), (err.mean() / (e * ref.abs().mean())).item(), time.perf_counter() - t0))
+        assert ref.abs().max() > 1e-2
+        assert err.max() <= 24 * e * ref.abs().max(), (i, err.max().item(), ref.abs().max().item())
+        assert err.mean() <= 12 * e * ref.abs().mean(), (i, err.mean().item(), ref.abs().mean().item())
+    assert (eps[0:2] - eps[2 * I - 2:]).abs().max() > 1e-3      # different prompts, different outputs

@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import bench
-from sta.pipeline import use_shipped_miopen_db, use_tuned_gemms
+from sta.pipeline import use_shipped_miopen_db
 images, policy = int(sys.argv[1]), sys.argv[2]
 find = len(sys.argv) > 3 and sys.argv[3] == "1"
-use_shipped_miopen_db(0); use_tuned_gemms()
+use_shipped_miopen_db(0)
 torch.backends.cudnn.benchmark = find
 t0 = time.time()
 r = bench.side_run(torch.device("cuda", 0), "fp16", 3, images, 1, 1, 512, 50, 2, checkpoint=policy, find=find)
