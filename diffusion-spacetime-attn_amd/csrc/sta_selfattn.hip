@@ -59,12 +59,71 @@ __device__ __forceinline__ float bfly_sum(float x) {
 // 2.5 instead of 3.5 vector instructions per score in a loop whose time is the vector pipe's.
 __device__ __forceinline__ float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }   // one v_max3_f32
 
+// Normalise by the softmax denominator and store: row-major [B][N][C], or self-attention out-fragment order (p.sfrag); the log-sum-exp
+// for the backward when asked. Shared by the loop below and the software-pipelined loop of the level-0 shape.
+template <typename T, int NDT, int QT, bool SUMROW>
+__device__ __forceinline__ void sa_epilogue(const SParams& p, f32x4 (&o)[QT][NDT], const float (&mrun)[QT], const float (&lrun)[QT],
+                                            const int b, const int h, const int px0, const int g, const int c16, const int lane) {
+  using V4 = typename Tr<T>::V4;
+  const int N = p.N, C = p.C, d = p.d;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int px = px0 + 16 * qt + c16;
+    float l;
+    if constexpr (SUMROW) {   // denominator = row d of O^T: tile NDT-1, row d % 16 = 4*g_s + r_s, held by the lanes of lane row g_s
+      const int rs_ = d & 15, g_s = rs_ >> 2, r_s = rs_ & 3;
+      float lr = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) lr = (r == r_s) ? o[qt][NDT - 1][r] : lr;
+      l = __shfl(lr, 16 * g_s + c16);
+    } else {
+      l = bfly_sum(lrun[qt]);
+    }
+    const float inv = 1.0f / l;
+    if constexpr (NDT == 3) {
+      if (p.sfrag) {
+        // Out-fragment order for sta_to_out_ln_ofrag (csrc/sta_rowgemm.hip): the wave's 16 pixels are one row group; head h's
+        // dims 0..31 are fragment h (lane (g, c): O^T rows 4g.. of tile 0 | tile 1 of pixel c — the accumulators as they are),
+        // its dims 32..39 one lane row of fragment 8 + h / 4 (lane rows 0, 1 store 8 bytes each). d = 40, N % 16 == 0.
+        if (px0 + 16 * qt >= N) continue;
+        char* gb = (char*)p.out + ((size_t)b * N + px0 + 16 * qt) * C * sizeof(T);
+        typename Tr<T>::V8 x8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { x8[r] = (T)(o[qt][0][r] * inv); x8[4 + r] = (T)(o[qt][1][r] * inv); }
+        *(typename Tr<T>::V8*)(gb + h * FRAG + lane * 16) = x8;
+        if (g < 2) {
+          V4 t4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) t4[r] = (T)(o[qt][2][r] * inv);
+          *(V4*)(gb + (8 + (h >> 2)) * FRAG + (16 * (h & 3) + c16) * 16 + 8 * g) = t4;
+        }
+        if (p.lse && g == 0 && px < N) p.lse[((size_t)b * p.H + h) * N + px] = mrun[qt] * p.sl2e + __builtin_amdgcn_logf(l);
+        continue;
+      }
+    }
+    if (px >= N) continue;
+    if (p.lse && g == 0)                   // P = exp2(s * sl2e - lse): exact whether or not the running maximum is stale
+      p.lse[((size_t)b * p.H + h) * N + px] = mrun[qt] * p.sl2e + __builtin_amdgcn_logf(l);
+    T* ob = (T*)p.out + ((size_t)b * N + px) * C + h * d;
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      const int dd = 16 * u + 4 * g;
+      if (dd < d) {
+        V4 r4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r4[r] = (T)(o[qt][u][r] * inv);
+        *(V4*)(ob + dd) = r4;
+      }
+    }
+  }
+}
+
 // NW waves per workgroup. NW = 4 (QT query tiles of 16 per wave): the shipped geometry. NW = 8 with QT = 1: the same loop sized for FOUR
 // waves per SIMD (<= 128 registers; two 512-thread workgroups per CU share each K / V^T block among 128 queries as before),
 // built to test whether a fourth wave fills the third of the vector-issue port that three waves leave idle
 // (profiles/r03_selfattn_32x32.md): it does not (launch_sa_cfg below).
 template <typename T, int NKS, int NDT, int QT, bool SUMROW, bool PRE, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void selfattn_fwd_kernel(const SParams p) {
+__global__ __launch_bounds__(64 * NW, NW == 8 ? (QT == 1 ? 4 : 2) : 1) void selfattn_fwd_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NKF = 4 * NKS;            // K fragments per block: 4 key tiles x NKS head-dim steps
@@ -324,58 +383,322 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void selfattn_fwd_kernel(
     if (blk + 2 < nblk) body(std::integral_constant<int, 2>{}, blk + 2);
   }
 
+  sa_epilogue<T, NDT, QT, SUMROW>(p, o, mrun, lrun, b, h, px0, g, c16, lane);
+}
+
+
+// ---- the level-0 shape (d = 40: NKS = 2, NDT = 3; q in log2 units; ones row; N % 64 == 0), software-pipelined -----------------
+//
+// The loop above runs S^T MFMAs -> softmax -> PV MFMAs one after the other inside a wave and leaves the overlap of the matrix pipe and
+// the vector pipe to chance (which phase the SIMD's other waves happen to be in): counters showed the two pipes' busy times simply ADD
+// UP — a 64-key block takes 1066 cycles against 476 of matrix pipe and 488 of vector issue (profiles/r03_selfattn_32x32.md). Here
+// one wave carries the overlap itself: its two query tiles A and B run half a block apart, and every half step issues the MFMAs of one
+// tile with the softmax of the OTHER between them, one small group of vector instructions behind each MFMA (an MFMA of this shape
+// leaves room for two plain or one transcendental instruction in its shadow, profiles/r03_mfma_valu_coissue.txt):
+//
+//     X(j):  MFMAs  O_A += V^T(j-1) P_A(j-1)   S_A(j) = K(j) Q_A - m_A      ||   vector  P_B(j-1) = exp2(S_B(j-1)), running maximum of B
+//     Y(j):  MFMAs  O_B += V^T(j-1) P_B(j-1)   S_B(j) = K(j) Q_B - m_B      ||   vector  P_A(j)   = exp2(S_A(j)),   running maximum of A
+//
+// 14 MFMAs and one tile's softmax (8 max3, 16 exp2, 8 convert) per half. K(j) and V^T(j-1) are read from the LDS ring once per
+// block for both tiles; the ring is 4 deep (block j-1 is still being read while j+1, j+2 are in flight): 64 KiB, two workgroups per CU.
+// The K operands of one 64-key block for d = 40: per key tile one k = 32 operand (dims 0..31) and one k = 16 operand (dims 32..39; its
+// upper eight k slots meet zeros on the q side). The k = 16 MFMA costs what the k = 32 one does, but the second k = 32 step of the
+// plain loop carried 24 padded dims per key through L2 -> LDS and LDS -> registers: 11 instead of 14 KiB per block in a launch
+// whose LDS-DMA stream is what it waits for (profiles/r05_selfattn.md).
+template <typename T> struct SaK {
+  typename Tr<T>::V8 big[4];
+  typename Tr<T>::V4 sm[4];
+};
+template <typename T> struct SaM16;
+template <> struct SaM16<_Float16> {
+  static __device__ __forceinline__ f32x4 mfma(f16x4 a, f16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0); }
+};
+template <> struct SaM16<__bf16> {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  static __device__ __forceinline__ f32x4 mfma(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4, a), __builtin_bit_cast(s16x4, b), c, 0, 0, 0);
+  }
+};
+template <typename T> struct SaQ {          // one query tile's B operands: dims 0..31, and dims 32..39 | zeros
+  typename Tr<T>::V8 big;
+  typename Tr<T>::V4 sm;
+};
+
+template <typename T>
+__device__ __forceinline__ void sa_softmax_chunk(const int k, f32x4 (&s)[4], f32x4 (&o)[3], typename Tr<T>::V8 (&pb)[2], float& m, float (&tmp)[6],
+                                                 const bool first) {
+  // the vector work of one tile's softmax, cut into the pieces that go behind MFMA number k of a half step (k = 0 .. 13)
+  switch (k) {
+    case 0: tmp[0] = max3f(s[0][0], s[0][1], s[0][2]); tmp[1] = max3f(s[0][3], s[1][0], s[1][1]); break;
+    case 1: tmp[2] = max3f(s[1][2], s[1][3], s[2][0]); tmp[3] = max3f(s[2][1], s[2][2], s[2][3]); break;
+    case 2: tmp[4] = max3f(s[3][0], s[3][1], s[3][2]); tmp[0] = max3f(tmp[0], tmp[1], tmp[2]); tmp[3] = max3f(tmp[3], tmp[4], s[3][3]); break;
+    case 3: {
+      float bm = fmaxf(tmp[0], tmp[3]);          // this lane's maximum of s - m over its 16 scores
+      // deferred rescale (see the loop above): the running maximum moves only when some pixel of the wave saw more than 2^RESCALE_LOG2
+      if (first || __any(bm > RESCALE_LOG2)) {
+        bm = bfly_max(bm);
+        const float delta = first ? bm : fmaxf(bm, 0.f);
+        m += delta;
+        if (!first) {
+          const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-  for (int qt = 0; qt < QT; ++qt) {
-    const int px = px0 + 16 * qt + c16;
-    float l;
-    if constexpr (SUMROW) {   // denominator = row d of O^T: tile NDT-1, row d % 16 = 4*g_s + r_s, held by the lanes of lane row g_s
-      const int rs_ = d & 15, g_s = rs_ >> 2, r_s = rs_ & 3;
-      float lr = 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) lr = (r == r_s) ? o[qt][NDT - 1][r] : lr;
-      l = __shfl(lr, 16 * g_s + c16);
-    } else {
-      l = bfly_sum(lrun[qt]);
-    }
-    const float inv = 1.0f / l;
-    if constexpr (NDT == 3) {
-      if (p.sfrag) {
-        // Out-fragment order for sta_to_out_ln_ofrag (csrc/sta_rowgemm.hip): the wave's 16 pixels are one row group; head h's
-        // dims 0..31 are fragment h (lane (g, c): O^T rows 4g.. of tile 0 | tile 1 of pixel c — the accumulators as they are),
-        // its dims 32..39 one lane row of fragment 8 + h / 4 (lane rows 0, 1 store 8 bytes each). d = 40, N % 16 == 0.
-        if (px0 + 16 * qt >= N) continue;
-        char* gb = (char*)p.out + ((size_t)b * N + px0 + 16 * qt) * C * sizeof(T);
-        typename Tr<T>::V8 x8;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { x8[r] = (T)(o[qt][0][r] * inv); x8[4 + r] = (T)(o[qt][1][r] * inv); }
-        *(typename Tr<T>::V8*)(gb + h * FRAG + lane * 16) = x8;
-        if (g < 2) {
-          V4 t4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t4[r] = (T)(o[qt][2][r] * inv);
-          *(V4*)(gb + (8 + (h >> 2)) * FRAG + (16 * (h & 3) + c16) * 16 + 8 * g) = t4;
+          for (int u = 0; u < 3; ++u) o[u] *= alpha;
         }
-        if (p.lse && g == 0 && px < N) p.lse[((size_t)b * p.H + h) * N + px] = mrun[qt] * p.sl2e + __builtin_amdgcn_logf(l);
-        continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[t][r] -= delta;
       }
+      break;
     }
-    if (px >= N) continue;
-    if (p.lse && g == 0)                   // P = exp2(s * sl2e - lse): exact whether or not the running maximum is stale
-      p.lse[((size_t)b * p.H + h) * N + px] = mrun[qt] * p.sl2e + __builtin_amdgcn_logf(l);
-    T* ob = (T*)p.out + ((size_t)b * N + px) * C + h * d;
+    default: {
+      if (k >= 4 && k < 12) {                    // two exponentials behind each of MFMAs 4 .. 11
+        const int t = (k - 4) >> 1, r0 = 2 * ((k - 4) & 1);
+        s[t][r0] = __builtin_amdgcn_exp2f(s[t][r0]);
+        s[t][r0 + 1] = __builtin_amdgcn_exp2f(s[t][r0 + 1]);
+      }
+      if (k >= 6 && (k & 1) == 0) {              // tile t's four values are final two MFMAs later: convert them (k = 6, 8, 10, 12)
+        const int t = (k - 6) >> 1;
 #pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      const int dd = 16 * u + 4 * g;
-      if (dd < d) {
-        V4 r4;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) r4[r] = (T)(o[qt][u][r] * inv);
-        *(V4*)(ob + dd) = r4;
+        for (int r = 0; r < 4; ++r) pb[t >> 1][4 * (t & 1) + r] = (T)s[t][r];
       }
     }
   }
 }
 
+#ifndef STA_SA_ABLATE
+#define STA_SA_ABLATE 0     // timing experiments (tools/asm_patch_ab.py flag:-DSTA_SA_ABLATE=bits; wrong results): 1 no softmax, 2 no MFMAs,
+#endif                      // 4 no per-block rendezvous, 8 no per-block LDS reads, 16 no LDS-DMA inside the loop
+// one half step: 14 MFMAs of tile `f` (PV of block j-1 when DO_PV, S^T of block j when DO_S) with the softmax of tile `v` between them
+template <typename T, bool DO_PV, bool DO_S, bool DO_SM>
+__device__ __forceinline__ void sa_half_step(const SaK<T>& ka, const typename Tr<T>::V8 (&va)[6], const SaQ<T>& qf,
+                                             f32x4 (&s_f)[4], f32x4 (&o_f)[3], const typename Tr<T>::V8 (&p_f)[2], const float m_f,
+                                             f32x4 (&s_v)[4], f32x4 (&o_v)[3], typename Tr<T>::V8 (&p_v)[2], float& m_v, const bool first_v) {
+  float tmp[6];
+  int k = 0;
+  auto vec = [&]() __attribute__((always_inline)) {
+#if !(STA_SA_ABLATE & 1)
+    if constexpr (DO_SM) sa_softmax_chunk<T>(k, s_v, o_v, p_v, m_v, tmp, first_v);
+#else
+    if (DO_SM && k == 0) {          // keep the scores and the P operands alive without the vector work
+#pragma unroll
+      for (int t = 0; t < 4; ++t) asm volatile("" : "+v"(s_v[t]));
+      asm volatile("" : "+v"(p_v[0]), "+v"(p_v[1]));
+    }
+#endif
+    ++k;
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (DO_PV) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+#if !(STA_SA_ABLATE & 2)
+        o_f[u] = Tr<T>::mfma(va[s2 * 3 + u], p_f[s2], o_f[u]);
+#else
+        asm volatile("" : "+v"(o_f[u]) : "v"(va[s2 * 3 + u]), "v"(p_f[s2]));
+#endif
+        vec();
+      }
+  }
+  if constexpr (DO_S) {
+    const float i0 = -m_f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#if !(STA_SA_ABLATE & 2)
+      s_f[t] = Tr<T>::mfma(ka.big[t], qf.big, f32x4{i0, i0, i0, i0});
+#else
+      s_f[t] = f32x4{i0, i0, i0, i0};
+      asm volatile("" : "+v"(s_f[t]) : "v"(ka.big[t]), "v"(qf.big));
+#endif
+      vec();
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#if !(STA_SA_ABLATE & 2)
+      s_f[t] = SaM16<T>::mfma(ka.sm[t], qf.sm, s_f[t]);       // three other MFMAs behind its k = 32 step: no mixed-shape hazard (sta/isa_lint.py)
+#else
+      asm volatile("" : "+v"(s_f[t]) : "v"(ka.sm[t]), "v"(qf.sm));
+#endif
+      vec();
+    }
+  }
+  if constexpr (DO_SM) {
+    while (k < 14) vec();                        // a half step without one of the MFMA groups (first / last block): the rest of the softmax
+  }
+}
+
+template <typename T, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SParams p) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  // fragments of a block (1 KiB each): 0..3 K dims 0..31 of key tile t; 4 K dims 32..39 of all 64 keys (lane = key); 5..10 V^T
+  constexpr int NDT = 3, NKF = 5, NVF = 6, NFR = NKF + NVF, PER = (NFR + NW - 1) / NW, NFRP = NW * PER, BB = NFRP * FRAG, DEPTH = 4;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int N = p.N, d = p.d;
+  const int b = blockIdx.y;
+  const int tile = blockIdx.x >> 3, h = blockIdx.x & 7;
+  const int px0 = (tile * NW + wv) * 32;
+  const T* qb = (const T*)p.q + (size_t)b * N * p.ldq + h * d;
+  const T* kb = (const T*)p.k + (size_t)b * N * p.ldk + h * d;
+  const T* vb = (const T*)p.vt + (size_t)b * p.vt_bs + (size_t)(h * d) * p.vt_rs;
+  SaQ<T> qf[2];
+#pragma unroll
+  for (int qt = 0; qt < 2; ++qt) {
+    const int px = px0 + 16 * qt + c16;
+    V8 z = {};
+    V4 z4 = {};
+    qf[qt].big = px < N ? *(const V8*)(qb + (size_t)px * p.ldq + 8 * g) : z;
+    qf[qt].sm = (px < N && g < 2) ? *(const V4*)(qb + (size_t)px * p.ldq + 32 + 4 * g) : z4;     // k slots 8..15 of the k = 16 step: zeros
+  }
+  // LDS-DMA of a 64-key block as in the loop above (fragments wv, wv + NW, ...; per-lane sources advanced by a constant)
+  const char* src[PER];
+  int step[PER];
+  unsigned keep = ~0u;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int f = wv + NW * i;
+    const int fs = f < NFR ? f : 0;
+    if (fs < 4) {
+      src[i] = (const char*)(kb + (size_t)tile_key(fs, c16) * p.ldk + 8 * g);
+      step[i] = __builtin_amdgcn_readfirstlane(KB * p.ldk * (int)sizeof(T));
+    } else if (fs == 4) {
+      src[i] = (const char*)(kb + (size_t)lane * p.ldk + 32);           // dims 32..39 of key `lane`: 16 bytes at LDS offset 16 lane
+      step[i] = __builtin_amdgcn_readfirstlane(KB * p.ldk * (int)sizeof(T));
+    } else {
+      const int f2 = fs - NKF;
+      const int s2 = f2 / NDT, u = f2 - s2 * NDT;
+      src[i] = (const char*)(vb + (size_t)min(16 * u + c16, d - 1) * p.vt_rs + 32 * s2 + 8 * g);
+      step[i] = __builtin_amdgcn_readfirstlane(KB * (int)sizeof(T));
+    }
+    const int f2 = f - NKF;
+    if (f < NFR && f2 >= 0 && f2 % NDT == NDT - 1 && 16 * (NDT - 1) + c16 == d) {      // the ones row of V^T: written once per ring slot
+      keep &= ~(1u << i);
+      V8 ones;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+#pragma unroll
+      for (int sl = 0; sl < DEPTH; ++sl) *(V8*)(smem_sa + sl * BB + f * FRAG + lane * 16) = ones;
+    }
+  }
+  // 11 fragments over NW waves: the first NFR - NW (PER - 1) waves copy PER of them per block, the others PER - 1 — no padding copies
+  // (the loop above copies 16 KiB per block: 14 fragments + fragment 0 twice more to keep one vmcnt for every wave); each wave counts
+  // its own copies (wave-uniform branch around the s_waitcnt immediates)
+  const bool full_share = wv < NFR - NW * (PER - 1);
+  auto stage = [&](char* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      if (i == PER - 1 && !full_share) break;
+      if (keep >> i & 1)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                         (__attribute__((address_space(3))) void*)(dst + (wv + NW * i) * FRAG), 16, 0, 0);
+      src[i] += step[i];
+    }
+  };
+  const int nblk = N / KB;
+  auto arrive = [&](const int blk) __attribute__((always_inline)) {      // block `blk` landed for every wave; everyone left block blk - 1
+    if (blk + 1 < nblk) {
+      if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER - 1) : "memory");
+    }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (no lgkmcnt wait: what this wave read from the slot that is overwritten next has been consumed by MFMAs a half step ago)
+#if !(STA_SA_ABLATE & 4)
+    __builtin_amdgcn_s_barrier();
+#endif
+  };
+  f32x4 oA[3], oB[3], sA[4], sB[4];
+  V8 pA[2], pB[2];
+  float mA = 0.f, mB = 0.f;
+#pragma unroll
+  for (int u = 0; u < 3; ++u) oA[u] = oB[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* lane_base = smem_sa + lane * 16;
+  // Operand registers are double-buffered: K(j+1) and V^T(j) are requested from LDS in the MIDDLE of block j (behind the rendezvous
+  // for block j+1) and land under its second half step. With the reads at the top of a block every wave of the workgroup — they leave
+  // the barrier together — sat out the LDS latency at the same time (profiles/r05_selfattn.md).
+  SaK<T> ka[2];
+  V8 va[2][NVF];
+  // the k = 16 operand of key tile t: row c = key tile_key(t, c), k slots 4g..4g+3 = dims 32 + 4 (g & 1) .. (lane rows 2, 3 meet zeros on
+  // the q side: they re-read rows 0, 1's bytes)
+  int ksm_off[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) ksm_off[t] = 4 * FRAG + 16 * tile_key(t, c16) + 8 * (g & 1);
+  auto load_k = [&](SaK<T>& dst, const int slot) __attribute__((always_inline)) {
+    const V8* fr = (const V8*)(lane_base + slot * BB);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst.big[t] = fr[t * 64];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) dst.sm[t] = *(const V4*)(smem_sa + slot * BB + ksm_off[t]);
+  };
+  auto load_v = [&](V8 (&dst)[NVF], const int slot) __attribute__((always_inline)) {
+    const V8* fr = (const V8*)(lane_base + slot * BB);
+#pragma unroll
+    for (int f = 0; f < NVF; ++f) dst[f] = fr[(NKF + f) * 64];
+  };
+  stage(smem_sa);
+  if (nblk > 1) stage(smem_sa + BB);
+  // block 0: S_A(0); rendezvous for block 1, its K and block 0's V^T requested; then S_B(0) with the softmax of A between its MFMAs
+  // (both tiles take the exact maximum of their first block: `first`)
+  arrive(0);
+  if (nblk > 2) stage(smem_sa + 2 * BB);
+  load_k(ka[0], 0);
+  sa_half_step<T, false, true, false>(ka[0], va[0], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, false);
+  if (nblk > 1) {
+    arrive(1);
+    if (nblk > 3) stage(smem_sa + 3 * BB);
+    load_k(ka[1], 1);
+  }
+  load_v(va[1], 0);
+  __builtin_amdgcn_sched_barrier(0);
+  sa_half_step<T, false, true, true>(ka[0], va[0], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, true);
+  auto body = [&](auto slot_tag, const int blk) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value, c = SLOT & 1;      // block blk sits in ring slot SLOT = blk % 4, register set blk & 1
+    sa_half_step<T, true, true, true>(ka[c], va[c], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, blk == 1);
+    if (blk + 1 < nblk) {
+      arrive(blk + 1);
+#if !(STA_SA_ABLATE & 16)
+      if (blk + 3 < nblk) stage(smem_sa + ((SLOT + 3) % DEPTH) * BB);
+#endif
+      load_k(ka[c ^ 1], (SLOT + 1) % DEPTH);
+    }
+    load_v(va[c ^ 1], SLOT);
+    __builtin_amdgcn_sched_barrier(0);
+    sa_half_step<T, true, true, true>(ka[c], va[c], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, false);
+  };
+  for (int blk = 1; blk < nblk; blk += DEPTH) {
+    body(std::integral_constant<int, 1>{}, blk);
+    if (blk + 1 < nblk) body(std::integral_constant<int, 2>{}, blk + 1);
+    if (blk + 2 < nblk) body(std::integral_constant<int, 3>{}, blk + 2);
+    if (blk + 3 < nblk) body(std::integral_constant<int, 0>{}, blk + 3);
+  }
+  // drain: PV of the last block for A with B's last softmax between, then PV for B (V^T of the last block: register set nblk & 1)
+  if (nblk & 1) {
+    sa_half_step<T, true, false, true>(ka[1], va[1], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, nblk == 1);
+    sa_half_step<T, true, false, false>(ka[1], va[1], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, false);
+  } else {
+    sa_half_step<T, true, false, true>(ka[0], va[0], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, false);
+    sa_half_step<T, true, false, false>(ka[0], va[0], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, false);
+  }
+  f32x4 o[2][3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) { o[0][u] = oA[u]; o[1][u] = oB[u]; }
+  const float mrun[2] = {mA, mB}, lrun[2] = {0.f, 0.f};
+  sa_epilogue<T, 3, 2, true>(p, o, mrun, lrun, b, h, px0, g, c16, lane);
+}
+
+template <typename T, int NW>
+int launch_sa_pipe(const SParams& p, hipStream_t st) {
+  constexpr int lds = 4 * ((11 + NW - 1) / NW * NW) * FRAG;
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)selfattn_fwd_pipe_kernel<T, NW>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn pipe) failed");
+  const int tiles = (p.N + 32 * NW - 1) / (32 * NW);
+  hipLaunchKernelGGL((selfattn_fwd_pipe_kernel<T, NW>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn pipe launch: %s", hipGetErrorString(e));
+}
 
 #ifdef STA_EXPERIMENT_SELFATTN32
 #include "../../tools/experiments/selfattn_fwd32.inc"     // 32x32x16-MFMA variant: measured slower in wall time (lower clocks), tools-only
@@ -401,6 +724,7 @@ int launch_sa_cfg(const SParams& p, hipStream_t st) {
   // instead of 32 queries — so it stays an opt-in that the parity tests keep green.
   if constexpr (NDT <= 3 && PRE) {
     if (g_sta_opt[STA_OPT_SELFATTN_WAVES] == 8) return launch_sa_geom<T, NKS, NDT, 1, SUMROW, PRE, 8>(p, st);
+    if (g_sta_opt[STA_OPT_SELFATTN_WAVES] == 16) return launch_sa_geom<T, NKS, NDT, 2, SUMROW, PRE, 8>(p, st);      // 256 queries per workgroup
   }
   return launch_sa_geom<T, NKS, NDT, QT, SUMROW, PRE, 4>(p, st);
 }
@@ -416,6 +740,14 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
 #ifdef STA_EXPERIMENT_SELFATTN32
   if (p.d > 32 && p.d <= 48 && (p.d & 15) && p.N % 64 == 0 && p.sl2e == 1.0f && g_sta_opt[STA_OPT_SELFATTN_32] != 2) return launch_sa32<T>(p, st);
 #endif
+  // the level-0 launch (d = 40, 8 heads, q in log2 units, whole 64-key blocks): the software-pipelined loop; STA_OPT_SELFATTN_PIPE = 2
+  // keeps the loop above (A/B, parity tests)
+  if (p.d == 40 && p.H == 8 && p.sl2e == 1.0f && p.N % KB == 0 && g_sta_opt[STA_OPT_SELFATTN_PIPE] != 2 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 8)
+  {
+    // 128 queries per workgroup (four waves, two workgroups per CU); 256 (eight waves, one workgroup per CU) as an option: profiles/r05_selfattn.md
+    const bool eight = g_sta_opt[STA_OPT_SELFATTN_PIPE] == 8;       // (measured equal to slower than four waves once the padding copies were gone)
+    return eight ? launch_sa_pipe<T, 8>(p, st) : launch_sa_pipe<T, 4>(p, st);
+  }
   switch ((p.d + 15) / 16) {
     case 1: return launch_sa<T, 1, 1>(p, st);
     case 2: return launch_sa<T, 1, 2>(p, st);

@@ -31,7 +31,7 @@ PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-f
                     "sta_xattn_proj3.hip": ["-ffinite-math-only"], "sta_rowgemm.hip": ["-ffinite-math-only"], "sta_ffgemm.hip": ["-ffinite-math-only"], "sta_conv.hip": ["-ffinite-math-only"], "sta_gemm.hip": ["-ffinite-math-only"]}
 
 STA_BF16, STA_F16 = 0, 1
-OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_SELFATTN_32, OPT_PROJ_PAIR, OPT_SELFATTN_WAVES = range(9)
+OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_SELFATTN_32, OPT_PROJ_PAIR, OPT_SELFATTN_WAVES, OPT_SELFATTN_PIPE = range(10)
 FWD_STAGED, FWD_SPLIT = 1, 2
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
 

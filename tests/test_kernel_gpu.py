@@ -410,6 +410,59 @@ def test_self_attention_deferred_rescale_branches(dtype, pre):
     assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (err.max(), ref.abs().max())
 
 
+@pytest.mark.parametrize("N", [64, 128, 192, 256, 320, 1024, 4096])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_self_attention_software_pipelined_loop(N, dtype):
+    """The level-0 launch of attn1 (d = 40, 8 heads, q in log2 units, whole 64-key blocks) runs a software-pipelined loop — the two
+    query tiles of a wave half a block apart, the MFMAs of one with the softmax of the other between them, operand registers
+    double-buffered across the mid-block rendezvous, K as a k = 32 + a k = 16 operand per key tile (csrc/sta_selfattn.hip,
+    selfattn_fwd_pipe_kernel). Its two geometries (128 and 256 queries per workgroup) must equal each other BIT FOR BIT and the plain
+    loop to 2 eps (dims 32..39 enter through another MFMA shape), for 1, 2, 3, 4, 5 (prologue / drain / every ring slot) and many blocks,
+    with keys that force the deferred-rescale branch of both tiles at chosen blocks, in row-major and out-fragment order, with and
+    without the log-sum-exp; and the fp64 softmax to 4 eps."""
+    from sta import lib, ops
+    B, C, heads = 2, 320, 8
+    d = C // heads
+    g = torch.Generator().manual_seed(N)
+    q = torch.randn(B, N, C, generator=g)
+    k = torch.randn(B, N, C, generator=g) * (0.3 + 2.7 * torch.arange(N).view(1, N, 1) / N)      # the maximum creeps up along the sequence
+    for key, px in ((N - 30, 5), (N // 2 + 1, 17 % N), (N - 1, 40)):                              # spikes: tile A and tile B pixels, late blocks
+        k[:, key] = 4.0 * q[:, px]
+    k[:, :64] = torch.where(torch.arange(64).view(1, 64, 1) < 32, -1.5 * q[:, 20:21], k[:, :64])   # pixel 20: half of block 0 far below zero
+    v = torch.randn(B, N, C, generator=g)
+    qs = (q * (d ** -0.5 * 1.4426950408889634)).to(dtype)
+    k, v = k.to(dtype), v.to(dtype)
+    qd, kd, vtd = qs.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda()
+    outs = {}
+    try:
+        for mode in (2, 4, 8, 0):
+            lib.set_option(lib.OPT_SELFATTN_PIPE, mode)
+            o = ops.self_attention(qd, kd, vtd, heads, ops.LN2)
+            o_f = ops.from_sfrag(ops.self_attention(qd, kd, vtd, heads, ops.LN2, sfrag=True)) if N % 16 == 0 else None
+            o_l, lse = ops.self_attention_lse(qd, kd, vtd, heads, ops.LN2) if hasattr(ops, "self_attention_lse") else (o, None)
+            torch.cuda.synchronize()
+            outs[mode] = (o, o_f, o_l, lse)
+    finally:
+        lib.set_option(lib.OPT_SELFATTN_PIPE, 0)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for mode in (8, 0):                               # (8 forced at every N; the dispatcher's own choice is one of the two)
+        for a, b_ in zip(outs[mode], outs[4]):
+            if a is not None:
+                assert torch.equal(a, b_), (mode, (a.float() - b_.float()).abs().max().item())
+    for a, b_ in zip(outs[4], outs[2]):
+        if a is not None:
+            assert ((a.float() - b_.float()).abs() <= 2 * eps * (1.0 + b_.float().abs())).all(), (a.float() - b_.float()).abs().max().item()
+    q64 = qs.double().view(B, N, heads, d).transpose(1, 2)
+    k64 = k.double().view(B, N, heads, d).transpose(1, 2)
+    v64 = v.double().view(B, N, heads, d).transpose(1, 2)
+    logits = q64 @ k64.transpose(-1, -2) * ops.LN2
+    ref = (torch.softmax(logits, -1) @ v64).transpose(1, 2).reshape(B, N, C)
+    for mode in (4, 8):
+        err = (outs[mode][0].float().cpu().double() - ref).abs()
+        assert torch.isfinite(outs[mode][0]).all()
+        assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (mode, err.max(), ref.abs().max())
+
+
 SA_BWD_SHAPES = [(2, 256, 320, 8), (2, 128, 160, 2), (1, 64, 64, 4), (1, 192, 96, 1), (3, 320, 128, 2), (1, 4096, 320, 8), (1, 1024, 640, 8),
                  # d = 160 (levels 2 / mid at 512^2, level 2 at 768^2: single-buffered dk/dv kernel), 128, 112, 144
                  (2, 256, 1280, 8), (2, 64, 1280, 8), (1, 576, 1280, 8), (1, 128, 256, 2), (1, 64, 112, 1), (2, 192, 288, 2)]

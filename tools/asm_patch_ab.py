@@ -16,6 +16,8 @@ patches (applied to the instruction stream of the kernels whose mangled name mat
   cvt_nop              s_nop 1 behind every v_cvt_pk_bf16_f32
   perm_nop             s_nop 7 in front of and behind every v_permlane*_swap
   line:N:TEXT          insert TEXT in front of line N of the kernel's text (1-based inside the kernel)
+  flag:-DNAME=V        not a text patch: an extra hipcc flag for this build of the source (ablation switches); the text then passes
+                       the library's own lint + cure (sta/isa_lint.py) like a product build
 """
 import os
 import re
@@ -118,18 +120,25 @@ def build(argv):
     text = open(dev_s).read()
     for p in procs:
         assert p.wait() == 0
+    from sta import isa_lint
     for v in variants:
         tag, plist = v.split("=", 1)
         w = os.path.join(OUT, tag)
         os.makedirs(w, exist_ok=True)
         patched = os.path.join(w, "dev.s")
+        plist = [p for p in plist.split(",") if p]
+        extra = [p[5:] for p in plist if p.startswith("flag:")]
+        vtext = text
+        if extra:
+            run(base + flags + extra + ["--cuda-device-only", "-S", src, "-o", patched + ".raw"])
+            vtext = isa_lint.fix_text(open(patched + ".raw").read())[0]
         with open(patched, "w") as fh:
-            fh.write(patch_text(text, kernel_re, [p for p in plist.split(",") if p]))
+            fh.write(patch_text(vtext, kernel_re, [p for p in plist if not p.startswith("flag:")]))
         run([LLVM + "/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", patched, "-o", w + "/dev.o"])
         run([LLVM + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", w + "/dev.o", "-o", w + "/dev.out"])
         run([LLVM + "/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950",
              "-input=/dev/null", "-input=" + w + "/dev.out", "-output=" + w + "/dev.hipfb"])
-        run(base + flags + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", w + "/dev.hipfb", "-o", w + "/host.o"])
+        run(base + flags + extra + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", w + "/dev.hipfb", "-o", w + "/host.o"])
         run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *common, w + "/host.o", "-o", os.path.join(OUT, "libsta_%s.so" % tag)])
         print("built", tag, flush=True)
 
