@@ -8,9 +8,9 @@ are already too few there), and to_k/to_v run once per prom
 
 How: weight rows are quantised once (`Fp8Linear.from_linear`: one fp32 scale per OUTPUT channel, absmax / 448),
 activations per call by the HIP kernel `sta_quant_rows_fp8` (one fp32 scale per row, csrc/sta_fp8.hip); the GEMM is
-e4m3 x e4m3 -> fp32 -> 16 bit on the fp8 MFMA path (hipBLASLt via `torch._scaled_mm`, a plain library GEMM) with both
+e4m3 x e4m3 -> fp32 -> 16 bit by hipBLASLt's row-scaled e4m3 GEMM (`torch._scaled_mm`: a plain library GEMM, no own fp8 kernel) with both
 scale vectors applied to the fp32 accumulators. Weight bytes halve (UNet transformer Linears: 0.61 GB -> 0.31 GB);
-on gfx950 the non-block-scaled fp8 MFMA runs at the 16-bit rate, so the gain is memory, not flops.
+on gfx950 the non-block-scaled fp8 MFMA runs at the 16-bit rate, so this is a weight-MEMORY option, not a rate option.
 Inference only (no autograd through the quantiser)."""
 import torch
 from torch import nn

@@ -27,16 +27,24 @@ for v in variants:
     #   skel=-DSTA_P3_ABLATE=19,src:sta_xattn_proj3.hip=tools/experiments/sta_xattn_proj3_ablate.hip
     swaps = dict(f[4:].split("=", 1) for f in flag_list if f.startswith("src:"))
     flag_list = [f for f in flag_list if not f.startswith("src:")]
-    for src in lib.SOURCES:
-        obj = out + "." + os.path.basename(src) + ".o"
-        base = os.path.basename(src)
-        if base in swaps:
-            src = os.path.join(ROOT, swaps[base])
-        cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", lib.INCLUDE, "-I", lib.CSRC,
-               *lib.PER_SOURCE_FLAGS.get(base, []), *flag_list, "-c", src, "-o", obj]
-        objs.append((subprocess.Popen(cmd), obj))
-    for pr, _ in objs:
-        assert pr.wait() == 0
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    work = tempfile.mkdtemp(prefix="sta_ab_")
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", lib.INCLUDE, "-I", lib.CSRC]
+    jobs = []
+    with ThreadPoolExecutor(max_workers=len(lib.SOURCES)) as ex:
+        for src in lib.SOURCES:
+            obj = out + "." + os.path.basename(src) + ".o"
+            b = os.path.basename(src)
+            if b in swaps:
+                src = os.path.join(ROOT, swaps[b])
+            # every variant goes through the product build's pipeline: assembly -> hazard lint + s_nop cure (sta/isa_lint.py) -> assemble
+            w = os.path.join(work, b)
+            os.makedirs(w, exist_ok=True)
+            jobs.append((ex.submit(lib._compile_checked, "hipcc", base, lib.PER_SOURCE_FLAGS.get(b, []) + flag_list, src, obj, w, False), obj))
+        for fut, _ in jobs:
+            fut.result()
+    objs = [(None, o) for _, o in jobs]
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", *[o for _, o in objs], "-o", out])
     for _, o in objs:
         os.remove(o)

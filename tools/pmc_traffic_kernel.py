@@ -40,9 +40,10 @@ ent = {"kernel": kernel + " (to_q inside, a head pair per workgroup, y in query-
        "raw_KiB": raw, "bytes_per_launch": (2 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"]) * 1024, "algorithmic_bytes": alg, "dtype": a.dtype,
        "source_sha": bench.source_sha(),
        "how": "tools/pmc_traffic_kernel.py: separate rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over tools/proj_bench.py --only pairqo "
-              "(KiB per dispatch, average of 16 launches); FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md); round 4"}
+              "(KiB per dispatch, average of 16 launches); FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B, MI355X_MICROARCH.md); round 5"}
 ent["ratio_to_algorithmic"] = round(ent["bytes_per_launch"] / alg, 4)
-src = os.path.join(ROOT, "profiles", "xattn_fwd_hbm_traffic.json")
+out = os.path.join(ROOT, "gpurun_out", "xattn_fwd_hbm_traffic.json")          # several runs of one GPU call accumulate here
+src = out if os.path.exists(out) else os.path.join(ROOT, "profiles", "xattn_fwd_hbm_traffic.json")
 doc = json.load(open(src)) if os.path.exists(src) else {}
 doc.setdefault("by_kernel", {})["proj_N%d_C%d_I%d" % (N, C, a.imgs) + ("" if a.dtype == "fp16" else "_" + a.dtype)] = ent
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
