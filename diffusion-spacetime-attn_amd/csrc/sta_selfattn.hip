@@ -529,7 +529,7 @@ __device__ __forceinline__ void sa_half_step(const SaK<T>& ka, const typename Tr
   }
 }
 
-template <typename T, int NW>
+template <typename T, int NW, int QT>
 __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
@@ -541,13 +541,13 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
   const int N = p.N, d = p.d;
   const int b = blockIdx.y;
   const int tile = blockIdx.x >> 3, h = blockIdx.x & 7;
-  const int px0 = (tile * NW + wv) * 32;
+  const int px0 = (tile * NW + wv) * 16 * QT;
   const T* qb = (const T*)p.q + (size_t)b * N * p.ldq + h * d;
   const T* kb = (const T*)p.k + (size_t)b * N * p.ldk + h * d;
   const T* vb = (const T*)p.vt + (size_t)b * p.vt_bs + (size_t)(h * d) * p.vt_rs;
-  SaQ<T> qf[2];
+  SaQ<T> qf[QT];
 #pragma unroll
-  for (int qt = 0; qt < 2; ++qt) {
+  for (int qt = 0; qt < QT; ++qt) {
     const int px = px0 + 16 * qt + c16;
     V8 z = {};
     V4 z4 = {};
@@ -575,13 +575,15 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
       step[i] = __builtin_amdgcn_readfirstlane(KB * (int)sizeof(T));
     }
     const int f2 = f - NKF;
-    if (f < NFR && f2 >= 0 && f2 % NDT == NDT - 1 && 16 * (NDT - 1) + c16 == d) {      // the ones row of V^T: written once per ring slot
+    if (f < NFR && f2 >= 0 && f2 % NDT == NDT - 1 && 16 * (NDT - 1) + c16 >= d) {
+      // rows 40..47 of V^T do not exist: row 40 is the ones row (softmax denominator), rows 41..47 feed accumulator rows nobody reads.
+      // Their lanes take no part in the DMA (7/16 of two fragments less through L2 -> LDS); their LDS bytes are written once per ring slot
       keep &= ~(1u << i);
-      V8 ones;
+      V8 fill;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ones[j] = (T)1.0f;
+      for (int j = 0; j < 8; ++j) fill[j] = (T)(16 * (NDT - 1) + c16 == d ? 1.0f : 0.0f);
 #pragma unroll
-      for (int sl = 0; sl < DEPTH; ++sl) *(V8*)(smem_sa + sl * BB + f * FRAG + lane * 16) = ones;
+      for (int sl = 0; sl < DEPTH; ++sl) *(V8*)(smem_sa + sl * BB + f * FRAG + lane * 16) = fill;
     }
   }
   // 11 fragments over NW waves: the first NFR - NW (PER - 1) waves copy PER of them per block, the others PER - 1 — no padding copies
@@ -610,11 +612,17 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
     __builtin_amdgcn_s_barrier();
 #endif
   };
-  f32x4 oA[3], oB[3], sA[4], sB[4];
-  V8 pA[2], pB[2];
-  float mA = 0.f, mB = 0.f;
+  // QT query tiles per wave, a 1 / QT block apart: step i of a block issues the MFMAs of tile i with the softmax of tile i - 1 (mod QT)
+  // between them. QT = 3: 192 queries per workgroup share a block's 11 KiB (and every operand read from LDS serves three tiles).
+  f32x4 o[QT][3], sc[QT][4];
+  V8 pb[QT][2];
+  float mrun[QT];
 #pragma unroll
-  for (int u = 0; u < 3; ++u) oA[u] = oB[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int qt = 0; qt < QT; ++qt) {
+    mrun[qt] = 0.f;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) o[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const char* lane_base = smem_sa + lane * 16;
   // Operand registers are double-buffered: K(j+1) and V^T(j) are requested from LDS in the MIDDLE of block j (behind the rendezvous
   // for block j+1) and land under its second half step. With the reads at the top of a block every wave of the workgroup — they leave
@@ -640,12 +648,12 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
   };
   stage(smem_sa);
   if (nblk > 1) stage(smem_sa + BB);
-  // block 0: S_A(0); rendezvous for block 1, its K and block 0's V^T requested; then S_B(0) with the softmax of A between its MFMAs
-  // (both tiles take the exact maximum of their first block: `first`)
+  // block 0: S of tile 0; rendezvous for block 1, its K and block 0's V^T requested; then S of tile i with the softmax of tile i - 1
+  // between its MFMAs (every tile takes the exact maximum of its first block: `first`)
   arrive(0);
   if (nblk > 2) stage(smem_sa + 2 * BB);
   load_k(ka[0], 0);
-  sa_half_step<T, false, true, false>(ka[0], va[0], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, false);
+  sa_half_step<T, false, true, false>(ka[0], va[0], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], false);
   if (nblk > 1) {
     arrive(1);
     if (nblk > 3) stage(smem_sa + 3 * BB);
@@ -653,10 +661,12 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
   }
   load_v(va[1], 0);
   __builtin_amdgcn_sched_barrier(0);
-  sa_half_step<T, false, true, true>(ka[0], va[0], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, true);
+#pragma unroll
+  for (int i = 1; i < QT; ++i)
+    sa_half_step<T, false, true, true>(ka[0], va[0], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], true);
   auto body = [&](auto slot_tag, const int blk) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value, c = SLOT & 1;      // block blk sits in ring slot SLOT = blk % 4, register set blk & 1
-    sa_half_step<T, true, true, true>(ka[c], va[c], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, blk == 1);
+    sa_half_step<T, true, true, true>(ka[c], va[c], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], blk == 1);
     if (blk + 1 < nblk) {
       arrive(blk + 1);
 #if !(STA_SA_ABLATE & 16)
@@ -666,7 +676,9 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
     }
     load_v(va[c ^ 1], SLOT);
     __builtin_amdgcn_sched_barrier(0);
-    sa_half_step<T, true, true, true>(ka[c], va[c], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, false);
+#pragma unroll
+    for (int i = 1; i < QT; ++i)
+      sa_half_step<T, true, true, true>(ka[c], va[c], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], false);
   };
   for (int blk = 1; blk < nblk; blk += DEPTH) {
     body(std::integral_constant<int, 1>{}, blk);
@@ -674,28 +686,30 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
     if (blk + 2 < nblk) body(std::integral_constant<int, 3>{}, blk + 2);
     if (blk + 3 < nblk) body(std::integral_constant<int, 0>{}, blk + 3);
   }
-  // drain: PV of the last block for A with B's last softmax between, then PV for B (V^T of the last block: register set nblk & 1)
-  if (nblk & 1) {
-    sa_half_step<T, true, false, true>(ka[1], va[1], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, nblk == 1);
-    sa_half_step<T, true, false, false>(ka[1], va[1], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, false);
-  } else {
-    sa_half_step<T, true, false, true>(ka[0], va[0], qf[0], sA, oA, pA, mA, sB, oB, pB, mB, false);
-    sa_half_step<T, true, false, false>(ka[0], va[0], qf[1], sB, oB, pB, mB, sA, oA, pA, mA, false);
-  }
-  f32x4 o[2][3];
+  // drain: PV of the last block for tile 0 with the last tile's last softmax between, then PV for the others (V^T of the last block:
+  // register set nblk & 1)
+  auto drain = [&](auto set_tag) __attribute__((always_inline)) {
+    constexpr int c = decltype(set_tag)::value;
+    sa_half_step<T, true, false, true>(ka[c], va[c], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], nblk == 1);
 #pragma unroll
-  for (int u = 0; u < 3; ++u) { o[0][u] = oA[u]; o[1][u] = oB[u]; }
-  const float mrun[2] = {mA, mB}, lrun[2] = {0.f, 0.f};
-  sa_epilogue<T, 3, 2, true>(p, o, mrun, lrun, b, h, px0, g, c16, lane);
+    for (int i = 1; i < QT; ++i)
+      sa_half_step<T, true, false, false>(ka[c], va[c], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], false);
+  };
+  if (nblk & 1) drain(std::integral_constant<int, 1>{});
+  else drain(std::integral_constant<int, 0>{});
+  float lrun[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) lrun[qt] = 0.f;
+  sa_epilogue<T, 3, QT, true>(p, o, mrun, lrun, b, h, px0, g, c16, lane);
 }
 
-template <typename T, int NW>
+template <typename T, int NW, int QT>
 int launch_sa_pipe(const SParams& p, hipStream_t st) {
   constexpr int lds = 4 * ((11 + NW - 1) / NW * NW) * FRAG;
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)selfattn_fwd_pipe_kernel<T, NW>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn pipe) failed");
-  const int tiles = (p.N + 32 * NW - 1) / (32 * NW);
-  hipLaunchKernelGGL((selfattn_fwd_pipe_kernel<T, NW>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds, st, p);
+  if (!attr.ensure((const void*)selfattn_fwd_pipe_kernel<T, NW, QT>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn pipe) failed");
+  const int tiles = (p.N + 16 * QT * NW - 1) / (16 * QT * NW);
+  hipLaunchKernelGGL((selfattn_fwd_pipe_kernel<T, NW, QT>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn pipe launch: %s", hipGetErrorString(e));
 }
@@ -745,8 +759,15 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
   if (p.d == 40 && p.H == 8 && p.sl2e == 1.0f && p.N % KB == 0 && g_sta_opt[STA_OPT_SELFATTN_PIPE] != 2 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 8)
   {
     // 128 queries per workgroup (four waves, two workgroups per CU); 256 (eight waves, one workgroup per CU) as an option: profiles/r05_selfattn.md
-    const bool eight = g_sta_opt[STA_OPT_SELFATTN_PIPE] == 8;       // (measured equal to slower than four waves once the padding copies were gone)
-    return eight ? launch_sa_pipe<T, 8>(p, st) : launch_sa_pipe<T, 4>(p, st);
+    if (g_sta_opt[STA_OPT_SELFATTN_PIPE] == 8) return launch_sa_pipe<T, 8, 2>(p, st);   // (measured equal to slower than four waves once the padding copies were gone)
+    if (g_sta_opt[STA_OPT_SELFATTN_PIPE] == 3) return launch_sa_pipe<T, 4, 3>(p, st);   // three query tiles per wave: 192 queries per workgroup
+    if (g_sta_opt[STA_OPT_SELFATTN_PIPE] == 4) return launch_sa_pipe<T, 4, 2>(p, st);
+    // Three tiles per wave move a third less through L2 -> LDS per query (-5 % at 64 x 8 heads, N = 4096; -4 % at N = 9216:
+    // profiles/r05_selfattn.md) but make 1.5 x longer workgroups: taken when the launch's rounds of 512 resident workgroups (2 per CU)
+    // do not quantise worse than with two tiles (8 images x 8 heads at N = 4096: 2.75 rounds of 192-query workgroups against 4.0 of 128)
+    const long wg3 = (long)((p.N + 191) / 192) * p.H * p.B, wg2 = (long)((p.N + 127) / 128) * p.H * p.B;
+    const long r3 = (wg3 + 511) / 512, r2 = (wg2 + 511) / 512;
+    return 57 * r3 < 40 * r2 ? launch_sa_pipe<T, 4, 3>(p, st) : launch_sa_pipe<T, 4, 2>(p, st);      // 3 x 0.95 vs 2 tiles' worth per round
   }
   switch ((p.d + 15) / 16) {
     case 1: return launch_sa<T, 1, 1>(p, st);

@@ -70,7 +70,7 @@ enum {
   STA_OPT_PROJ_PAIR = 7,    /* sta_xattn_fwd_proj: 1 = head-pair kernel whenever the shape allows, 2 = one head per workgroup */
   STA_OPT_SELFATTN_WAVES = 8, /* sta_selfattn_fwd at d <= 48, log2-domain path: 8 = eight waves x one query tile (four waves per SIMD; measured
                                  slower, kept for tests / tools), anything else = four waves x two tiles */
-  STA_OPT_SELFATTN_PIPE = 9, /* sta_selfattn_fwd at d = 40, 8 heads, log2-domain q, N % 64 == 0: 2 = the plain loop instead of the software-pipelined one; 4 / 8 = force its four- / eight-wave geometry */
+  STA_OPT_SELFATTN_PIPE = 9, /* sta_selfattn_fwd at d = 40, 8 heads, log2-domain q, N % 64 == 0: 2 = the plain loop instead of the software-pipelined one; 3 = three query tiles per wave (192 queries per workgroup), 4 / 8 = four / eight waves x two tiles */
   STA_OPT_COUNT = 10
 };
 int sta_set_option(int key, int value);

@@ -435,7 +435,7 @@ def test_self_attention_software_pipelined_loop(N, dtype):
     qd, kd, vtd = qs.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda()
     outs = {}
     try:
-        for mode in (2, 4, 8, 0):
+        for mode in (2, 4, 8, 3, 0):
             lib.set_option(lib.OPT_SELFATTN_PIPE, mode)
             o = ops.self_attention(qd, kd, vtd, heads, ops.LN2)
             o_f = ops.from_sfrag(ops.self_attention(qd, kd, vtd, heads, ops.LN2, sfrag=True)) if N % 16 == 0 else None
@@ -445,7 +445,7 @@ def test_self_attention_software_pipelined_loop(N, dtype):
     finally:
         lib.set_option(lib.OPT_SELFATTN_PIPE, 0)
     eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
-    for mode in (8, 0):                               # (8 forced at every N; the dispatcher's own choice is one of the two)
+    for mode in (8, 3, 0):                            # (8 waves / 3 tiles per wave forced at every N; the dispatcher's own choice is one of them)
         for a, b_ in zip(outs[mode], outs[4]):
             if a is not None:
                 assert torch.equal(a, b_), (mode, (a.float() - b_.float()).abs().max().item())
@@ -457,7 +457,7 @@ def test_self_attention_software_pipelined_loop(N, dtype):
     v64 = v.double().view(B, N, heads, d).transpose(1, 2)
     logits = q64 @ k64.transpose(-1, -2) * ops.LN2
     ref = (torch.softmax(logits, -1) @ v64).transpose(1, 2).reshape(B, N, C)
-    for mode in (4, 8):
+    for mode in (4, 8, 3):
         err = (outs[mode][0].float().cpu().double() - ref).abs()
         assert torch.isfinite(outs[mode][0]).all()
         assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (mode, err.max(), ref.abs().max())

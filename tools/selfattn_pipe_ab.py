@@ -30,7 +30,7 @@ for dtype in (torch.float16, torch.bfloat16):
         run = lambda: ops.self_attention(qk[..., :C], qk[..., C:], vt, h, ops.LN2)
         res = {"dtype": str(dtype)[6:], "B": B, "N": N, "d": d}
         outs = {}
-        names = {(0, 0): "pipelined_8waves", (4, 0): "pipelined_4waves", (2, 0): "plain_4waves", (2, 16): "plain_8waves"}
+        names = {(4, 0): "pipelined_4x2", (3, 0): "pipelined_4x3", (8, 0): "pipelined_8x2", (2, 0): "plain_4x2"}
         for rnd in range(2):
             for (mode, waves), name in names.items():
                 lib.set_option(lib.OPT_SELFATTN_PIPE, mode)
@@ -39,7 +39,7 @@ for dtype in (torch.float16, torch.bfloat16):
                 res.setdefault(name + "_us", []).append(round(timed(run), 1))
         lib.set_option(lib.OPT_SELFATTN_PIPE, 0)
         lib.set_option(lib.OPT_SELFATTN_WAVES, 0)
-        res["max_abs_diff"] = max((outs[n] - outs["plain_4waves"]).abs().max().item() for n in outs)
+        res["max_abs_diff"] = max((outs[n] - outs["plain_4x2"]).abs().max().item() for n in outs)
         flop = 4.0 * B * h * N * N * d
         for n in names.values():
             res["tflops_" + n] = round(flop / min(res[n + "_us"]) / 1e6, 1)
