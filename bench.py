@@ -82,6 +82,10 @@ def parse():
                     help="start the ranks, form the process group (RCCL on GPUs, gloo without), broadcast the frozen weights, check every "
                          "rank holds rank 0's bytes, and stop BEFORE the first kernel of the sampler: the multi-rank plumbing of --gpus N, "
                          "runnable on a CPU-only host (a reduced-width UNet there)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST MODE for one-GPU boxes: all --gpus N ranks run on GPU 0 and gloo carries the collectives (RCCL refuses duplicate "
+                         "devices in one communicator). Everything else of the N > 1 path is the real thing: own ranks, per-rank MIOpen db copies, "
+                         "the bucketed weight transfer, hipGraph capture in N processes, barrier + max over ranks. Not a throughput figure")
     ap.add_argument("--opt-epochs", type=int, default=0,
                     help="weight-optimisation epochs (0 = fixed weights = BASELINE configs[1], the headline; 3 = configs[2] "
                          "with a CLIP stand-in loss, reported as a side measurement)")
@@ -439,7 +443,7 @@ def dry_launch(a, rank, world, local):
     from sta import parallel
     from sta.pipeline import build_sd_v1
     on_gpu = torch.cuda.is_available()
-    dev = torch.device("cuda", local) if on_gpu else torch.device("cpu")
+    dev = torch.device("cuda", 0 if a.share_gpu else local) if on_gpu else torch.device("cpu")
     dt = (torch.float16 if a.dtype == "fp16" else torch.bfloat16) if on_gpu else torch.float32
     over = None if on_gpu else dict(model_channels=32, num_heads=2, context_dim=64)
     model = build_sd_v1(dev, dt, with_vae=on_gpu, init_weights=(rank == 0), seed=0, unet_overrides=over,
@@ -482,7 +486,7 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
         raise SystemExit(self_launch(a.gpus))
     from sta import parallel
-    rank, world, local = parallel.init_from_env()
+    rank, world, local = parallel.init_from_env(backend="gloo" if a.share_gpu else None)
     if world != a.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (run `python bench.py --gpus %d`, which starts its own ranks, or "
                          "torch.distributed.run --nproc-per-node %d)" % (a.gpus, world, a.gpus, a.gpus))
@@ -490,13 +494,16 @@ def main():
         return dry_launch(a, rank, world, local)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    db_slot = local
+    if a.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from ldm.models.diffusion.plms import PLMSSampler
     from sta import lib
     from sta.pipeline import DEFAULT_CENTRES, build_sd_v1, conditionings, load_prompts, set_recompute, use_shipped_miopen_db
     lib.load()
-    use_shipped_miopen_db(local)      # per-rank copy of the shipped MIOpen find-db (before the first convolution)
+    use_shipped_miopen_db(db_slot)      # per-rank copy of the shipped MIOpen find-db (before the first convolution)
 
     K, dt = a.objects, (torch.float16 if a.dtype == "fp16" else torch.bfloat16)
     ckpt_mode = None
@@ -577,7 +584,7 @@ def main():
                                        "fixed blend weights (BASELINE configs[1])" if a.opt_epochs == 0 else
                                        "%d weight-optimisation epochs, CLIP stand-in loss (BASELINE configs[2])" % a.opt_epochs),
                    "global_batch": world * I, "images_per_step": I, "prompts": "first 64 of datasets/mscoco.txt; step j of rank r takes prompts ((j * %d + r) * %d + i) %% 64" % (world, I),
-                   "parallelism": "prompt-parallel dp%d" % world, "hipgraph": not a.no_graph,
+                   "parallelism": "prompt-parallel dp%d" % world + (" (TEST MODE: all ranks on GPU 0, collectives over gloo)" if a.share_gpu else ""), "hipgraph": not a.no_graph,
                    "linear_weights": "e4m3 (sta.fp8)" if a.fp8 else a.dtype, "trunk_layout": "NHWC" if (a.channels_last or a.opt_epochs == 0) and not a.nchw else "NCHW",
                    "trunk_kernels": _trunk_kernels(a),
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,

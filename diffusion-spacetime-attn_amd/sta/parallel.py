@@ -46,6 +46,13 @@ def _broadcast_flat(flat, src, world):
     the group with mismatched calls (hang). Both backends used here implement scatter (RCCL through send/recv, gloo
     natively). Tiny buckets go as one plain broadcast."""
     n = flat.numel()
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        # ranks sharing one GPU (bench.py --share-gpu: the N > 1 plumbing on a one-GPU box, where RCCL refuses duplicate devices):
+        # gloo has no scatter / all-gather on device tensors, the bucket is staged through the host
+        host = flat.cpu()
+        _broadcast_flat(host, src, world)
+        flat.copy_(host)
+        return
     if n < 4096 * world:
         dist.broadcast(flat, src=src)
         return
@@ -101,6 +108,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

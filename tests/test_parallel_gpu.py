@@ -112,3 +112,20 @@ def test_bench_two_ranks_end_to_end():
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["weight_broadcast_bytes"] > 1.5e9
+
+
+def test_bench_two_ranks_sharing_one_gpu_end_to_end():
+    """What a one-GPU box CAN execute of the N = 2 bench: `--share-gpu` puts both ranks on GPU 0 and lets gloo carry
+    the collectives (RCCL refuses duplicate devices); everything else is the real multi-rank path — bench.py starting its own ranks,
+    rank 0's weights reaching rank 1 through the bucketed scatter + all-gather (1.9 GB, host-staged here), a MIOpen user-db copy per rank,
+    the CFG UNet call captured into a hipGraph in two processes at once, disjoint prompt shards, barrier + max over ranks, ONE JSON line."""
+    r, lines = _bench("--gpus", "2", "--share-gpu", "--steps", "1", "--warmup", "1", "--images-per-step", "2", "--ddim_steps", "4",
+                      "--no-cpu-baseline", "--no-side-runs", "--no-roofline", timeout=1500)
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 4
+    assert out["config"]["weight_broadcast_bytes"] > 1.5e9 and "TEST MODE" in out["config"]["parallelism"]
+    r, lines = _bench("--gpus", "2", "--share-gpu", "--dry-launch")
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["weights_identical_on_every_rank"] and d["backend"] == "gloo" and d["device"] == "cuda" and d["n_gpus"] == 2
