@@ -507,6 +507,106 @@ __global__ __launch_bounds__(256) void add_layernorm_qfrag_kernel(const T* __res
   for (int t = threadIdx.x; t < nvec * 16; t += 256) yo[t] = *(const V8*)(tile + (t >> 4) * CHUNK + (t & 15) * 16);
 }
 
+// The same for 512 < C <= 1024 (SD-v1 level 1, C = 640: norm2's output feeding the locals-from-L2 projection-fused kernel of
+// csrc/sta_xattn_proj.hip): a lane holds chunks `lane` and `lane + 64` of its four rows — add_layernorm_kernel's own lane
+// assignment and summation order (chunk 0's eight values, then chunk 1's), so the values stay bit-identical to the row-major pass.
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_qfrag_wide_kernel(const T* __restrict__ x, const T* __restrict__ f,
+                                                                     const T* __restrict__ bias, const T* __restrict__ gamma,
+                                                                     const T* __restrict__ beta, T* s_out, T* __restrict__ y,
+                                                                     long R, int C, float eps) {
+  using V8 = typename V8T<T>::type;
+  constexpr int CHUNK = 272, NV = 2;
+  __shared__ __attribute__((aligned(16))) char tile[64 * NV * CHUNK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nvec = C >> 3;
+  const long row0 = (long)blockIdx.x * 16 + 4 * wv;
+  float v[4][NV][8];
+  float sum[4], sq[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long row = row0 + r;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = lane + 64 * j;
+      V8 a = {}, b = {};
+      if (idx < nvec) {
+        a = ((const V8*)(x + row * C))[idx];
+        if (f) b = ((const V8*)(f + row * C))[idx];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[r][j][e] = (float)a[e];
+      if (f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[r][j][e] += (float)b[e];
+      }
+    }
+  }
+  V8 bs[NV] = {}, gm[NV] = {}, bt[NV] = {};
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = lane + 64 * j;
+    if (idx < nvec) {
+      if (bias) bs[j] = ((const V8*)bias)[idx];
+      gm[j] = ((const V8*)gamma)[idx];
+      bt[j] = ((const V8*)beta)[idx];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const long row = row0 + r;
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = lane + 64 * j;
+      if (bias) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[r][j][e] += (float)bs[j][e];
+      }
+      if (s_out) {
+        V8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          o[e] = (T)v[r][j][e];
+          v[r][j][e] = (float)o[e];
+        }
+        if (idx < nvec) ((V8*)(s_out + row * C))[idx] = o;
+      }
+      if (idx < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += v[r][j][e];
+      }
+    }
+    sum[r] = t;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float mean = wave_sum(sum[r]) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+      if (lane + 64 * j < nvec) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float dlt = v[r][j][e] - mean;
+          q += dlt * dlt;
+        }
+      }
+    sq[r] = q;
+    const float rstd = rsqrtf(wave_sum(sq[r]) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = lane + 64 * j;
+      V8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (T)((v[r][j][e] - mean) * rstd * (float)gm[j][e] + (float)bt[j][e]);
+      if (idx < nvec) *(V8*)(tile + idx * CHUNK + (4 * wv + r) * 16) = o;
+    }
+  }
+  __syncthreads();
+  V8* yo = (V8*)y + (size_t)blockIdx.x * nvec * 16;
+  for (int t = threadIdx.x; t < nvec * 16; t += 256) yo[t] = *(const V8*)(tile + (t >> 4) * CHUNK + (t & 15) * 16);
+}
+
 // --------------------------------------------------------------------------------------------------
 // y = a + b + bias[c] over [B][C][HW]
 // --------------------------------------------------------------------------------------------------
@@ -613,11 +713,20 @@ int sta_add_layernorm_qfrag(const void* x, const void* f, const void* bias, cons
                             void* y, long R, int C, float eps, int dtype, void* stream) {
   g_sta_err[0] = 0;
   if (!x || !gamma || !beta || !y) return sta_fail(STA_E_ARG, "null pointer");
-  if (R <= 0 || R % 16 || C <= 0 || C % 32 || C > 512)
-    return sta_fail(STA_E_ARG, "add_layernorm_qfrag: R=%ld C=%d (need R %% 16 == 0, C %% 32 == 0, C <= 512)", R, C);
+  if (R <= 0 || R % 16 || C <= 0 || C % 32 || C > 1024)
+    return sta_fail(STA_E_ARG, "add_layernorm_qfrag: R=%ld C=%d (need R %% 16 == 0, C %% 32 == 0, C <= 1024)", R, C);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
   const unsigned blocks = (unsigned)(R / 16);
   hipStream_t st = (hipStream_t)stream;
+  if (C > 512) {      // two chunks per lane
+    if (dtype == STA_BF16)
+      hipLaunchKernelGGL(add_layernorm_qfrag_wide_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)f,
+                         (const __bf16*)bias, (const __bf16*)gamma, (const __bf16*)beta, (__bf16*)s, (__bf16*)y, R, C, eps);
+    else
+      hipLaunchKernelGGL(add_layernorm_qfrag_wide_kernel<_Float16>, dim3(blocks), dim3(256), 0, st, (const _Float16*)x, (const _Float16*)f,
+                         (const _Float16*)bias, (const _Float16*)gamma, (const _Float16*)beta, (_Float16*)s, (_Float16*)y, R, C, eps);
+    return launched("add_layernorm_qfrag");
+  }
   if (dtype == STA_BF16)
     hipLaunchKernelGGL(add_layernorm_qfrag_kernel<__bf16>, dim3(blocks), dim3(256), 0, st, (const __bf16*)x, (const __bf16*)f,
                        (const __bf16*)bias, (const __bf16*)gamma, (const __bf16*)beta, (__bf16*)s, (__bf16*)y, R, C, eps);

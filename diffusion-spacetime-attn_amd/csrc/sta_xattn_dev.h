@@ -321,12 +321,26 @@ __device__ __forceinline__ void store_row16(T* obase, const f32x4 (&a)[NDT], int
   }
 }
 
+// Where a context's operand fragments come from: LDS (`const V8*` = wave-uniform base + lane, fragment f at f * 64 elements) or,
+// for the kernels that cannot keep every context resident (sta_xattn_proj.hip, locals-from-L2 variant), the packed image in
+// global memory through a buffer descriptor — one fully coalesced 1-KiB load per fragment, per-fragment offset in an SGPR.
+template <typename V8>
+struct SrdFrags {
+  __amdgpu_buffer_rsrc_t r;
+  unsigned voff;     // lane * 16
+  unsigned soff;     // byte offset of the (context, head) block inside the descriptor's range (wave-uniform)
+};
+template <typename V8>
+__device__ __forceinline__ V8 frag_at(const V8* fr, int f) { return fr[f * 64]; }
+template <typename V8>
+__device__ __forceinline__ V8 frag_at(const SrdFrags<V8>& fr, int f) { return srd_load16<V8>(fr.r, fr.voff, fr.soff + 1024u * (unsigned)f); }
+
 // One context of the LDS-resident kernel for the QT pixel tiles of a wave. KIND is compile time — 0: ""
 // on the uncond row (-> au), 1: global prompt on the cond row (-> ac), 2: a local prompt, ac += w (A - au) —
 // so there is no per-context select/copy of the accumulators, queries or weights left in the instruction
 // stream (the runtime-`c` version spent ~2/3 of its VALU slots on v_cndmask/v_mov and scalar branches).
-template <typename T, int NDT, int QT, int KIND>
-__device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, const typename Tr<T>::V8 (&q)[QT][nks_of(NDT)],
+template <typename T, int NDT, int QT, int KIND, typename FR>
+__device__ __forceinline__ void attend_staged(const FR fr, const typename Tr<T>::V8 (&q)[QT][nks_of(NDT)],
                                               const f32x4 kb4, const float sl2e, const float (&w)[QT],
                                               f32x4 (&au)[QT][NDT], f32x4 (&ac)[QT][NDT], const int sumrow) {
   using V8 = typename Tr<T>::V8;
@@ -345,12 +359,12 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
   if constexpr (JIT) {
     V8 kt[2][NKS];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) kt[0][s] = fr[s * 64];
+    for (int s = 0; s < NKS; ++s) kt[0][s] = frag_at<V8>(fr, s);
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
       if (t + 1 < NKT) {
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) kt[(t + 1) & 1][s] = fr[((t + 1) * NKS + s) * 64];
+        for (int s = 0; s < NKS; ++s) kt[(t + 1) & 1][s] = frag_at<V8>(fr, ((t + 1) * NKS + s));
       }
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -363,7 +377,7 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
   } else {
     V8 ka[NKF];
 #pragma unroll
-    for (int f = 0; f < NKF; ++f) ka[f] = fr[f * 64];
+    for (int f = 0; f < NKF; ++f) ka[f] = frag_at<V8>(fr, f);
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
@@ -375,7 +389,7 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
       }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int f = 0; f < NVF; ++f) va[f] = fr[(NKF + f) * 64];
+    for (int f = 0; f < NVF; ++f) va[f] = frag_at<V8>(fr, (NKF + f));
   }
   float inv[QT];
   V8 pb[QT][NPS];
@@ -388,12 +402,12 @@ __device__ __forceinline__ void attend_staged(const typename Tr<T>::V8* fr, cons
   if constexpr (JIT) {
     V8 vt[2][NPS];
 #pragma unroll
-    for (int s = 0; s < NPS; ++s) vt[0][s] = fr[(NKF + s * NDT) * 64];
+    for (int s = 0; s < NPS; ++s) vt[0][s] = frag_at<V8>(fr, (NKF + s * NDT));
 #pragma unroll
     for (int u = 0; u < NDT; ++u) {
       if (u + 1 < NDT) {
 #pragma unroll
-        for (int s = 0; s < NPS; ++s) vt[(u + 1) & 1][s] = fr[(NKF + s * NDT + u + 1) * 64];
+        for (int s = 0; s < NPS; ++s) vt[(u + 1) & 1][s] = frag_at<V8>(fr, (NKF + s * NDT + u + 1));
       }
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {

@@ -107,9 +107,18 @@ struct PParams {
 //   attention   : contexts 0, 1 and the local contexts whose disc touches the wave's pixels, from LDS
 //                 (attend_staged, shared with sta_xattn.hip) — blend in registers, 16-byte stores.
 // No barrier after the prologue: waves drift apart, one wave's projection MFMAs run beside another's softmax VALU.
-template <typename T, int NDT, int NWV, int RING>
+//
+// LL2 (locals from L2; SD-v1 level 1: C = 640, d = 80): the Wq slice (100 KiB) and the TWO mandatory contexts (2 x 30 KiB) fill
+// the CU's 160 KiB exactly; the local contexts — needed only by the 16-pixel groups a disc touches — are read as MFMA operands
+// straight from the packed image in global memory (one coalesced 1-KiB buffer load per fragment, L2 hits: the image of a prompt
+// is 30 KiB per (context, head) and every workgroup of the image walks it).
+// YFRAG: y in query-fragment order (sta_add_layernorm_qfrag), as in the head-pair kernel: one load = one contiguous KiB.
+// (A fully unrolled projection loop with the Wq fragments of k-step s + 1 requested before the MFMAs of step s — the schedule of
+// sta_xattn_proj3.hip — measured 3 % SLOWER here than hipcc's just-in-time reads at 36 registers more: profiles/r05_level1_proj.md.)
+template <typename T, int NDT, int NWV, int RING, bool LL2 = false, bool YFRAG = false>
 __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PParams p) {
   using V8 = typename Tr<T>::V8;
+  constexpr unsigned YSTEP = YFRAG ? 1024u : 64u;      // bytes between consecutive k-steps of a lane's y loads
   constexpr int NKS = nks_of(NDT);
   constexpr int NFWD = fwd_frags(NDT);
   constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
@@ -139,7 +148,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
 
   // ---- prologue: LDS-DMA of Wq_h and every context, first y steps of the first tile -------------------------
   stage_frags(p.wq + (size_t)h * nwq * FRAG, smem, nwq, wv, NWV, lane);
-  for (int c = 0; c < K + 2; ++c) stage_frags(kv + c * ctx_stride, lds_ctx + c * CB, NFWD, wv, NWV, lane);
+  for (int c = 0; c < (LL2 ? 2 : K + 2); ++c) stage_frags(kv + c * ctx_stride, lds_ctx + c * CB, NFWD, wv, NWV, lane);
+  // LL2: descriptor over this image's whole packed K/V image; block (ctx, h) sits at (ctx * H + h) * CB
+  SrdFrags<V8> gfr;
+  gfr.r = make_srd(p.kv + (size_t)img * (K + 2) * ctx_stride, (unsigned)((K + 2) * ctx_stride));
+  gfr.voff = (unsigned)lane * 16u;
+  gfr.soff = 0u;
 
   const int mine = (p.tiles - wt + W - 1) / W;    // tiles wt, wt + W, ... of this workgroup
   const int iters = mine < p.iters ? mine : p.iters;
@@ -151,6 +165,10 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
   // over L2 channels, measured equal to slower: 87.3 / 91.5 / 101 us with heads 4 / 2 / 1 per phase vs 87.2 us.)
   auto tile_of = [&](int it) -> int { return wt + it * W; };
   auto voff_of = [&](int it) -> unsigned {
+    if constexpr (YFRAG) {      // fragment s of the wave's 16-pixel group: byte offset of its first pixel's row + 1024 s + 16 lane
+      const int px0 = tile_of(it) * TP + wv * 16;
+      return (it < iters && px0 < N) ? (unsigned)px0 * row_bytes + (unsigned)lane * 16u : 0xfffffff0u;
+    }
     const int px = tile_of(it) * TP + wv * 16 + c16;
     return (it < iters && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
   };
@@ -163,8 +181,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
   unsigned mb = mask_of(0);
 #pragma unroll
   for (int j = 0; j < RING; ++j) {
-    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
-    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
+    yr0[j] = srd_load16<V8>(y_srd, voff, YSTEP * j);
+    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + YSTEP * j);
   }
   const f32x4 kb4 = last_tile_bias(g, p.M);
   const float sl2e = p.sl2e;
@@ -200,7 +218,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
         // refill this slot with step s + RING: of this tile, or of the next one (zeros past the last tile)
         const bool wrap = s + RING >= nkc;        // scalar
         const unsigned vo = wrap ? voffn : voff;
-        const unsigned so = 64u * (unsigned)(wrap ? s + RING - nkc : s + RING);
+        const unsigned so = YSTEP * (unsigned)(wrap ? s + RING - nkc : s + RING);
         yr0[j] = srd_load16<V8>(y_srd, vo, so);
         yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
       }
@@ -234,7 +252,12 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
       if (!__ballot((mbits >> i) & 1u)) continue;  // none of this wave's pixels inside disc i
       const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
       w[0] = ((mbits >> i) & 1u) ? cw : 0.f;
-      attend_staged<T, NDT, 1, 2>((const V8*)(lds_ctx + (size_t)(2 + i) * CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
+      if constexpr (LL2) {
+        gfr.soff = (unsigned)(((2 + i) * p.H + h) * CB);
+        attend_staged<T, NDT, 1, 2>(gfr, q1, kb4, sl2e, w, au, ac, sumrow);
+      } else {
+        attend_staged<T, NDT, 1, 2>((const V8*)(lds_ctx + (size_t)(2 + i) * CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
+      }
     }
     if (it == 1) STA_T(6);
     if (valid) {
@@ -249,7 +272,7 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
   STA_T_END();
 }
 
-template <typename T, int NDT, int NWV, int RING>
+template <typename T, int NDT, int NWV, int RING, bool LL2 = false, bool YFRAG = false>
 int launch_proj_cfg(PParams p, int n_img, int lds, hipStream_t st) {
   constexpr int TP = 16 * NWV;
   p.tiles = (p.N + TP - 1) / TP;
@@ -262,9 +285,9 @@ int launch_proj_cfg(PParams p, int n_img, int lds, hipStream_t st) {
   if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
   p.W = (p.tiles + p.iters - 1) / p.iters;
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_kernel<T, NDT, NWV, RING>, 160 * 1024))
+  if (!attr.ensure((const void*)xattn_fwd_proj_kernel<T, NDT, NWV, RING, LL2, YFRAG>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_kernel<T, NDT, NWV, RING>), dim3(p.W * p.H, n_img), dim3(64 * NWV), lds, st, p);
+  hipLaunchKernelGGL((xattn_fwd_proj_kernel<T, NDT, NWV, RING, LL2, YFRAG>), dim3(p.W * p.H, n_img), dim3(64 * NWV), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj launch: %s", hipGetErrorString(e));
 }
@@ -275,6 +298,13 @@ int launch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
   // (profiles/r02_proj_fusion.md) and are gone. 4-wave workgroups stay reachable for small launches (tests).
   if (g_sta_opt[STA_OPT_STAGED_WAVES] == 4) return launch_proj_cfg<T, NDT, 4, 5>(p, n_img, lds, st);
   return launch_proj_cfg<T, NDT, 8, 5>(p, n_img, lds, st);
+}
+
+// The locals-from-L2 variant is built for the one shape that needs it (d = 80: SD-v1 level 1); 8 waves x a 5-deep y ring
+template <typename T>
+int launch_proj_ll2(const PParams& p, int n_img, int lds, hipStream_t st, bool qfrag) {
+  if ((p.d + 15) / 16 != 5) return sta_fail(STA_E_UNSUP, "head dim %d: the locals-from-L2 projection-fused forward is built for 64 < d <= 80", p.d);
+  return qfrag ? launch_proj_cfg<T, 5, 8, 5, true, true>(p, n_img, lds, st) : launch_proj_cfg<T, 5, 8, 5, true, false>(p, n_img, lds, st);
 }
 
 template <typename T>
@@ -290,9 +320,16 @@ int dispatch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
   return sta_fail(STA_E_UNSUP, "head dim %d unsupported by the projection-fused forward", p.d);
 }
 
-int proj_lds_bytes(int C, int heads, int K) {
+// LDS plan of a launch: everything resident where that fits a CU (160 KiB); else, where the Wq slice and the two mandatory
+// contexts fit (and the kernel exists: d = 80), those stay resident and the local contexts come from L2 (`ll2`).
+constexpr int LDS_CU = 160 * 1024;
+int proj_lds_bytes(int C, int heads, int K, bool* ll2 = nullptr) {
   const int d = C / heads, ndt = (d + 15) / 16;
-  return (ndt * (C / 32) + (K + 2) * fwd_frags(ndt)) * FRAG;
+  const int full = (ndt * (C / 32) + (K + 2) * fwd_frags(ndt)) * FRAG;
+  const int two = (ndt * (C / 32) + 2 * fwd_frags(ndt)) * FRAG;
+  const bool l = full > LDS_CU && two <= LDS_CU && ndt == 5 && g_sta_opt[STA_OPT_PROJ_LL2] != 2;
+  if (ll2) *ll2 = l;
+  return l ? two : full;
 }
 
 int check_proj_shape(int N, int C, int heads, int M, int K) {
@@ -303,7 +340,7 @@ int check_proj_shape(int N, int C, int heads, int M, int K) {
   if (C % (32 * RING_MIN)) return sta_fail(STA_E_UNSUP, "C=%d unsupported by the projection-fused forward (need C %% %d == 0)", C, 32 * RING_MIN);
   if (M > STA_MAX_KEYS || M <= 16 * (NKT - 1)) return sta_fail(STA_E_UNSUP, "M=%d keys unsupported (65..%d)", M, STA_MAX_KEYS);
   if (K > STA_MAX_OBJECTS) return sta_fail(STA_E_UNSUP, "K=%d objects unsupported (max %d)", K, STA_MAX_OBJECTS);
-  if (proj_lds_bytes(C, heads, K) > 160 * 1024)
+  if (proj_lds_bytes(C, heads, K) > LDS_CU)
     return sta_fail(STA_E_UNSUP, "Wq slice + %d contexts need %d bytes of LDS (160 KiB per CU)", K + 2, proj_lds_bytes(C, heads, K));
   return STA_OK;
 }
@@ -323,6 +360,14 @@ int sta_xattn_fwd_proj_supported(int C, int heads, int M, int K) {
   const int rc = check_proj_shape(16, C, heads, M, K);
   g_sta_err[0] = 0;
   return rc == STA_OK;
+}
+
+int sta_xattn_fwd_proj_locals_from_l2(int C, int heads, int M, int K) {
+  const int rc = check_proj_shape(16, C, heads, M, K);
+  g_sta_err[0] = 0;
+  bool ll2 = false;
+  if (rc == STA_OK) proj_lds_bytes(C, heads, K, &ll2);
+  return rc == STA_OK && ll2;
 }
 
 size_t sta_xattn_packed_wq_bytes(int C, int heads) {
@@ -401,7 +446,9 @@ static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packe
 int sta_xattn_fwd_proj_qfrag_supported(int n_img, int N, int C, int heads, int M, int K) {
   const int rc = n_img < 1 ? STA_E_ARG : check_proj_shape(N, C, heads, M, K);
   g_sta_err[0] = 0;
-  return rc == STA_OK && N % 16 == 0 && takes_pair_kernel(n_img, N, C, heads, M, K);
+  bool ll2 = false;
+  if (rc == STA_OK) proj_lds_bytes(C, heads, K, &ll2);
+  return rc == STA_OK && N % 16 == 0 && (ll2 || takes_pair_kernel(n_img, N, C, heads, M, K));
 }
 
 int sta_xattn_fwd_proj_qfrag(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
@@ -442,7 +489,8 @@ static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packe
   }
   p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K; p.nkc = C / 32;
   p.sl2e = scale * 1.4426950408889634f;
-  const int lds = proj_lds_bytes(C, heads, K);
+  bool ll2 = false;
+  const int lds = proj_lds_bytes(C, heads, K, &ll2);
   hipStream_t st = (hipStream_t)stream;
   // Head pairs share one read of y where both heads' operands fit a CU (d = 40, C = 160 / 320, K <= 2: sta_xattn_proj3.hip)
   // and the launch still fills the chip with one pair workgroup per CU (level 0 at 32 / 16 images: 147 / 72 us against
@@ -453,6 +501,11 @@ static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packe
     const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
     return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st, qfrag, ofrag);
   }
-  if (qfrag) return sta_fail(STA_E_UNSUP, "query-fragment order is read by the head-pair kernel only (sta_xattn_fwd_proj_qfrag_supported)");
+  if (ll2) {      // SD-v1 level 1: Wq + the two mandatory contexts resident, local contexts from L2
+    if (qfrag && N % 16) return sta_fail(STA_E_UNSUP, "query-fragment order needs N %% 16 == 0 (N=%d)", N);
+    if (ofrag) return sta_fail(STA_E_UNSUP, "out-fragment order is written by the head-pair kernel only");
+    return dtype == STA_BF16 ? launch_proj_ll2<__bf16>(p, n_img, lds, st, qfrag) : launch_proj_ll2<_Float16>(p, n_img, lds, st, qfrag);
+  }
+  if (qfrag) return sta_fail(STA_E_UNSUP, "query-fragment order is read by the head-pair and the locals-from-L2 kernels only (sta_xattn_fwd_proj_qfrag_supported)");
   return dtype == STA_BF16 ? dispatch_proj<__bf16>(p, n_img, lds, st) : dispatch_proj<_Float16>(p, n_img, lds, st);
 }

@@ -121,8 +121,8 @@ def add_layernorm(x, f, bias, ln_weight, ln_bias, eps, store_sum=True, qfrag=Fal
     operand fragments) for sta.ops.xattn_forward_proj(..., qfrag=True), its only legal consumer."""
     C = x.shape[-1]
     if qfrag:
-        if C % 32 or C > 512 or (x.numel() // C) % 16:
-            raise ValueError("query-fragment order needs C %% 32 == 0, C <= 512 and a multiple of 16 rows, got %s" % (tuple(x.shape),))
+        if C % 32 or C > 1024 or (x.numel() // C) % 16:
+            raise ValueError("query-fragment order needs C %% 32 == 0, C <= 1024 and a multiple of 16 rows, got %s" % (tuple(x.shape),))
         s = torch.empty_like(x) if store_sum else None
         y = torch.empty_like(x)
         lib.check(lib.load().sta_add_layernorm_qfrag(x.data_ptr(), _ptr(f), _ptr(bias), ln_weight.data_ptr(), ln_bias.data_ptr(),

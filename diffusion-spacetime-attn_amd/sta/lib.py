@@ -31,7 +31,7 @@ PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-f
                     "sta_xattn_proj3.hip": ["-ffinite-math-only"], "sta_rowgemm.hip": ["-ffinite-math-only"], "sta_ffgemm.hip": ["-ffinite-math-only"], "sta_conv.hip": ["-ffinite-math-only"], "sta_gemm.hip": ["-ffinite-math-only"]}
 
 STA_BF16, STA_F16 = 0, 1
-OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_SELFATTN_32, OPT_PROJ_PAIR, OPT_SELFATTN_WAVES, OPT_SELFATTN_PIPE = range(10)
+OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_SELFATTN_32, OPT_PROJ_PAIR, OPT_SELFATTN_WAVES, OPT_SELFATTN_PIPE, OPT_PROJ_LL2 = range(11)
 FWD_STAGED, FWD_SPLIT = 1, 2
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
 
@@ -45,6 +45,7 @@ SYMBOLS = {
     "sta_xattn_pack_kv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sta_xattn_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_fwd_proj_supported": (_i, [_i, _i, _i, _i]),
+    "sta_xattn_fwd_proj_locals_from_l2": (_i, [_i, _i, _i, _i]),
     "sta_xattn_packed_wq_bytes": (_sz, [_i, _i]),
     "sta_xattn_pack_wq": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sta_xattn_packed_kv_proj_bytes": (_sz, [_i, _i, _i]),

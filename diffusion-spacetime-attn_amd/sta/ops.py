@@ -185,12 +185,25 @@ def xattn_backward(q, packed, mask, coef, dout, scale):
 PROJ_MIN_WORKGROUPS = 256     # 128-pixel workgroup tiles x heads x images from which the projection-fused kernel is used
 
 
+PROJ_LL2_IN_MODEL = True      # does the model take the locals-from-L2 variant (SD-v1 level 1) where the launch is large enough?
+                              # (measured in situ against the to_q GEMM + sta_xattn_fwd: profiles/r05_level1_proj.md)
+
+
+def proj_locals_from_l2(C, heads, M, K):
+    """Shapes sta_xattn_fwd_proj takes with only Wq + the two mandatory contexts resident (local contexts read from L2)."""
+    return bool(_lib.load().sta_xattn_fwd_proj_locals_from_l2(C, heads, M, K))
+
+
 def proj_supported(C, heads, M, K, N=None, n_img=1):
-    """Shapes sta_xattn_fwd_proj takes (Wq slice + all contexts resident in LDS) and, when N is given, launches
-    large enough that its one-workgroup-per-CU structure fills the chip."""
+    """Shapes sta_xattn_fwd_proj takes (Wq slice + all contexts resident in LDS, or — SD-v1 level 1 — the local contexts left
+    in L2) and, when N is given (the model's question), launches large enough that its one-workgroup-per-CU structure fills the chip."""
     if not _lib.load().sta_xattn_fwd_proj_supported(C, heads, M, K):
         return False
-    return N is None or ((N + 127) // 128) * heads * n_img >= PROJ_MIN_WORKGROUPS
+    if N is None:
+        return True
+    if proj_locals_from_l2(C, heads, M, K) and not PROJ_LL2_IN_MODEL:
+        return False
+    return ((N + 127) // 128) * heads * n_img >= PROJ_MIN_WORKGROUPS
 
 
 def pack_wq(weight, heads):

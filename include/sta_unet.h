@@ -52,7 +52,7 @@ int sta_add_layernorm(const void* x, const void* f, const void* bias, const void
  * s (C/32 per group, 1 KiB each) holds at byte offset (P * C/32 + s) * 1024 + (16 g + c) * 16 the 8 values
  * y[16 P + c][32 s + 8 g .. + 7] — one fragment is one MFMA B operand of sta_xattn_fwd_proj_qfrag (lane = 16 g + c),
  * fetched by one fully coalesced 1-KiB load. Same bytes in total as row-major. s (if not NULL) stays row-major.
- * R % 16 == 0, C % 32 == 0, C <= 512. Values are bit-identical to sta_add_layernorm's.
+ * R % 16 == 0, C % 32 == 0, C <= 1024 (two chunks per lane above 512). Values are bit-identical to sta_add_layernorm's.
  */
 int sta_add_layernorm_qfrag(const void* x, const void* f, const void* bias, const void* gamma, const void* beta,
                             void* s, void* y, long R, int C, float eps, int dtype, void* stream);

@@ -71,7 +71,9 @@ enum {
   STA_OPT_SELFATTN_WAVES = 8, /* sta_selfattn_fwd at d <= 48, log2-domain path: 8 = eight waves x one query tile (four waves per SIMD; measured
                                  slower, kept for tests / tools), anything else = four waves x two tiles */
   STA_OPT_SELFATTN_PIPE = 9, /* sta_selfattn_fwd at d = 40, 8 heads, log2-domain q, N % 64 == 0: 2 = the plain loop instead of the software-pipelined one; 3 = three query tiles per wave (192 queries per workgroup), 4 / 8 = four / eight waves x two tiles */
-  STA_OPT_COUNT = 10
+  STA_OPT_PROJ_LL2 = 10,    /* sta_xattn_fwd_proj where Wq + every context do not fit a CU's LDS but Wq + the two mandatory ones do (SD-v1 level 1,
+                               C = 640, d = 80): 2 = refuse (the block then takes the GEMM + sta_xattn_fwd); default: local contexts from L2 */
+  STA_OPT_COUNT = 11
 };
 int sta_set_option(int key, int value);
 
@@ -148,6 +150,9 @@ int sta_xattn_pack_kv_proj(const void* k, const void* v, void* packed,
 int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                        const float* coef, void* out,
                        int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+/* != 0 iff sta_xattn_fwd_proj takes this shape with the Wq slice and the two mandatory contexts resident in LDS and the K local
+ * contexts read from L2 as MFMA operands (SD-v1 level 1: C = 640, d = 80, K >= 1; attention.py:178 + :175-197 + :278-294 as above). */
+int sta_xattn_fwd_proj_locals_from_l2(int C, int heads, int M, int K);
 
 /*
  * sta_xattn_fwd_proj reading y in QUERY-FRAGMENT order (include/sta_unet.h: sta_add_layernorm_qfrag writes it): y = norm2(hidden)
@@ -155,9 +160,10 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
  * of kernels, like the packed K / V / Wq images. Per 16-pixel group and batch row C/32 fragments of 1 KiB, fragment s holding
  * at byte (16 g + c) * 16 the values y[16 P + c][32 s + 8 g .. + 7]: one load instruction of a wave is one coalesced KiB
  * and IS the MFMA B operand (row-major y costs 16 half-used 128-byte lines per instruction, or a DPP hand-over).
- * Results are bit-identical to sta_xattn_fwd_proj on the same values. Taken by the head-pair kernel only:
+ * Results are bit-identical to sta_xattn_fwd_proj on the same values. Taken by the head-pair kernel —
  * sta_xattn_fwd_proj_qfrag_supported(n_img, N, C, heads, M, K) != 0 iff d = 40, C in {160, 320}, K <= 2, 64 < M <= 77,
- * N % 16 == 0 and the launch has >= 256 pair workgroups.
+ * N % 16 == 0 and the launch has >= 256 pair workgroups — and by the locals-from-L2 kernel of SD-v1 level 1 (C = 640, d = 80,
+ * K >= 1, N % 16 == 0: Wq slice + the two mandatory contexts fill the CU's LDS, local contexts are MFMA operands read from L2).
  */
 int sta_xattn_fwd_proj_qfrag_supported(int n_img, int N, int C, int heads, int M, int K);
 int sta_xattn_fwd_proj_qfrag(const void* y_frag, const void* packed_wq, const void* packed_kv, const uint8_t* mask,

@@ -84,7 +84,7 @@ def test_add_layernorm(R, C, dtype, with_f, with_bias):
     _close(y2, F.layer_norm(s_ref, (C,), w.float(), b.float(), 1e-5), dtype)
 
 
-@pytest.mark.parametrize("R,C", [(8192, 320), (4096, 160), (16, 512), (48, 32)])
+@pytest.mark.parametrize("R,C", [(8192, 320), (4096, 160), (16, 512), (48, 32), (2048, 640), (32, 1024), (64, 544)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("with_f,with_bias,store", [(True, True, True), (True, False, True), (False, False, False)])
 def test_add_layernorm_query_fragment_order(R, C, dtype, with_f, with_bias, store):
@@ -109,7 +109,7 @@ def test_add_layernorm_query_fragment_order(R, C, dtype, with_f, with_bias, stor
         off = ((P * (C // 32) + sfr) * 64 + 16 * gl + c) * 8
         assert torch.equal(flat[off:off + 8], y0[16 * P + c, 32 * sfr + 8 * gl:32 * sfr + 8 * gl + 8])
     L = lib.load()
-    for (r_bad, c_bad) in [(R + 8, C), (R, 16), (R, 544)]:
+    for (r_bad, c_bad) in [(R + 8, C), (R, 16), (R, 1056)]:
         rc = L.sta_add_layernorm_qfrag(x.data_ptr(), 0, 0, w.data_ptr(), b.data_ptr(), 0, y1.data_ptr(), r_bad, c_bad, 1e-5, lib.STA_F16, 0)
         assert rc == -1 and "qfrag" in lib.last_error()
 

@@ -635,6 +635,11 @@ PROJ_SHAPES = [
     (576, 480, 10, 0, 1, None, 0, True),     # d = 48 with 10 heads (15 k-steps), no objects (per head)
     (9216, 320, 8, 4, 1, None, 0, True),     # BASELINE configs[4] level 0 (768^2, 4 objects; per head)
     (9216, 320, 8, 2, 2, None, 0, True),     # 768^2 with 2 objects: head pairs
+    (1024, 640, 8, 2, 2, None, 0, True),     # SD-v1 level 1 (d = 80): Wq + the two mandatory contexts fill the LDS, locals from L2
+    (1024, 640, 8, 2, 16, None, 0, True),    # ... 16 prompts: 8 tiles per image, one workgroup per (head, tile pair)
+    (1000, 640, 8, 3, 2, 3, 0, True),        # ... ragged N, three objects, forced tile count
+    (1024, 640, 8, 1, 3, None, 4, True),     # ... one object, 4-wave workgroups (falls back to 8: the variant is built for 8 waves)
+    (2304, 640, 8, 4, 1, None, 0, True),     # BASELINE configs[4] level 1 (768^2, 4 objects)
 ]
 
 
@@ -679,6 +684,11 @@ def test_fwd_proj_matches_oracle(N, C, heads, K, I, tiles, waves, pair, dtype):
         ref = orc.fused_xattn(q16.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
         err = (a[2 * i:2 * i + 2].cpu().double() - ref).abs()
         assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
+    if C == 640 and N % 16 == 0:
+        # the locals-from-L2 kernel reads y in query-fragment order too: same values, same arithmetic, bit-identical result
+        assert ops.proj_qfrag_supported(C, heads, 77, K, N, I)
+        out_f = ops.xattn_forward_proj(ops.to_qfrag(y), ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I), mb, coef, scale, qfrag=True)
+        assert torch.equal(out_f, out)
 
 
 PAIR_SHAPES = [
@@ -761,13 +771,21 @@ def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
 
 
 def test_fwd_proj_rejects_what_it_cannot_hold():
-    """Level 1 of SD-v1 (C = 640: 100 KiB of Wq + 4 contexts of 30 KiB) does not fit one CU's LDS: the C-ABI says so
-    instead of launching, and the block then takes the GEMM + sta_xattn_fwd."""
+    """Level 2 of SD-v1 (C = 1280: 400 KiB of Wq per head) does not fit one CU's LDS, and level 1 (C = 640: 100 KiB of Wq + 4
+    contexts of 30 KiB) fits only with the local contexts left in L2 (STA_OPT_PROJ_LL2 = 2 refuses that variant): the C-ABI
+    says so instead of launching, and the block then takes the GEMM + sta_xattn_fwd."""
     from sta import lib, ops
-    assert not ops.proj_supported(640, 8, 77, 2)
+    assert ops.proj_supported(640, 8, 77, 2) and ops.proj_supported(640, 8, 77, 0)
+    assert not ops.proj_supported(1280, 8, 77, 2)
     assert not ops.proj_supported(320, 8, 77, 5)
     L = lib.load()
     y = torch.zeros(2, 64, 640, device="cuda", dtype=torch.float16)
-    rc = L.sta_xattn_fwd_proj(y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), 1, 64, 640, 8, 77, 2,
-                              1.0, lib.STA_F16, 0)
-    assert rc == -2 and "LDS" in lib.last_error()
+    lib.set_option(lib.OPT_PROJ_LL2, 2)
+    try:
+        assert not ops.proj_supported(640, 8, 77, 2)
+        rc = L.sta_xattn_fwd_proj(y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), y.data_ptr(), 1, 64, 640, 8, 77, 2,
+                                  1.0, lib.STA_F16, 0)
+        err = lib.last_error()
+    finally:
+        lib.set_option(lib.OPT_PROJ_LL2, 0)
+    assert rc == -2 and "LDS" in err

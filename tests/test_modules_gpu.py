@@ -828,7 +828,8 @@ def test_full_width_fixed_weight_unet_call_at_the_bench_batch_vs_fp32_oracle(mon
     full-width SD-v1 UNet (859.5 M parameters, synthetic weights) on 64 prompts (batch 128), fp16, NHWC trunk, no autograd — i.e.
     every sta.fused switch in its product state: the HIP 3x3 convolutions, row GEMMs, the in-place concatenation, GroupNorm
     statistics from the producers, the level-0 chain of private fragment layouts around the projection-fused head-pair kernel
-    (256 workgroups x 16 tiles), the LDS-resident kernel at levels 1 / 2 / mid, the HIP self-attention — against the SAME modules
+    (256 workgroups x 16 tiles), the locals-from-L2 projection-fused kernel at level 1, the LDS-resident kernel at levels 2 / mid,
+    the HIP self-attention — against the SAME modules
     with the same (fp16-rounded) weights in fp32 on the host cores with the ORACLE's fused op (tests.cpu_backend.oracle_ops: the
     combination the CPU suite pins to the reference's goldens), for images 0 and 63.  The reduced-width golden UNet (G4) cannot take
     the C = 320 chain or sta_conv; this is the full-width counterpart with G4's stated tolerance: max |eps - ref| <= 24 eps max |ref|,
@@ -855,9 +856,17 @@ def test_full_width_fixed_weight_unet_call_at_the_bench_batch_vs_fp32_oracle(mon
     real_conv = fused.conv3x3_nhwc
     monkeypatch.setattr(fused, "conv3x3_nhwc", lambda *a, **k: (launches.append("conv"), real_conv(*a, **k))[1])
     prompt_state.begin_prompt([c[2] for c in conds], first_timestep=981)
-    with torch.no_grad():
-        eps = model.apply_model_extra(pair(x, x), 0, t, c_in, coef=coef, bboxs_curr=[centres] * I).float().cpu()
+    from sta import ops
+    ops.LAUNCH_LOG = []
+    try:
+        with torch.no_grad():
+            eps = model.apply_model_extra(pair(x, x), 0, t, c_in, coef=coef, bboxs_curr=[centres] * I).float().cpu()
+        kinds = sorted((r[0], r[2], r[3]) for r in ops.LAUNCH_LOG)
+    finally:
+        ops.LAUNCH_LOG = None
     assert launches.count("conv") == 47                 # the fixed-weight trunk ran on csrc/sta_conv.hip
+    # the 16 cross-attention launches: to_q INSIDE the kernel at level 0 (head pairs) and level 1 (locals from L2), GEMM + LDS-resident kernel below
+    assert kinds == [("attn", 64, 1280)] + [("attn", 256, 1280)] * 5 + [("proj", 1024, 640)] * 5 + [("proj", 4096, 320)] * 5, kinds
     assert eps.shape == (2 * I, 4, 64, 64) and torch.isfinite(eps).all()
     sd = {k_: (v.detach().float().cpu().contiguous() if v.dtype.is_floating_point else v.detach().cpu()) for k_, v in model.state_dict().items()}
     xs, cs = x.float().cpu(), [(uc_.float().cpu(), c_.float().cpu(), [l.float().cpu() for l in loc_]) for uc_, c_, loc_ in conds]

@@ -27,8 +27,25 @@ def timed(fn, iters):
     return e0.elapsed_time(e1) * 1e3 / iters
 
 
+def timed_cold(fn, iters, scratch):
+    """Every call behind a 512 MiB fill (untimed): the operands of the call come from HBM, not from the 256 MiB Infinity Cache,
+    as they do inside a UNet call (profiles/r04_insitu_vs_warm.md). One event pair per call, raw times."""
+    for _ in range(2):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        scratch.add_(1)
+        e0.record()
+        fn()
+        e1.record()
+    torch.cuda.synchronize()
+    ts = sorted(e0.elapsed_time(e1) * 1e3 for e0, e1 in ev)
+    return ts[len(ts) // 2]
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cold", action="store_true", help="flush the caches before every call (median of per-call event pairs)")
     ap.add_argument("--N", type=int, default=4096)
     ap.add_argument("--C", type=int, default=320)
     ap.add_argument("--K", type=int, default=2)
@@ -38,7 +55,11 @@ def main():
     ap.add_argument("--dtype", default="fp16")
     ap.add_argument("--waves", type=int, nargs="*", default=[8])      # accepted for old command lines, unused
     ap.add_argument("--only", default=None, help="run only this arm (for rocprofv3): proj | gemm | attn")
+    ap.add_argument("--opt", nargs="*", default=[], help="library options for the whole run, e.g. OPT_PROJ_LL2=3")
     a = ap.parse_args()
+    for kv in a.opt:
+        k_, v_ = kv.split("=")
+        lib.set_option(getattr(lib, k_), int(v_))
     dt = torch.float16 if a.dtype == "fp16" else torch.bfloat16
     dev, heads, M, I, N, C, K = "cuda", 8, 77, a.imgs, a.N, a.C, a.K
     g = torch.Generator().manual_seed(0)
@@ -109,13 +130,14 @@ def main():
     if a.only:
         arms = {k_: f for k_, f in arms.items() if any(k_.startswith(o) for o in a.only.split(","))}
     res = {n: [] for n in arms}
+    scratch = torch.zeros(512 << 20, dtype=torch.uint8, device=dev) if a.cold else None
     for _ in range(a.rounds):
         for n, f in arms.items():
-            res[n].append(round(timed(f, a.iters), 2))
+            res[n].append(round(timed_cold(f, min(a.iters, 30), scratch) if a.cold else timed(f, a.iters), 2))
     f_attn = I * 4.0 * M * C * N * (K + 2)
     f_proj = I * 2.0 * 2 * N * C * C
     byts = I * (8.0 * N * C + 4.0 * (K + 2) * M * C + K * N) + 2.0 * C * C
-    out = {"N": N, "C": C, "K": K, "imgs": I, "dtype": a.dtype, "us": res, "attn_gflop": f_attn / 1e9, "proj_gflop": f_proj / 1e9, "mbytes": byts / 1e6}
+    out = {"N": N, "C": C, "K": K, "imgs": I, "dtype": a.dtype, "cold": bool(a.cold), "opt": a.opt, "us": res, "attn_gflop": f_attn / 1e9, "proj_gflop": f_proj / 1e9, "mbytes": byts / 1e6}
     for n, v_ in res.items():
         if n.startswith("proj") or n.startswith("pair"):
             us = min(v_)
