@@ -91,7 +91,101 @@ __device__ __forceinline__ void attend3n(KFr<T>& kf, const char* vb, const char*
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// MODE 0: the product's attend3 (NP = 1 only); 1: attend3n (MFMA clusters grouped across the NP pixel groups)
+// Both mandatory contexts of a head as TWO INTERLEAVED chains of one wave (they are independent: other q row, other K / V^T, other
+// output): the S^T MFMAs of context 1 are issued with the softmax of context 0 between them, the PV MFMAs of context 0 with the
+// softmax of context 1, the PV MFMAs of context 1 with the blend of context 0 — sched_group_barrier pins "one MFMA, then IL vector
+// instructions". Costs the second context's K operands (30 registers) and scores (20) live beside the first's.
+// kf holds K(ctx 0) on entry and K of the block behind `knb` / `kns` on exit.
+template <typename T, int IL>
+__device__ __forceinline__ void attend_pair_il(KFr<T>& kf, const char* blk, const int koffb, const int koffs, const int voffb, const int voffs,
+                                               const char* knb, const char* kns, const typename Tr<T>::V8& q0, const typename Tr<T>::V4& qs0,
+                                               const typename Tr<T>::V8& q1, const typename Tr<T>::V4& qs1, const f32x4 kb4, const float sl2e,
+                                               f32x4 (&au)[3], f32x4 (&ac)[3]) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  constexpr int M_MFMA = 0x8, M_VALU = 0x402;
+  KFr<T> kf1;
+  load_k<T>(kf1, blk + CTXB + koffb, blk + CTXB + koffs);
+  V8 v0b[3][2], v1b[3][2];
+  V4 v0s[3], v1s[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    v0b[u][0] = *(const V8*)(blk + voffb + u * 16 * VROW);
+    v0b[u][1] = *(const V8*)(blk + voffb + u * 16 * VROW + 64);
+    v0s[u] = *(const V4*)(blk + voffs + u * 16 * VROW);
+  }
+  f32x4 st0[NKT], st1[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = Tr<T>::mfma(kf.big[t], q0, acc);
+    st0[t] = M16<T>::mfma(kf.sm[t], qs0, acc);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---- S^T of context 1 with the softmax of context 0 between its MFMAs
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    st1[t] = Tr<T>::mfma(kf1.big[t], q1, acc);
+  }
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) st1[t] = M16<T>::mfma(kf1.sm[t], qs1, st1[t]);
+  softmax_biased(st0, sl2e, false);
+  const V8 p00 = cat8<T>(st0[0], st0[1]), p01 = cat8<T>(st0[2], st0[3]);
+  const V4 p02 = cvt4<T>(st0[4]);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    __builtin_amdgcn_sched_group_barrier(M_MFMA, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(M_VALU, IL, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    v1b[u][0] = *(const V8*)(blk + CTXB + voffb + u * 16 * VROW);
+    v1b[u][1] = *(const V8*)(blk + CTXB + voffb + u * 16 * VROW + 64);
+    v1s[u] = *(const V4*)(blk + CTXB + voffs + u * 16 * VROW);
+  }
+  // ---- PV of context 0 with the softmax of context 1 between its MFMAs
+  f32x4 o0[3], o1[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) o0[u] = Tr<T>::mfma(v0b[u][0], p00, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int u = 0; u < 3; ++u) o0[u] = Tr<T>::mfma(v0b[u][1], p01, o0[u]);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) o0[u] = M16<T>::mfma(v0s[u], p02, o0[u]);
+  softmax_biased(st1, sl2e, false);
+  const V8 p10 = cat8<T>(st1[0], st1[1]), p11 = cat8<T>(st1[2], st1[3]);
+  const V4 p12 = cvt4<T>(st1[4]);
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    __builtin_amdgcn_sched_group_barrier(M_MFMA, 1, 0);
+    __builtin_amdgcn_sched_group_barrier(M_VALU, IL + 1, 0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  load_k<T>(kf, knb, kns);
+  // ---- PV of context 1 with the blend of context 0 between its MFMAs
+#pragma unroll
+  for (int u = 0; u < 3; ++u) o1[u] = Tr<T>::mfma(v1b[u][0], p10, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+  for (int u = 0; u < 3; ++u) o1[u] = Tr<T>::mfma(v1b[u][1], p11, o1[u]);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) o1[u] = M16<T>::mfma(v1s[u], p12, o1[u]);
+  {
+    const float inv = bcast_row2(__builtin_amdgcn_rcpf(o0[2][0]));
+#pragma unroll
+    for (int u = 0; u < 3; ++u) au[u] = o0[u] * inv;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    const float inv = bcast_row2(__builtin_amdgcn_rcpf(o1[2][0]));
+#pragma unroll
+    for (int u = 0; u < 3; ++u) ac[u] = o1[u] * inv;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// MODE 0: the product's attend3 (NP = 1 only); 1: attend3n (MFMA clusters grouped across the NP pixel groups);
+// 2 / 3: attend_pair_il with 6 / 4 vector instructions behind every MFMA (NP = 1)
 template <typename T, int NP, int NWV, int MODE>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void chain_probe_kernel(const char* kvimg, const T* qsrc, unsigned* sink, int reps, float sl2e) {
   using V8 = typename Tr<T>::V8;
@@ -140,6 +234,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void chain_probe_kernel
       static_assert(MODE != 0 || NP == 1, "the product's attend3 takes one pixel group");
       attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0[0], qs0[0], kb4, sl2e, 0.f, au[0], ac[0]);
       attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, other + koffb, other + koffs, q1[0], qs1[0], kb4, sl2e, 0.f, au[0], ac[0]);
+    } else if constexpr (MODE >= 2) {
+      attend_pair_il<T, MODE == 2 ? 6 : 4>(kf, blk, koffb, koffs, voffb, voffs, other + koffb, other + koffs, q0[0], qs0[0], q1[0], qs1[0], kb4, sl2e, au[0], ac[0]);
     } else {
       attend3n<T, 0, NP>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sl2e, w, au, ac);
       attend3n<T, 1, NP>(kf, blk + CTXB + voffb, blk + CTXB + voffs, other + koffb, other + koffs, q1, qs1, kb4, sl2e, w, au, ac);
@@ -178,6 +274,9 @@ extern "C" int p3_chain_probe(const void* kv, const void* q, void* sink, int rep
     case 1: return bf16 ? launch_probe<__bf16, 1, 4, 0>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 4, 0>(kv, q, sink, reps, sl2e, st);
     case 2: return bf16 ? launch_probe<__bf16, 2, 4, 1>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 2, 4, 1>(kv, q, sink, reps, sl2e, st);
     case 3: return bf16 ? launch_probe<__bf16, 1, 8, 1>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 8, 1>(kv, q, sink, reps, sl2e, st);
+    case 5: return bf16 ? launch_probe<__bf16, 1, 8, 2>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 8, 2>(kv, q, sink, reps, sl2e, st);
+    case 6: return bf16 ? launch_probe<__bf16, 1, 8, 3>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 8, 3>(kv, q, sink, reps, sl2e, st);
+    case 7: return bf16 ? launch_probe<__bf16, 1, 4, 2>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 4, 2>(kv, q, sink, reps, sl2e, st);
     case 4: return bf16 ? launch_probe<__bf16, 2, 8, 1>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 2, 8, 1>(kv, q, sink, reps, sl2e, st);
   }
   return -1;

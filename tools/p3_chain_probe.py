@@ -43,13 +43,16 @@ def main():
     sl2e = 40 ** -0.5 * 1.4426950408889634
     names = {0: "1 group x 8 waves (product: two waves per SIMD)", 1: "1 group x 4 waves (one wave per SIMD)",
              2: "2 groups x 4 waves (one wave per SIMD, two chains per wave)", 3: "1 group x 8 waves, grouped-MFMA code path",
-             4: "2 groups x 8 waves (two waves per SIMD, two chains per wave)"}
+             4: "2 groups x 8 waves (two waves per SIMD, two chains per wave)",
+             5: "1 group x 8 waves, the two mandatory contexts as interleaved chains (6 vector instructions behind every MFMA)",
+             6: "1 group x 8 waves, interleaved chains (4 behind every MFMA)",
+             7: "1 group x 4 waves (one wave per SIMD), interleaved chains (6 behind every MFMA)"}
     # context-heads per SIMD and launch: waves per SIMD x groups x 4 x reps
-    per_simd = {0: 2 * 1 * 4, 1: 1 * 1 * 4, 2: 1 * 2 * 4, 3: 2 * 1 * 4, 4: 2 * 2 * 4}
+    per_simd = {0: 2 * 1 * 4, 1: 1 * 1 * 4, 2: 1 * 2 * 4, 3: 2 * 1 * 4, 4: 2 * 2 * 4, 5: 2 * 1 * 4, 6: 2 * 1 * 4, 7: 1 * 1 * 4}
     st = torch.cuda.current_stream().cuda_stream
     res = {}
     for rnd in range(3):
-        for v in (0, 1, 2, 3, 4):
+        for v in sorted(per_simd):
             for _ in range(2):
                 assert L.p3_chain_probe(kv.data_ptr(), q.data_ptr(), sink.data_ptr(), a.reps, sl2e, v, int(dt == torch.bfloat16), st) == 0
             torch.cuda.synchronize()
