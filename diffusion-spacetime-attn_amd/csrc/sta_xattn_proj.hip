@@ -28,6 +28,10 @@
 
 namespace {
 
+#ifndef STA_PROJ_ABLATE
+#define STA_PROJ_ABLATE 0   // timing experiments only (tools/asm_patch_ab.py flag:-DSTA_PROJ_ABLATE=bits; wrong results): 1 no output stores,
+#endif                      // 2 no y refills in the loop, 4 no attention, 8 no projection MFMAs, 16 no local contexts, 32 no Wq fragment reads
+
 constexpr int RING_MIN = 5;   // k-steps (32 channels each) of y per ring refill; C % (32 * RING_MIN) == 0
 
 // to_q.weight [C][C] (row = output channel h*d + dd, col = input channel) -> per head [s][u] fragments:
@@ -209,18 +213,24 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
         const int s = s0 + j;
         V8 a[NDT];
 #pragma unroll
-        for (int u = 0; u < NDT; ++u) a[u] = wf[(s * NDT + u) * 64];
+        for (int u = 0; u < NDT; ++u) a[u] = wf[((STA_PROJ_ABLATE & 32 ? 0 : s) * NDT + u) * 64];
 #pragma unroll
         for (int u = 0; u < NDT; ++u) {
+#if STA_PROJ_ABLATE & 8
+          asm volatile("" : "+v"(qa0[u]), "+v"(qa1[u]) : "v"(a[u]), "v"(yr0[j]), "v"(yr1[j]));
+#else
           qa0[u] = Tr<T>::mfma(a[u], yr0[j], qa0[u]);
           qa1[u] = Tr<T>::mfma(a[u], yr1[j], qa1[u]);
+#endif
         }
         // refill this slot with step s + RING: of this tile, or of the next one (zeros past the last tile)
         const bool wrap = s + RING >= nkc;        // scalar
         const unsigned vo = wrap ? voffn : voff;
         const unsigned so = YSTEP * (unsigned)(wrap ? s + RING - nkc : s + RING);
+#if !(STA_PROJ_ABLATE & 2)
         yr0[j] = srd_load16<V8>(y_srd, vo, so);
         yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+#endif
       }
     }
     if (it == 1) STA_T(3);
@@ -243,12 +253,17 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
     // ---- attention + blend -------------------------------------------------------------------------------
     f32x4 au[1][NDT], ac[1][NDT];
     float w[1] = {0.f};
+#if STA_PROJ_ABLATE & 4
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) { au[0][u] = qa0[u]; ac[0][u] = qa1[u]; }
+    asm volatile("" :: "v"(q0[0][0]), "v"(q1[0][0]));
+#else
     attend_staged<T, NDT, 1, 0>((const V8*)lds_ctx + lane, q0, kb4, sl2e, w, au, ac, sumrow);
     if (it == 1) STA_T(4);
     attend_staged<T, NDT, 1, 1>((const V8*)(lds_ctx + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
     if (it == 1) STA_T(5);
     const unsigned mbits = valid ? (mb & kmask) : 0u;
-    for (int i = 0; i < K; ++i) {
+    for (int i = 0; i < ((STA_PROJ_ABLATE & 16) ? 0 : K); ++i) {
       if (!__ballot((mbits >> i) & 1u)) continue;  // none of this wave's pixels inside disc i
       const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
       w[0] = ((mbits >> i) & 1u) ? cw : 0.f;
@@ -259,8 +274,13 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
         attend_staged<T, NDT, 1, 2>((const V8*)(lds_ctx + (size_t)(2 + i) * CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
       }
     }
+#endif
     if (it == 1) STA_T(6);
-    if (valid) {
+#if STA_PROJ_ABLATE & 1
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) asm volatile("" :: "v"(au[0][u]), "v"(ac[0][u]));      // the results stay alive without their stores
+#endif
+    if (valid && !(STA_PROJ_ABLATE & 1)) {
       T* obase = ob + (size_t)px_own * C + h * d;
       store_row16<T, NDT>(obase, au[0], g, d);
       store_row16<T, NDT>(obase + (size_t)N * C, ac[0], g, d);
