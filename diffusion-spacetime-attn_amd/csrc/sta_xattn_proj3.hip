@@ -183,15 +183,103 @@ __device__ __forceinline__ typename Tr<T>::V4 cvt4(const f32x4& a) {
   return r;
 }
 
+// The OPTIMISTIC softmax of the bf16 instantiations (profiles/r05_level0.md: a SIMD's matrix and vector cycles add up in this kernel, and
+// 54 of a context's 175 ns of vector work are the running maximum — 9 v_max3, the row butterfly — and the scale-and-subtract FMAs).
+// A bf16 P operand has fp32's exponent range, so P = exp2(S) needs no maximum as long as the denominator (the ones row of V^T, summed
+// by the PV MFMAs in fp32) stays inside [2^-100, 2^100): |logit| < ~65. The scores arrive in log2 units (scale * log2 e is folded into q where
+// the projection's accumulators are rounded). The denominator's range is checked per context — outside it in any
+// lane sends the WAVE through the standard path for that context (K and V^T operands re-read from LDS: exact for any input,
+// tests/test_kernel_gpu.py::test_fwd_proj_pair_bf16_extreme_logits). fp16 keeps the maximum: its P overflows at 2^16.
+#ifndef STA_P3_OPTIMISTIC
+#define STA_P3_OPTIMISTIC 1      // 0: the standard softmax in both types (same-box A/B builds: tools/asm_patch_ab.py flag:-DSTA_P3_OPTIMISTIC=0)
+#endif
+template <typename T> constexpr bool kOptimistic = STA_P3_OPTIMISTIC && std::is_same<T, __bf16>::value;
+
 // One context of one head. kf holds its K operands on entry (requested a context earlier) and the NEXT context's on
-// exit (`knb`, `kns`: that block's per-lane K addresses). vb / vs: this context's per-lane V^T addresses.
+// exit (`knb`, `kns`: that block's per-lane K addresses). vb / vs: this context's per-lane V^T addresses; kcb / kcs: its K
+// addresses (the optimistic path's fall-back re-reads them).
 // KIND 0: "" on the uncond row -> au;  1: global prompt on the cond row -> ac;  2: local prompt, ac += w (A - au).
+// `sl2e`: scale * log2 e, or 1 where the scores already are in log2 units (kOptimistic).
 template <typename T, int KIND>
 __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* vs, const char* knb, const char* kns,
                                         const typename Tr<T>::V8& qbig, const typename Tr<T>::V4& qsm, const f32x4 kb4,
-                                        const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3]) {
+                                        const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3],
+                                        const char* kcb = nullptr, const char* kcs = nullptr) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
+  if constexpr (kOptimistic<T>) {
+    V8 vbig[3][2];
+    V4 vsm[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      vbig[u][0] = *(const V8*)(vb + u * 16 * VROW);
+      vbig[u][1] = *(const V8*)(vb + u * 16 * VROW + 64);
+      vsm[u] = *(const V4*)(vs + u * 16 * VROW);
+    }
+    // the k = 32 steps of all tiles first, then the k = 16 steps: four other MFMAs between a tile's two shapes (no mixed-shape hazard,
+    // nothing for sta/isa_lint.py to pad)
+    f32x4 st[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) st[t] = Tr<T>::mfma(kf.big[t], qbig, (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) st[t] = M16<T>::mfma(kf.sm[t], qsm, st[t]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(st[t][r]);
+    const V8 p0 = cat8<T>(st[0], st[1]), p1 = cat8<T>(st[2], st[3]);
+    const V4 p2 = cvt4<T>(st[4]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_k<T>(kf, knb, kns);
+    f32x4 o[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) o[u] = Tr<T>::mfma(vbig[u][0], p0, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+    for (int u = 0; u < 3; ++u) o[u] = Tr<T>::mfma(vbig[u][1], p1, o[u]);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) o[u] = M16<T>::mfma(vsm[u], p2, o[u]);
+    // the denominator sits in lane row 2 (lanes 32..47): anything outside [2^-100, 2^100) there -> the standard path. Tested on the
+    // BITS (this file is compiled with -ffinite-math-only: a floating-point class test of inf / NaN would be folded away): one unsigned
+    // compare rejects negatives, zeros, denormals, infinities and NaNs as well; the margin of 2^27 to either end of the fp32 range keeps the
+    // other rows of O^T (sums of P * v) finite whenever the ones row passes.
+    const bool row2 = (threadIdx.x & 48) == 32;
+    const bool bad = row2 && (__float_as_uint(o[2][0]) - 0x0D800000u) >= (0x71800000u - 0x0D800000u);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+      load_k<T>(kf, kcb, kcs);                      // kf doubles as the buffer: the next context's operands are requested again below
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        vbig[u][0] = *(const V8*)(vb + u * 16 * VROW);
+        vbig[u][1] = *(const V8*)(vb + u * 16 * VROW + 64);
+        vsm[u] = *(const V4*)(vs + u * 16 * VROW);
+      }
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) st[t] = Tr<T>::mfma(kf.big[t], qbig, (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) st[t] = M16<T>::mfma(kf.sm[t], qsm, st[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_k<T>(kf, knb, kns);
+      softmax_biased(st, 1.0f, false);
+      const V8 r0 = cat8<T>(st[0], st[1]), r1 = cat8<T>(st[2], st[3]);
+      const V4 r2 = cvt4<T>(st[4]);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) o[u] = Tr<T>::mfma(vbig[u][0], r0, f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int u = 0; u < 3; ++u) o[u] = Tr<T>::mfma(vbig[u][1], r1, o[u]);
+#pragma unroll
+      for (int u = 0; u < 3; ++u) o[u] = M16<T>::mfma(vsm[u], r2, o[u]);
+    }
+    const float inv = bcast_row2(__builtin_amdgcn_rcpf(o[2][0]));
+    const float wi = w * inv;
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      if (KIND == 0) au[u] = o[u] * inv;
+      else if (KIND == 1) ac[u] = o[u] * inv;
+      else ac[u] = o[u] * wi + (ac[u] - au[u] * w);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    return;
+  }
   // V^T operands first: they land under the S^T MFMAs and the softmax
   V8 vbig[3][2];
   V4 vsm[3];
@@ -443,6 +531,14 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
 
     // accumulators -> S^T B operands (rounded to T once). Head A: tiles 0 | 1 (+ tile 2 rows g < 2), head B: tiles 3 | 4
     // (+ tile 2 rows g >= 2); the small operand (tile 2) serves both heads, the K images carry the zeros.
+    if constexpr (kOptimistic<T>) {      // scores in log2 units: scale * log2 e goes into q where the accumulators are rounded
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        qa0[u] = qa0[u] * sl2e;
+        qa1[u] = qa1[u] * sl2e;
+      }
+    }
+    const float sm_scale = kOptimistic<T> ? 1.0f : sl2e;
     const V8 qA0 = cat8<T>(qa0[0], qa0[1]), qA1 = cat8<T>(qa1[0], qa1[1]);
     const V8 qB0 = cat8<T>(qa0[3], qa0[4]), qB1 = cat8<T>(qa1[3], qa1[4]);
     const V4 qs0 = cvt4<T>(qa0[2]), qs1 = cvt4<T>(qa1[2]);
@@ -461,10 +557,10 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const unsigned rest = wneed >> first_local;
         return rest ? blk + (size_t)(2 + first_local + __builtin_ctz(rest)) * CTXB : other;
       };
-      attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sl2e, 0.f, au, ac);
+      attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sm_scale, 0.f, au, ac, blk + koffb, blk + koffs);
       {
         const char* nx = next_of(0);
-        attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sl2e, 0.f, au, ac);
+        attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, 0.f, au, ac, blk + CTXB + koffb, blk + CTXB + koffs);
       }
       for (int i = 0; i < K; ++i) {
         if (!((wneed >> i) & 1u)) continue;
@@ -472,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const float w = ((mbits >> i) & 1u) ? cw : 0.f;
         const char* cb = blk + (size_t)(2 + i) * CTXB;
         const char* nx = next_of(i + 1);
-        attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sl2e, w, au, ac);
+        attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, w, au, ac, cb + koffb, cb + koffs);
       }
       ou = pack_out<T>(au);
       oc = pack_out<T>(ac);

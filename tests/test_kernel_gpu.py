@@ -770,6 +770,64 @@ def test_fwd_proj_pair_matches_oracle(N, C, heads, K, I, tiles, M, dtype):
             assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
 
 
+@pytest.mark.parametrize("mode", ["overflow", "underflow", "one_image"])
+def test_fwd_proj_pair_bf16_extreme_logits(mode):
+    """The bf16 head-pair kernel's OPTIMISTIC softmax (P = exp2(S) without the running maximum; csrc/sta_xattn_proj3.hip::attend3) and its
+    guard: where a context's denominator is not a normal number the wave repeats that context on the standard path.  overflow: keys x 300
+    => |logit| in the hundreds, exp2 overflows in every wave;  underflow: all-positive queries against all-negative keys => every
+    P = 0, the denominator is zero;  one_image: only the second image of the launch is extreme (the first must still match the oracle at
+    the usual 4 eps).  With logits this large a 2^-9 relative rounding difference in q moves a logit by several tenths, so against the
+    fp64 oracle (fed q = round16(y Wq^T), as everywhere) the extreme images are held to: finite everywhere, bit-identical across the three
+    layouts, and inside the ordinary 4 eps of the oracle fed the q the kernel rounds (see below)."""
+    from sta import lib, ops
+    dev, dtype, N, C, heads, K, I = "cuda", torch.bfloat16, 1024, 320, 8, 2, 2
+    g = torch.Generator().manual_seed(5)
+    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype)
+    cases = [list(_case(N, C, heads, K, dtype, seed=90 + i)) for i in range(I)]
+    extreme = [1] if mode == "one_image" else [0, 1]
+    if mode == "underflow":
+        wq = wq.abs()
+    for i in extreme:
+        if mode == "underflow":
+            cases[i][0] = (cases[i][0].float().abs() + 0.5).to(dtype)         # y > 0, Wq > 0  =>  q > 0
+            cases[i][1] = (-(cases[i][1].float().abs() + 0.5) * 8.0).to(dtype)  # k < 0: logits around -500 ... -1500
+        else:
+            cases[i][1] = (cases[i][1].float() * 300.0).to(dtype)
+    y = torch.cat([c[0] for c in cases]).to(dev)
+    k = torch.cat([c[1] for c in cases]).to(dev)
+    v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    scale = (C // heads) ** -0.5
+    lib.set_option(lib.OPT_PROJ_PAIR, 1)
+    try:
+        wqf, kvp = ops.pack_wq(wq.to(dev), heads), ops.pack_kv_proj(k, v, heads, n_img=I)
+        out = ops.xattn_forward_proj(y, wqf, kvp, mb, coef, scale)
+        out_q = ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True)
+        out_o = ops.from_ofrag(ops.xattn_forward_proj(ops.to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True))
+    finally:
+        lib.set_option(lib.OPT_PROJ_PAIR, 0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out_q, out) and torch.equal(out_o, out)
+    eps = 2.0 ** -8
+    sl2e = scale * 1.4426950408889634
+    for i in range(I):
+        yi, ki, vi, mi, ci = cases[i]
+        q64 = yi.double() @ wq.double().t()
+        ref = orc.fused_xattn(q64.to(dtype).double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
+        frac = lambda r: ((out[2 * i:2 * i + 2].float().cpu().double() - r).abs() <= 4 * eps * (1.0 + r.abs())).double().mean().item()
+        if i in extreme:
+            # the kernel rounds q * scale * log2(e) to bf16 (scores in log2 units), the oracle's usual input is round16(q): at logits in the
+            # hundreds that 2^-9 relative difference moves a logit by several tenths and flips near-tie pixels (the reference's own bf16
+            # logits carry the same relative error). Held to 4 eps against the oracle fed the q the kernel uses; the usual input: printed
+            ref_k = orc.fused_xattn((q64 * sl2e).to(dtype).double() / sl2e, ki.double(), vi.double(), mi, ci.double(), heads, scale)
+            print("%s, image %d: inside 4 eps of the oracle fed q rounded in log2 units %.4f, fed round16(q) %.4f" % (mode, i, frac(ref_k), frac(ref)))
+            assert frac(ref_k) > 0.995, (i, frac(ref_k), frac(ref))
+        else:
+            assert frac(ref) == 1.0, (i, frac(ref))
+
+
 def test_fwd_proj_rejects_what_it_cannot_hold():
     """Level 2 of SD-v1 (C = 1280: 400 KiB of Wq per head) does not fit one CU's LDS, and level 1 (C = 640: 100 KiB of Wq + 4
     contexts of 30 KiB) fits only with the local contexts left in L2 (STA_OPT_PROJ_LL2 = 2 refuses that variant): the C-ABI

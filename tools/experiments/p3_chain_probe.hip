@@ -184,7 +184,61 @@ __device__ __forceinline__ void attend_pair_il(KFr<T>& kf, const char* blk, cons
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// MODE 0: the product's attend3 (NP = 1 only); 1: attend3n (MFMA clusters grouped across the NP pixel groups);
+// The optimistic softmax: scores arrive in log2 units (the caller folded scale * log2 e into q), P = exp2(S) WITHOUT the running maximum —
+// no v_max3 chain, no row butterfly, no scale-and-subtract FMAs. Exact whenever the denominator stays a normal fp32 number, which the
+// 8-bit exponent of bf16 P operands allows for |logit| < ~80; GUARD: the denominator's class is checked (zero / denormal / inf / NaN) and a
+// wave-uniform branch would take the standard path (here: only the check and a dummy branch, for timing).
+template <typename T, bool GUARD>
+__device__ __forceinline__ void attend3_nomax(KFr<T>& kf, const char* vb, const char* vs, const char* knb, const char* kns,
+                                              const typename Tr<T>::V8& qbig, const typename Tr<T>::V4& qsm, const f32x4 kb4, f32x4 (&a)[3], unsigned* flag) {
+  using V8 = typename Tr<T>::V8;
+  using V4 = typename Tr<T>::V4;
+  V8 vbig[3][2];
+  V4 vsm[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    vbig[u][0] = *(const V8*)(vb + u * 16 * VROW);
+    vbig[u][1] = *(const V8*)(vb + u * 16 * VROW + 64);
+    vsm[u] = *(const V4*)(vs + u * 16 * VROW);
+  }
+  f32x4 st[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+    acc = Tr<T>::mfma(kf.big[t], qbig, acc);
+    acc = M16<T>::mfma(kf.sm[t], qsm, acc);
+    st[t] = acc;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[t][r] = __builtin_amdgcn_exp2f(st[t][r]);
+  const V8 p0 = cat8<T>(st[0], st[1]), p1 = cat8<T>(st[2], st[3]);
+  const V4 p2 = cvt4<T>(st[4]);
+  __builtin_amdgcn_sched_barrier(0);
+  load_k<T>(kf, knb, kns);
+  f32x4 o[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = Tr<T>::mfma(vbig[u][0], p0, acc);
+    acc = Tr<T>::mfma(vbig[u][1], p1, acc);
+    acc = M16<T>::mfma(vsm[u], p2, acc);
+    o[u] = acc;
+  }
+  if constexpr (GUARD) {
+    // lane row 2 holds the denominator: anything but a normal positive number sends the WAVE down the standard path
+    const bool bad = __builtin_isfpclass(o[2][0], 0x3ff & ~0x100) && (threadIdx.x & 63) >= 32 && (threadIdx.x & 63) < 48;
+    if (__builtin_amdgcn_ballot_w64(bad)) atomicAdd(flag, 1u);
+  }
+  const float inv = bcast_row2(__builtin_amdgcn_rcpf(o[2][0]));
+#pragma unroll
+  for (int u = 0; u < 3; ++u) a[u] = o[u] * inv;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// MODE 0: the product's attend3 (NP = 1 only); 1: attend3n (MFMA clusters grouped across the NP pixel groups); 4 / 5: attend3_nomax without / with guard;
 // 2 / 3: attend_pair_il with 6 / 4 vector instructions behind every MFMA (NP = 1)
 template <typename T, int NP, int NWV, int MODE>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void chain_probe_kernel(const char* kvimg, const T* qsrc, unsigned* sink, int reps, float sl2e) {
@@ -234,6 +288,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void chain_probe_kernel
       static_assert(MODE != 0 || NP == 1, "the product's attend3 takes one pixel group");
       attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0[0], qs0[0], kb4, sl2e, 0.f, au[0], ac[0]);
       attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, other + koffb, other + koffs, q1[0], qs1[0], kb4, sl2e, 0.f, au[0], ac[0]);
+    } else if constexpr (MODE >= 4) {
+      attend3_nomax<T, MODE == 5>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0[0], qs0[0], kb4, au[0], sink);
+      attend3_nomax<T, MODE == 5>(kf, blk + CTXB + voffb, blk + CTXB + voffs, other + koffb, other + koffs, q1[0], qs1[0], kb4, ac[0], sink);
     } else if constexpr (MODE >= 2) {
       attend_pair_il<T, MODE == 2 ? 6 : 4>(kf, blk, koffb, koffs, voffb, voffs, other + koffb, other + koffs, q0[0], qs0[0], q1[0], qs1[0], kb4, sl2e, au[0], ac[0]);
     } else {
@@ -277,6 +334,8 @@ extern "C" int p3_chain_probe(const void* kv, const void* q, void* sink, int rep
     case 5: return bf16 ? launch_probe<__bf16, 1, 8, 2>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 8, 2>(kv, q, sink, reps, sl2e, st);
     case 6: return bf16 ? launch_probe<__bf16, 1, 8, 3>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 8, 3>(kv, q, sink, reps, sl2e, st);
     case 7: return bf16 ? launch_probe<__bf16, 1, 4, 2>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 4, 2>(kv, q, sink, reps, sl2e, st);
+    case 8: return bf16 ? launch_probe<__bf16, 1, 8, 4>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 8, 4>(kv, q, sink, reps, sl2e, st);
+    case 9: return bf16 ? launch_probe<__bf16, 1, 8, 5>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 1, 8, 5>(kv, q, sink, reps, sl2e, st);
     case 4: return bf16 ? launch_probe<__bf16, 2, 8, 1>(kv, q, sink, reps, sl2e, st) : launch_probe<_Float16, 2, 8, 1>(kv, q, sink, reps, sl2e, st);
   }
   return -1;

@@ -46,9 +46,11 @@ def main():
              4: "2 groups x 8 waves (two waves per SIMD, two chains per wave)",
              5: "1 group x 8 waves, the two mandatory contexts as interleaved chains (6 vector instructions behind every MFMA)",
              6: "1 group x 8 waves, interleaved chains (4 behind every MFMA)",
-             7: "1 group x 4 waves (one wave per SIMD), interleaved chains (6 behind every MFMA)"}
+             7: "1 group x 4 waves (one wave per SIMD), interleaved chains (6 behind every MFMA)",
+             8: "1 group x 8 waves, optimistic softmax: no running maximum, scores in log2 units",
+             9: "1 group x 8 waves, optimistic softmax + the denominator-class guard"}
     # context-heads per SIMD and launch: waves per SIMD x groups x 4 x reps
-    per_simd = {0: 2 * 1 * 4, 1: 1 * 1 * 4, 2: 1 * 2 * 4, 3: 2 * 1 * 4, 4: 2 * 2 * 4, 5: 2 * 1 * 4, 6: 2 * 1 * 4, 7: 1 * 1 * 4}
+    per_simd = {0: 2 * 1 * 4, 1: 1 * 1 * 4, 2: 1 * 2 * 4, 3: 2 * 1 * 4, 4: 2 * 2 * 4, 5: 2 * 1 * 4, 6: 2 * 1 * 4, 7: 1 * 1 * 4, 8: 2 * 1 * 4, 9: 2 * 1 * 4}
     st = torch.cuda.current_stream().cuda_stream
     res = {}
     for rnd in range(3):
