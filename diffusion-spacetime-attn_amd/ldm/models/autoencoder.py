@@ -32,12 +32,13 @@ class ResnetBlock(nn.Module):
         if in_channels != out_channels:
             self.nin_shortcut = nn.Conv2d(in_channels, out_channels, 1)
 
-    def forward(self, x):
+    def forward(self, x, gn_next=True):
+        """`gn_next=False`: the result feeds an Upsample convolution, not a GroupNorm — its producer keeps no statistics."""
         if _fused.conv3x3_supported(x, self.conv1.weight):
             # fixed-weight decode on an NHWC decoder: both convolutions on csrc/sta_conv.hip, the shortcut add in the second one's epilogue
             h = _fused.conv3x3_module(self, self.conv1, _norm_silu(self.norm1, x), bias=self.conv1.bias)
             skip = self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x
-            return _fused.conv3x3_module(self, self.conv2, _norm_silu(self.norm2, h), bias=self.conv2.bias, res=skip)
+            return _fused.conv3x3_module(self, self.conv2, _norm_silu(self.norm2, h), bias=self.conv2.bias, res=skip, stats=gn_next)
         h = self.conv1(_norm_silu(self.norm1, x))
         h = self.conv2(_norm_silu(self.norm2, h))
         return (self.nin_shortcut(x) if hasattr(self, "nin_shortcut") else x) + h
@@ -135,8 +136,8 @@ class Decoder(nn.Module):
         h = self.mid.block_2(self.mid.attn_1(self.mid.block_1(h)))
         for i_level in reversed(range(self.num_resolutions)):
             lvl = self.up[i_level]
-            for blk in lvl.block:
-                h = blk(h)
+            for j, blk in enumerate(lvl.block):
+                h = blk(h, gn_next=not (i_level != 0 and j == len(lvl.block) - 1))      # the level's last block feeds the Upsample convolution
             if i_level != 0:
                 h = lvl.upsample(h)
         return self.conv_out(_norm_silu(self.norm_out, h))

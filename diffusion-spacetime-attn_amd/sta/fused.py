@@ -345,11 +345,14 @@ def packed_conv_weight(owner, conv):
     return hit[1]
 
 
-def conv3x3_module(owner, conv, x, bias=None, res=None, up2=False):
+def conv3x3_module(owner, conv, x, bias=None, res=None, up2=False, stats=True):
     """conv(x) (+ bias + res) for a 3x3 nn.Conv2d outside autograd: the HIP convolution where it applies, the library convolution
-    (+ the fused bias / residual pass) elsewhere. `bias=None` means bias-free (the caller folds conv.bias into a later pass)."""
+    (+ the fused bias / residual pass) elsewhere. `bias=None` means bias-free (the caller folds conv.bias into a later pass).
+    `stats=False`: the result is not read by a GroupNorm next (e.g. it feeds an Upsample convolution) — no epilogue statistics, no
+    partial buffer, no finalize launch."""
     if conv3x3_supported(x, conv.weight, up2=up2) and (res is None or is_nhwc(res)):
-        return conv3x3_nhwc(x, packed_conv_weight(owner, conv), conv.weight.shape[0], up2=up2, bias=bias, res=res, stats=GN_STATS_FROM_PRODUCER)
+        return conv3x3_nhwc(x, packed_conv_weight(owner, conv), conv.weight.shape[0], up2=up2, bias=bias, res=res,
+                            stats=GN_STATS_FROM_PRODUCER and stats)
     if up2:
         x = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest")
     h = torch.nn.functional.conv2d(x, conv.weight, None, conv.stride, conv.padding)

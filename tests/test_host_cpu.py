@@ -486,6 +486,37 @@ def test_trunk_kernel_host_entry_points():
     assert fused.CONV3X3 and fused.LINEAR_ROWS and fused.CAT_IN_PLACE and fused.GN_STATS_FROM_PRODUCER and fused.CONV_MIN_ITEMS == 64
 
 
+def test_projection_fused_forward_lds_plan():
+    """Host-only rules of sta_xattn_fwd_proj (csrc/sta_xattn_proj.hip): which shapes keep every context resident in the CU's 160 KiB, which
+    keep the Wq slice + the two mandatory contexts and read the local contexts from L2 (SD-v1 level 1), which are refused; and what the model
+    asks (launch size, the PROJ_LL2_IN_MODEL switch). No GPU work."""
+    from sta import lib, ops
+    L = lib.load()
+    S, LL2 = L.sta_xattn_fwd_proj_supported, L.sta_xattn_fwd_proj_locals_from_l2
+    assert S(320, 8, 77, 2) and not LL2(320, 8, 77, 2)            # level 0: 30 KiB of Wq + 4 x 19 KiB
+    assert S(320, 8, 77, 4) and not S(320, 8, 77, 5)              # 6 contexts fit, 7 do not
+    assert S(640, 8, 77, 0) and not LL2(640, 8, 77, 0)            # level 1 without objects: 100 + 2 x 30 KiB = the whole LDS
+    assert S(640, 8, 77, 2) and LL2(640, 8, 77, 2) and LL2(640, 8, 77, 4)
+    assert not S(1280, 8, 77, 2) and not LL2(1280, 8, 77, 2)      # level 2: 400 KiB of Wq per head
+    assert not S(640, 8, 64, 2)                                   # M <= 64 keys: refused by every forward of this family
+    lib.set_option(lib.OPT_PROJ_LL2, 2)
+    try:
+        assert not S(640, 8, 77, 2) and not LL2(640, 8, 77, 2) and S(320, 8, 77, 2)
+    finally:
+        lib.set_option(lib.OPT_PROJ_LL2, 0)
+    assert L.sta_xattn_fwd_proj_qfrag_supported(4, 1024, 640, 8, 77, 2) and not L.sta_xattn_fwd_proj_qfrag_supported(4, 1000, 640, 8, 77, 2)
+    # the model's question: enough workgroups to fill the chip, and the switch
+    assert ops.PROJ_LL2_IN_MODEL
+    assert ops.proj_supported(640, 8, 77, 2, N=1024, n_img=64) and ops.proj_supported(640, 8, 77, 2, N=1024, n_img=4)
+    assert not ops.proj_supported(640, 8, 77, 2, N=1024, n_img=3)                 # 192 workgroups
+    ops.PROJ_LL2_IN_MODEL = False
+    try:
+        assert not ops.proj_supported(640, 8, 77, 2, N=1024, n_img=64) and ops.proj_supported(640, 8, 77, 2)
+        assert ops.proj_supported(320, 8, 77, 2, N=4096, n_img=64)
+    finally:
+        ops.PROJ_LL2_IN_MODEL = True
+
+
 def test_fused_row_passes_are_gated_by_what_a_launch_addresses():
     """the fragment-order chain of level 0 refuses rows * width * 2 >= 4 GiB inside the C-ABI, where no row-major fallback
     is left; the Python gate in front of the chain must say no first (205 prompts per step at 512^2 for the [rows, 1280] GEGLU output)."""
