@@ -177,10 +177,12 @@ __device__ __forceinline__ typename Tr<T>::V8 cat8(const f32x4& lo, const f32x4&
 }
 template <typename T>
 __device__ __forceinline__ typename Tr<T>::V4 cvt4(const f32x4& a) {
-  typename Tr<T>::V4 r;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) r[j] = (T)a[j];
-  return r;
+  // two PAIR conversions: written element by element hipcc 7.2 emits, for bf16, four single v_cvt_pk_bf16_f32 + two v_perm_b32
+  typedef __attribute__((ext_vector_type(2))) float F2;
+  typedef __attribute__((ext_vector_type(2))) T T2;
+  typedef __attribute__((ext_vector_type(2))) unsigned U2;
+  const T2 lo = __builtin_convertvector(F2{a[0], a[1]}, T2), hi = __builtin_convertvector(F2{a[2], a[3]}, T2);
+  return __builtin_bit_cast(typename Tr<T>::V4, U2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
 }
 
 // The OPTIMISTIC softmax of the bf16 instantiations (profiles/r05_level0.md: a SIMD's matrix and vector cycles add up in this kernel, and
@@ -221,6 +223,7 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     f32x4 st[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) st[t] = Tr<T>::mfma(kf.big[t], qbig, (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f});
+    __builtin_amdgcn_sched_barrier(0);               // hipcc otherwise moves a tile's k = 16 step right behind its k = 32 step again
 #pragma unroll
     for (int t = 0; t < NKT; ++t) st[t] = M16<T>::mfma(kf.sm[t], qsm, st[t]);
     __builtin_amdgcn_sched_barrier(0);
@@ -237,6 +240,7 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     for (int u = 0; u < 3; ++u) o[u] = Tr<T>::mfma(vbig[u][0], p0, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
     for (int u = 0; u < 3; ++u) o[u] = Tr<T>::mfma(vbig[u][1], p1, o[u]);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 3; ++u) o[u] = M16<T>::mfma(vsm[u], p2, o[u]);
     // the denominator sits in lane row 2 (lanes 32..47): anything outside [2^-100, 2^100) there -> the standard path. Tested on the
