@@ -188,8 +188,8 @@ __device__ __forceinline__ typename Tr<T>::V4 cvt4(const f32x4& a) {
 // The OPTIMISTIC softmax of the bf16 instantiations (profiles/r05_level0.md: a SIMD's matrix and vector cycles add up in this kernel, and
 // 54 of a context's 175 ns of vector work are the running maximum — 9 v_max3, the row butterfly — and the scale-and-subtract FMAs).
 // A bf16 P operand has fp32's exponent range, so P = exp2(S) needs no maximum as long as the denominator (the ones row of V^T, summed
-// by the PV MFMAs in fp32) stays inside [2^-100, 2^100): |logit| < ~65. The scores arrive in log2 units (scale * log2 e is folded into q where
-// the projection's accumulators are rounded). The denominator's range is checked per context — outside it in any
+// by the PV MFMAs in fp32) stays inside [2^-100, 2^100): |logit| < ~65. The scores arrive in log2 units (scale * log2 e is folded into the Wq
+// fragments in LDS, once per workgroup). The denominator's range is checked per context — outside it in any
 // lane sends the WAVE through the standard path for that context (K and V^T operands re-read from LDS: exact for any input,
 // tests/test_kernel_gpu.py::test_fwd_proj_pair_bf16_extreme_logits). fp16 keeps the maximum: its P overflows at 2^16.
 #ifndef STA_P3_OPTIMISTIC
@@ -451,6 +451,17 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   const int voffb = KBYTES + c16 * VROW + 16 * g, voffs = KBYTES + c16 * VROW + 128 + 8 * g;
   const V8* wf = (const V8*)lds_wq + lane;
   wait_dma_and_sync();
+  if constexpr (kOptimistic<T>) {
+    // scores in log2 units: scale * log2 e goes into the pair's Wq fragments, once per workgroup, in LDS (nwq fragments of 64 lanes x 8
+    // values; W' = round16(W * sl2e)) — the projection then delivers q * scale * log2 e with no per-item multiply
+    for (int f = (int)threadIdx.x; f < nwq * 64; f += 64 * NWV) {
+      V8 w = ((const V8*)lds_wq)[f];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (T)((float)w[j] * sl2e);
+      ((V8*)lds_wq)[f] = w;
+    }
+    __syncthreads();
+  }
 
   while (qcur < nitems) {
     // ---- projection: 5 column tiles x both batch rows; Wq fragments one k-step ahead -------------------------------
@@ -535,13 +546,6 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
 
     // accumulators -> S^T B operands (rounded to T once). Head A: tiles 0 | 1 (+ tile 2 rows g < 2), head B: tiles 3 | 4
     // (+ tile 2 rows g >= 2); the small operand (tile 2) serves both heads, the K images carry the zeros.
-    if constexpr (kOptimistic<T>) {      // scores in log2 units: scale * log2 e goes into q where the accumulators are rounded
-#pragma unroll
-      for (int u = 0; u < NT; ++u) {
-        qa0[u] = qa0[u] * sl2e;
-        qa1[u] = qa1[u] * sl2e;
-      }
-    }
     const float sm_scale = kOptimistic<T> ? 1.0f : sl2e;
     const V8 qA0 = cat8<T>(qa0[0], qa0[1]), qA1 = cat8<T>(qa1[0], qa1[1]);
     const V8 qB0 = cat8<T>(qa0[3], qa0[4]), qB1 = cat8<T>(qa1[3], qa1[4]);

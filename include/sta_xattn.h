@@ -160,8 +160,8 @@ int sta_xattn_fwd_proj_locals_from_l2(int C, int heads, int M, int K);
  * of kernels, like the packed K / V / Wq images. Per 16-pixel group and batch row C/32 fragments of 1 KiB, fragment s holding
  * at byte (16 g + c) * 16 the values y[16 P + c][32 s + 8 g .. + 7]: one load instruction of a wave is one coalesced KiB
  * and IS the MFMA B operand (row-major y costs 16 half-used 128-byte lines per instruction, or a DPP hand-over).
- * Results are bit-identical to sta_xattn_fwd_proj on the same values (bf16 at SD-v1 level 0, all three layouts: the head-pair kernel rounds
- * q * scale * log2(e) instead of q to bf16 and takes its softmax without the running maximum, with a per-context range check of the
+ * Results are bit-identical to sta_xattn_fwd_proj on the same values (bf16 at SD-v1 level 0, all three layouts: the head-pair kernel folds
+ * scale * log2(e) into its Wq fragments (W' = round16(W scale log2 e)) and takes its softmax without the running maximum, with a per-context range check of the
  * denominator that falls back to the standard softmax — same result class, exact for any logits). Taken by the head-pair kernel —
  * sta_xattn_fwd_proj_qfrag_supported(n_img, N, C, heads, M, K) != 0 iff d = 40, C in {160, 320}, K <= 2, 64 < M <= 77,
  * N % 16 == 0 and the launch has >= 256 pair workgroups — and by the locals-from-L2 kernel of SD-v1 level 1 (C = 640, d = 80,

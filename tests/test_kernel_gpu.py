@@ -818,10 +818,11 @@ def test_fwd_proj_pair_bf16_extreme_logits(mode):
         ref = orc.fused_xattn(q64.to(dtype).double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
         frac = lambda r: ((out[2 * i:2 * i + 2].float().cpu().double() - r).abs() <= 4 * eps * (1.0 + r.abs())).double().mean().item()
         if i in extreme:
-            # the kernel rounds q * scale * log2(e) to bf16 (scores in log2 units), the oracle's usual input is round16(q): at logits in the
-            # hundreds that 2^-9 relative difference moves a logit by several tenths and flips near-tie pixels (the reference's own bf16
-            # logits carry the same relative error). Held to 4 eps against the oracle fed the q the kernel uses; the usual input: printed
-            ref_k = orc.fused_xattn((q64 * sl2e).to(dtype).double() / sl2e, ki.double(), vi.double(), mi, ci.double(), heads, scale)
+            # the kernel folds scale * log2(e) into its Wq fragments (W' = round16(W scale log2 e): scores in log2 units) and rounds
+            # q = y W'^T to bf16, the oracle's usual input is round16(y W^T): at logits in the hundreds that 2^-9 relative difference moves a
+            # logit by several tenths and flips near-tie pixels (the reference's own bf16 logits carry the same relative error). Held to 4 eps against the oracle fed the q the kernel uses; the usual input: printed
+            q_k = (yi.double() @ (wq.double() * sl2e).to(dtype).double().t()).to(dtype).double() / sl2e      # W' = round16(W scale log2 e), q = round16(y W'^T)
+            ref_k = orc.fused_xattn(q_k, ki.double(), vi.double(), mi, ci.double(), heads, scale)
             print("%s, image %d: inside 4 eps of the oracle fed q rounded in log2 units %.4f, fed round16(q) %.4f" % (mode, i, frac(ref_k), frac(ref)))
             assert frac(ref_k) > 0.995, (i, frac(ref_k), frac(ref))
         else:
