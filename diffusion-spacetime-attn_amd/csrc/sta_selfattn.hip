@@ -30,6 +30,9 @@ struct SParams {
   float sl2e;       // scale * log2(e)
   float* lse;       // optional [B][H][N]: log2-domain log-sum-exp of the scaled scores (what the backward kernels re-derive P from)
   int sfrag;        // 1: `out` leaves in self-attention out-fragment order (sta_selfattn_fwd_sfrag; d = 40, 8 heads, N % 16 == 0)
+  unsigned* flags;  // sta_selfattn_fwd_optimistic: one word per workgroup of the pipelined kernel — written by the optimistic launch (1: a
+                    // denominator left [2^-100, 2^100)), read by the repair launch of the standard loop (0: the workgroup returns at once)
+  int optimistic;   // 1: launch the optimistic loop + the repair launch (bf16, the pipelined kernel's shapes)
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem_sa[];
@@ -424,10 +427,13 @@ template <typename T> struct SaQ {          // one query tile's B operands: dims
   typename Tr<T>::V4 sm;
 };
 
-template <typename T>
+template <typename T, bool OPT>
 __device__ __forceinline__ void sa_softmax_chunk(const int k, f32x4 (&s)[4], f32x4 (&o)[3], typename Tr<T>::V8 (&pb)[2], float& m, float (&tmp)[6],
                                                  const bool first) {
   // the vector work of one tile's softmax, cut into the pieces that go behind MFMA number k of a half step (k = 0 .. 13)
+  // OPT (bf16, sta_selfattn_fwd_optimistic): no running maximum behind a tile's first block — P = exp2(S - m_0) with the first block's exact
+  // maximum; the kernel checks the range of every denominator at the end and flags the workgroup for the repair launch
+  if (OPT && k < 4 && !first) return;
   switch (k) {
     case 0: tmp[0] = max3f(s[0][0], s[0][1], s[0][2]); tmp[1] = max3f(s[0][3], s[1][0], s[1][1]); break;
     case 1: tmp[2] = max3f(s[1][2], s[1][3], s[2][0]); tmp[3] = max3f(s[2][1], s[2][2], s[2][3]); break;
@@ -470,7 +476,7 @@ __device__ __forceinline__ void sa_softmax_chunk(const int k, f32x4 (&s)[4], f32
 #define STA_SA_ABLATE 0     // timing experiments (tools/asm_patch_ab.py flag:-DSTA_SA_ABLATE=bits; wrong results): 1 no softmax, 2 no MFMAs,
 #endif                      // 4 no per-block rendezvous, 8 no per-block LDS reads, 16 no LDS-DMA inside the loop
 // one half step: 14 MFMAs of tile `f` (PV of block j-1 when DO_PV, S^T of block j when DO_S) with the softmax of tile `v` between them
-template <typename T, bool DO_PV, bool DO_S, bool DO_SM>
+template <typename T, bool DO_PV, bool DO_S, bool DO_SM, bool OPT = false>
 __device__ __forceinline__ void sa_half_step(const SaK<T>& ka, const typename Tr<T>::V8 (&va)[6], const SaQ<T>& qf,
                                              f32x4 (&s_f)[4], f32x4 (&o_f)[3], const typename Tr<T>::V8 (&p_f)[2], const float m_f,
                                              f32x4 (&s_v)[4], f32x4 (&o_v)[3], typename Tr<T>::V8 (&p_v)[2], float& m_v, const bool first_v) {
@@ -478,7 +484,7 @@ __device__ __forceinline__ void sa_half_step(const SaK<T>& ka, const typename Tr
   int k = 0;
   auto vec = [&]() __attribute__((always_inline)) {
 #if !(STA_SA_ABLATE & 1)
-    if constexpr (DO_SM) sa_softmax_chunk<T>(k, s_v, o_v, p_v, m_v, tmp, first_v);
+    if constexpr (DO_SM) sa_softmax_chunk<T, OPT>(k, s_v, o_v, p_v, m_v, tmp, first_v);
 #else
     if (DO_SM && k == 0) {          // keep the scores and the P operands alive without the vector work
 #pragma unroll
@@ -529,10 +535,13 @@ __device__ __forceinline__ void sa_half_step(const SaK<T>& ka, const typename Tr
   }
 }
 
-template <typename T, int NW, int QT>
+template <typename T, int NW, int QT, bool OPT = false>
 __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
+  if constexpr (!OPT) {      // the repair launch behind an optimistic one: only flagged workgroups run
+    if (p.flags && p.flags[blockIdx.y * gridDim.x + blockIdx.x] == 0) return;
+  }
   // fragments of a block (1 KiB each): 0..3 K dims 0..31 of key tile t; 4 K dims 32..39 of all 64 keys (lane = key); 5..10 V^T
   constexpr int NDT = 3, NKF = 5, NVF = 6, NFR = NKF + NVF, PER = (NFR + NW - 1) / NW, NFRP = NW * PER, BB = NFRP * FRAG, DEPTH = 4;
   const int lane = threadIdx.x & 63;
@@ -653,7 +662,7 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
   arrive(0);
   if (nblk > 2) stage(smem_sa + 2 * BB);
   load_k(ka[0], 0);
-  sa_half_step<T, false, true, false>(ka[0], va[0], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], false);
+  sa_half_step<T, false, true, false, OPT>(ka[0], va[0], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], false);
   if (nblk > 1) {
     arrive(1);
     if (nblk > 3) stage(smem_sa + 3 * BB);
@@ -663,10 +672,10 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int i = 1; i < QT; ++i)
-    sa_half_step<T, false, true, true>(ka[0], va[0], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], true);
+    sa_half_step<T, false, true, true, OPT>(ka[0], va[0], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], true);
   auto body = [&](auto slot_tag, const int blk) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value, c = SLOT & 1;      // block blk sits in ring slot SLOT = blk % 4, register set blk & 1
-    sa_half_step<T, true, true, true>(ka[c], va[c], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], blk == 1);
+    sa_half_step<T, true, true, true, OPT>(ka[c], va[c], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], blk == 1);
     if (blk + 1 < nblk) {
       arrive(blk + 1);
 #if !(STA_SA_ABLATE & 16)
@@ -678,7 +687,7 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 1; i < QT; ++i)
-      sa_half_step<T, true, true, true>(ka[c], va[c], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], false);
+      sa_half_step<T, true, true, true, OPT>(ka[c], va[c], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], false);
   };
   for (int blk = 1; blk < nblk; blk += DEPTH) {
     body(std::integral_constant<int, 1>{}, blk);
@@ -690,25 +699,42 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
   // register set nblk & 1)
   auto drain = [&](auto set_tag) __attribute__((always_inline)) {
     constexpr int c = decltype(set_tag)::value;
-    sa_half_step<T, true, false, true>(ka[c], va[c], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], nblk == 1);
+    sa_half_step<T, true, false, true, OPT>(ka[c], va[c], qf[0], sc[0], o[0], pb[0], mrun[0], sc[QT - 1], o[QT - 1], pb[QT - 1], mrun[QT - 1], nblk == 1);
 #pragma unroll
     for (int i = 1; i < QT; ++i)
-      sa_half_step<T, true, false, false>(ka[c], va[c], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], false);
+      sa_half_step<T, true, false, false, OPT>(ka[c], va[c], qf[i], sc[i], o[i], pb[i], mrun[i], sc[i - 1], o[i - 1], pb[i - 1], mrun[i - 1], false);
   };
   if (nblk & 1) drain(std::integral_constant<int, 1>{});
   else drain(std::integral_constant<int, 0>{});
   float lrun[QT];
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) lrun[qt] = 0.f;
+  if constexpr (OPT) {
+    // every query's denominator (row 40 of O^T = tile 2, row 8: lane row 2, register 0) must lie in [2^-100, 2^100): tested on the bits
+    // (-ffinite-math-only would fold a class test of inf / NaN away); one word per workgroup tells the repair launch what to redo
+    bool bad = false;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) bad |= (g == 2) && (__float_as_uint(o[qt][2][0]) - 0x0D800000u) >= (0x71800000u - 0x0D800000u);
+    const int wg_bad = __syncthreads_or((int)bad);
+    if (threadIdx.x == 0) p.flags[blockIdx.y * gridDim.x + blockIdx.x] = wg_bad ? 1u : 0u;
+  }
   sa_epilogue<T, 3, QT, true>(p, o, mrun, lrun, b, h, px0, g, c16, lane);
 }
 
 template <typename T, int NW, int QT>
 int launch_sa_pipe(const SParams& p, hipStream_t st) {
   constexpr int lds = 4 * ((11 + NW - 1) / NW * NW) * FRAG;
-  static StaLdsAttr attr;
+  static StaLdsAttr attr, attr_opt;
   if (!attr.ensure((const void*)selfattn_fwd_pipe_kernel<T, NW, QT>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn pipe) failed");
   const int tiles = (p.N + 16 * QT * NW - 1) / (16 * QT * NW);
+  if constexpr (std::is_same<T, __bf16>::value) {
+    if (p.optimistic) {
+      // the optimistic loop (no running maximum behind a tile's first block: a tenth of the loop's instructions less), then the
+      // standard loop for the workgroups it flagged — with ordinary logits every workgroup of the second launch returns at once
+      if (!attr_opt.ensure((const void*)selfattn_fwd_pipe_kernel<T, NW, QT, true>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn pipe) failed");
+      hipLaunchKernelGGL((selfattn_fwd_pipe_kernel<T, NW, QT, true>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds, st, p);
+    }
+  }
   hipLaunchKernelGGL((selfattn_fwd_pipe_kernel<T, NW, QT>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn pipe launch: %s", hipGetErrorString(e));
@@ -786,9 +812,20 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
 
 }  // namespace
 
+// bf16 at the pipelined kernel's shapes (d = 40, 8 heads, whole 64-key blocks, q in log2 units), that kernel not switched off
+extern "C" int sta_selfattn_optimistic_supported(int N, int C, int heads, float scale, int dtype) {
+  const float sl2e = scale * 1.4426950408889634f;
+  return dtype == STA_BF16 && heads == 8 && C == 320 && N >= KB && N % KB == 0 && fabsf(sl2e - 1.0f) < 1e-6f &&
+         g_sta_opt[STA_OPT_SELFATTN_PIPE] != 2 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 8;
+}
+// one word per workgroup of the widest grid the dispatcher may choose (128 queries per workgroup)
+extern "C" size_t sta_selfattn_optimistic_flags_bytes(int B, int N, int heads) {
+  return B > 0 && N > 0 && heads > 0 ? (size_t)B * heads * ((N + 127) / 128) * sizeof(unsigned) : 0;
+}
+
 static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int N, int C,
                             int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
-                            void* stream, int sfrag = 0) {
+                            void* stream, int sfrag = 0, unsigned* flags = nullptr) {
   g_sta_err[0] = 0;
   if (!q || !k || !vt || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (B < 1 || B > 65535 || N < 8 || N % 8 || C <= 0 || heads <= 0 || C % heads)
@@ -803,7 +840,9 @@ static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* 
   if (fabsf(sl2e - 1.0f) < 1e-6f) sl2e = 1.0f;       // scale = ln 2: q is already in log2 units (pre-scaled W_q) -> the PRE kernels
   if (sfrag && !(C == 320 && heads == 8 && N % 16 == 0))
     return sta_fail(STA_E_UNSUP, "self-attention out-fragment order: C = 320 with 8 heads and N %% 16 == 0 (C=%d heads=%d N=%d)", C, heads, N);
-  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, sl2e, lse, sfrag};
+  SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, sl2e, lse, sfrag, flags, flags ? 1 : 0};
+  if (flags && !sta_selfattn_optimistic_supported(N, C, heads, scale, dtype))
+    return sta_fail(STA_E_UNSUP, "optimistic self-attention: bf16, d = 40 with 8 heads, N %% 64 == 0, q in log2 units (scale = ln 2)");
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_sa<__bf16>(p, st) : dispatch_sa<_Float16>(p, st);
 }
@@ -825,4 +864,12 @@ extern "C" int sta_selfattn_fwd_sfrag(const void* q, const void* k, const void* 
                                       int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
                                       void* stream) {
   return selfattn_fwd_any(q, k, vt, out_frag, nullptr, B, N, C, heads, ldq, ldk, vt_row_stride, vt_batch_stride, scale, dtype, stream, 1);
+}
+
+extern "C" int sta_selfattn_fwd_optimistic(const void* q, const void* k, const void* vt, void* out, void* flags, int B, int N, int C,
+                                           int heads, int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype,
+                                           int sfrag, void* stream) {
+  if (!flags) return sta_fail(STA_E_ARG, "null pointer");
+  return selfattn_fwd_any(q, k, vt, out, nullptr, B, N, C, heads, ldq, ldk, vt_row_stride, vt_batch_stride, scale, dtype, stream, sfrag ? 1 : 0,
+                          (unsigned*)flags);
 }

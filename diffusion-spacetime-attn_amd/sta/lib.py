@@ -61,6 +61,9 @@ SYMBOLS = {
     "sta_xattn_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "sta_xattn_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_selfattn_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
+    "sta_selfattn_fwd_optimistic": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _i, _vp]),
+    "sta_selfattn_optimistic_supported": (_i, [_i, _i, _i, _f, _i]),
+    "sta_selfattn_optimistic_flags_bytes": (ctypes.c_size_t, [_i, _i, _i]),
     "sta_selfattn_fwd_lse": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _l, _l, _f, _i, _vp]),
     "sta_selfattn_bwd": (_i, [_vp] * 13 + [_i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_groupnorm_silu": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _i, _vp]),

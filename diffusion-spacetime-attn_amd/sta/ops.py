@@ -399,6 +399,10 @@ def to_sfrag(x):
     return t.contiguous().view(x.shape)
 
 
+SELFATTN_OPTIMISTIC = True      # bf16 self-attention at level 0 through sta_selfattn_fwd_optimistic (profiles/r05_selfattn.md)
+_SA_FLAGS = {}
+
+
 def self_attention_sfrag_supported(x, heads):
     B, N, C = x.shape
     return self_attention_supported(x, heads) and C == 320 and heads == 8 and N % 16 == 0
@@ -422,6 +426,18 @@ def self_attention(q, k, vt, heads, scale, sfrag=False):
         vt = vt.contiguous()
     out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
     L = _lib.load()
+    if SELFATTN_OPTIMISTIC and L.sta_selfattn_optimistic_supported(N, C, heads, float(scale), _dtype_code(q)):
+        # bf16 at the pipelined kernel's shapes: no running maximum behind a tile's first key block + a repair launch for the workgroups whose
+        # denominators left the safe range (sta_selfattn_fwd_optimistic); one flag word per workgroup, cached per device
+        nbytes = L.sta_selfattn_optimistic_flags_bytes(B, N, heads)
+        key = (q.device, nbytes)
+        flags = _SA_FLAGS.get(key)
+        if flags is None:
+            flags = _SA_FLAGS[key] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+        _lib.check(L.sta_selfattn_fwd_optimistic(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), flags.data_ptr(), B, N, C, heads,
+                                                 q.stride(1), k.stride(1), vt.stride(1), vt.stride(0), float(scale), _dtype_code(q), 1 if sfrag else 0,
+                                                 _stream(q)), "sta_selfattn_fwd_optimistic")
+        return out
     fn, name = (L.sta_selfattn_fwd_sfrag, "sta_selfattn_fwd_sfrag") if sfrag else (L.sta_selfattn_fwd, "sta_selfattn_fwd")
     _lib.check(fn(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), B, N, C, heads,
                   q.stride(1), k.stride(1), vt.stride(1), vt.stride(0), float(scale), _dtype_code(q), _stream(q)), name)

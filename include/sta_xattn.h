@@ -242,6 +242,20 @@ int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, in
                      int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype, void* stream);
 
 /*
+ * The same forward with an OPTIMISTIC softmax, bf16 at the shapes of the software-pipelined kernel (SD-v1 level 0: C = 320, 8 heads,
+ * N % 64 == 0, q in log2 units — sta_selfattn_optimistic_supported): a bf16 P operand has fp32's exponent range, so behind a query tile's
+ * first key block (whose exact maximum is subtracted) the loop keeps NO running maximum — a tenth of its instructions, in a loop whose
+ * matrix and vector cycles add up (profiles/r05_level0.md). Every denominator is range-checked at the end ([2^-100, 2^100)); a workgroup
+ * that fails writes flags[workgroup] = 1 and the SECOND launch this call issues — the standard loop — recomputes exactly those
+ * workgroups (every other one returns at once): exact for any logits. flags: sta_selfattn_optimistic_flags_bytes(B, N, heads) bytes of
+ * device memory, caller-owned, no initialisation needed. sfrag != 0: output in out-fragment order as sta_selfattn_fwd_sfrag.
+ */
+int sta_selfattn_optimistic_supported(int N, int C, int heads, float scale, int dtype);
+size_t sta_selfattn_optimistic_flags_bytes(int B, int N, int heads);
+int sta_selfattn_fwd_optimistic(const void* q, const void* k, const void* vt, void* out, void* flags, int B, int N, int C, int heads,
+                                int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype, int sfrag, void* stream);
+
+/*
  * The same forward for the differentiable path (the weight-optimisation epochs: plms.py:275-277 back-propagates
  * through attn1 of every checkpointed block, diffusionmodules/util.py:123-145): additionally writes
  *   lse : [B][heads][N] float32 = log2 of the row sums of exp(scale q k^T), i.e. P = exp2(scale*log2(e)*s - lse),

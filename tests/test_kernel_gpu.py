@@ -463,6 +463,58 @@ def test_self_attention_software_pipelined_loop(N, dtype):
         assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (mode, err.max(), ref.abs().max())
 
 
+@pytest.mark.parametrize("sfrag", [False, True])
+def test_self_attention_optimistic_and_its_repair_launch(sfrag):
+    """bf16 at level 0 takes sta_selfattn_fwd_optimistic: behind a query tile's first key block the loop keeps no running maximum
+    (P = exp2(S - m_0): bf16 has fp32's exponent range), every denominator is range-checked and a flagged workgroup is recomputed by the
+    standard loop in the same call. (a) ordinary logits, with the maximum creeping up by ~40 log2 units along the sequence: no workgroup
+    flagged, 4 eps of the fp64 softmax, 2 eps of the standard loop; (b) keys late in the sequence that lift some queries' maximum by
+    ~180 log2 units: exp2 overflows in the optimistic pass, their workgroups are flagged (others are not) and the result is exact again."""
+    from sta import lib, ops
+    dtype, B, N, C, heads = torch.bfloat16, 2, 1024, 320, 8
+    d = C // heads
+    assert ops.SELFATTN_OPTIMISTIC and lib.load().sta_selfattn_optimistic_supported(N, C, heads, ops.LN2, lib.STA_BF16)
+    assert not lib.load().sta_selfattn_optimistic_supported(N, C, heads, ops.LN2, lib.STA_F16)
+    g = torch.Generator().manual_seed(7)
+    q = torch.randn(B, N, C, generator=g)
+    k0 = torch.randn(B, N, C, generator=g) * (0.3 + 2.7 * torch.arange(N).view(1, N, 1) / N)
+    v = torch.randn(B, N, C, generator=g).to(dtype)
+    qs = (q * (d ** -0.5 * 1.4426950408889634)).to(dtype)
+    for case in ("ordinary", "spiked"):
+        k = k0.clone()
+        if case == "spiked":
+            for key, px in ((700, 5), (990, 300)):          # batch 0 and 1, all heads: pixels 5 and 300 see a logit of several hundred at a late key
+                k[:, key] = 20.0 * q[:, px]           # its own query: ~180 log2 units above everything else; other queries: +- 30 (1 sigma)
+        k = k.to(dtype)
+        qd, kd, vtd = qs.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda()
+        fkey = (qd.device, B * heads * ((N + 127) // 128) * 4)
+        ops._SA_FLAGS[fkey] = torch.zeros(fkey[1], dtype=torch.uint8, device=qd.device)      # words beyond the chosen grid stay zero
+        out = ops.self_attention(qd, kd, vtd, heads, ops.LN2, sfrag=sfrag)
+        torch.cuda.synchronize()
+        flags = ops._SA_FLAGS[fkey].view(torch.int32).cpu()       # this shape's flag words (one per workgroup of the grid the dispatcher chose)
+        out = ops.from_sfrag(out) if sfrag else out
+        ops.SELFATTN_OPTIMISTIC = False
+        try:
+            std = ops.self_attention(qd, kd, vtd, heads, ops.LN2)
+        finally:
+            ops.SELFATTN_OPTIMISTIC = True
+        q64 = qs.double().view(B, N, heads, d).transpose(1, 2)
+        k64 = k.double().view(B, N, heads, d).transpose(1, 2)
+        v64 = v.double().view(B, N, heads, d).transpose(1, 2)
+        logits = q64 @ k64.transpose(-1, -2) * ops.LN2
+        ref = (torch.softmax(logits, -1) @ v64).transpose(1, 2).reshape(B, N, C)
+        eps = 2.0 ** -8
+        err = (out.float().cpu().double() - ref).abs()
+        assert torch.isfinite(out).all()
+        assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (case, err.max().item())
+        assert ((out.float() - std.float()).abs() <= 2 * eps * (1.0 + std.float().abs())).all()
+        grow = ((logits.max(-1).values - logits[..., :64].max(-1).values) * 1.4426950408889634).max().item()
+        if case == "ordinary":
+            assert 20 < grow < 90 and int(flags.sum()) == 0, (grow, int(flags.sum()))
+        else:
+            assert grow > 150 and 0 < int(flags.sum()) < flags.numel(), (grow, int(flags.sum()), flags.numel())
+
+
 SA_BWD_SHAPES = [(2, 256, 320, 8), (2, 128, 160, 2), (1, 64, 64, 4), (1, 192, 96, 1), (3, 320, 128, 2), (1, 4096, 320, 8), (1, 1024, 640, 8),
                  # d = 160 (levels 2 / mid at 512^2, level 2 at 768^2: single-buffered dk/dv kernel), 128, 112, 144
                  (2, 256, 1280, 8), (2, 64, 1280, 8), (1, 576, 1280, 8), (1, 128, 256, 2), (1, 64, 112, 1), (2, 192, 288, 2)]
