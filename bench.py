@@ -251,6 +251,18 @@ def source_sha(names=("sta_xattn_proj3.hip", "sta_xattn_proj3.h", "sta_xattn_dev
     return h.hexdigest()[:16]
 
 
+def _selfattn_optimistic_state():
+    """What the level-0 self-attention calls of the timed region left in their flags buffers (sta.ops._SA_FLAGS: one per shape): the calls the
+    optimistic loop still sits out, and how many workgroups the LAST call handed to the repair launch of the standard loop — the timed
+    rate belongs to the optimistic loop only if both are 0."""
+    from sta import ops
+    res = []
+    for (d_, nbytes), f in ops._SA_FLAGS.items():
+        w = f.view(torch.int32).cpu()
+        res.append({"workgroups": (nbytes // 4) - 2, "sitting_out_calls": int(w[0]), "flagged_last_call": int(w[2:].sum())})
+    return {"enabled": bool(ops.SELFATTN_OPTIMISTIC), "buffers": res}
+
+
 def _trunk_kernels(a):
     """Which of the trunk's operations run on own HIP kernels in this run (sta.fused switches; the tracked epochs keep the library's
     differentiable convolutions / GEMMs)."""
@@ -590,6 +602,7 @@ def main():
                    "weight_broadcast_s": round(t_bcast, 3), "weight_broadcast_bytes": nbytes,
                    "peak_hbm_gib": round(peak_gb, 1), **({"recompute": ckpt_mode} if a.opt_epochs > 1 else {})},
     }
+    out["config"]["selfattn_optimistic"] = _selfattn_optimistic_state()
     if not a.no_roofline:
         out["roofline"] = roofline_leg(model, dev, dt, a.dtype, I, K, lat, prompts[mine(0)[0]], centres)
     _phase("roofline leg done")

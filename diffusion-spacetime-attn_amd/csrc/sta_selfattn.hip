@@ -30,9 +30,9 @@ struct SParams {
   float sl2e;       // scale * log2(e)
   float* lse;       // optional [B][H][N]: log2-domain log-sum-exp of the scaled scores (what the backward kernels re-derive P from)
   int sfrag;        // 1: `out` leaves in self-attention out-fragment order (sta_selfattn_fwd_sfrag; d = 40, 8 heads, N % 16 == 0)
-  unsigned* flags;  // sta_selfattn_fwd_optimistic: one word per workgroup of the pipelined kernel — written by the optimistic launch (1: a
-                    // denominator left [2^-100, 2^100)), read by the repair launch of the standard loop (0: the workgroup returns at once)
-  int optimistic;   // 1: launch the optimistic loop + the repair launch (bf16, the pipelined kernel's shapes)
+  unsigned* flags;  // sta_selfattn_fwd_optimistic: two state words, then one word per workgroup of the pipelined kernel — written by the
+                    // optimistic launch (1: a denominator left its range), read by the repair launch of the standard loop (0: return at once)
+  int optimistic;   // 1: launch the optimistic loop + the repair launch (the pipelined kernel's shapes, both 16-bit types)
 };
 
 extern __shared__ __attribute__((aligned(16))) char smem_sa[];
@@ -431,7 +431,7 @@ template <typename T, bool OPT>
 __device__ __forceinline__ void sa_softmax_chunk(const int k, f32x4 (&s)[4], f32x4 (&o)[3], typename Tr<T>::V8 (&pb)[2], float& m, float (&tmp)[6],
                                                  const bool first) {
   // the vector work of one tile's softmax, cut into the pieces that go behind MFMA number k of a half step (k = 0 .. 13)
-  // OPT (bf16, sta_selfattn_fwd_optimistic): no running maximum behind a tile's first block — P = exp2(S - m_0) with the first block's exact
+  // OPT (sta_selfattn_fwd_optimistic): no running maximum behind a tile's first block — P = exp2(S - m_0) with the first block's exact
   // maximum; the kernel checks the range of every denominator at the end and flags the workgroup for the repair launch
   if (OPT && k < 4 && !first) return;
   switch (k) {
@@ -535,12 +535,34 @@ __device__ __forceinline__ void sa_half_step(const SaK<T>& ka, const typename Tr
   }
 }
 
+constexpr unsigned SA_OPT_SITOUT = 64;
 template <typename T, int NW, int QT, bool OPT = false>
 __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
+  // flags (sta_selfattn_fwd_optimistic): word 0 = calls the optimistic loop still sits out, word 1 = workgroups flagged by this call,
+  // word 2 + w = workgroup w of this grid must be redone. The two leading words carry state from call to call: a call in which more than
+  // an eighth of the workgroups failed (activations whose row maxima lie further than the type's headroom above the own neighbourhood's)
+  // switches the optimistic loop off for the next SA_OPT_SITOUT calls — those cost the standard loop plus an empty launch — instead of
+  // paying both loops every time.
+  const unsigned wg_id = blockIdx.y * gridDim.x + blockIdx.x;
   if constexpr (!OPT) {      // the repair launch behind an optimistic one: only flagged workgroups run
-    if (p.flags && p.flags[blockIdx.y * gridDim.x + blockIdx.x] == 0) return;
+    if (p.flags) {
+      const unsigned mine = p.flags[2 + wg_id];
+      if (wg_id == 0 && threadIdx.x == 0) {           // the call's bookkeeping (the optimistic launch of the next call is stream-ordered behind this one)
+        // (device-scope atomics: the optimistic launch read word 0 through the scalar cache, and a plain load here was served the line it
+        // left there — word 1 without the failures counted since)
+        const unsigned failed = atomicExch(p.flags + 1, 0u);
+        const unsigned sitout = __hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.flags, 8u * failed > gridDim.x * gridDim.y ? SA_OPT_SITOUT : (sitout ? sitout - 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (mine == 0) return;
+    }
+  } else {
+    if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {      // sitting out: everything goes to the standard loop
+      if (threadIdx.x == 0) p.flags[2 + wg_id] = 1u;
+      return;
+    }
   }
   // fragments of a block (1 KiB each): 0..3 K dims 0..31 of key tile t; 4 K dims 32..39 of all 64 keys (lane = key); 5..10 V^T
   constexpr int NDT = 3, NKF = 5, NVF = 6, NFR = NKF + NVF, PER = (NFR + NW - 1) / NW, NFRP = NW * PER, BB = NFRP * FRAG, DEPTH = 4;
@@ -599,6 +621,18 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
   // (the loop above copies 16 KiB per block: 14 fragments + fragment 0 twice more to keep one vmcnt for every wave); each wave counts
   // its own copies (wave-uniform branch around the s_waitcnt immediates)
   const bool full_share = wv < NFR - NW * (PER - 1);
+  const int nblk = N / KB;
+  // OPT: the key loop starts at the workgroup's OWN 64-key block and wraps around (block number j of the loop = key block (j0 + j) mod
+  // nblk). A query's largest logits sit in its own neighbourhood of the image, so the first block's exact maximum m_0 is within fp16's
+  // 2^16 of the row maximum for ordinary activations and P = exp2(S - m_0) needs no running maximum in EITHER 16-bit type; whatever
+  // does overflow is caught by the denominator test below and redone by the repair launch.
+  int to_wrap = nblk;
+  if constexpr (OPT) {
+    const int j0 = min(tile * (16 * QT * NW / KB), nblk - 1);
+    to_wrap = nblk - j0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) src[i] += (long)j0 * step[i];
+  }
   auto stage = [&](char* dst) __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
@@ -608,8 +642,13 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
                                          (__attribute__((address_space(3))) void*)(dst + (wv + NW * i) * FRAG), 16, 0, 0);
       src[i] += step[i];
     }
+    if constexpr (OPT) {
+      if (--to_wrap == 0) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) src[i] -= (long)nblk * step[i];
+      }
+    }
   };
-  const int nblk = N / KB;
   auto arrive = [&](const int blk) __attribute__((always_inline)) {      // block `blk` landed for every wave; everyone left block blk - 1
     if (blk + 1 < nblk) {
       if (full_share) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
@@ -710,13 +749,19 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) lrun[qt] = 0.f;
   if constexpr (OPT) {
-    // every query's denominator (row 40 of O^T = tile 2, row 8: lane row 2, register 0) must lie in [2^-100, 2^100): tested on the bits
+    // every query's denominator (row 40 of O^T = tile 2, row 8: lane row 2, register 0) must lie in [2^-100, 2^100) for bf16 and in
+    // [2^-100, 2^15) for fp16 — a P that reached fp16's largest number (as inf or saturated, whatever the conversion's rounding mode
+    // does) alone lifts its denominator past 2^15; the first block's own maximum contributes exactly 1. Tested on the bits
     // (-ffinite-math-only would fold a class test of inf / NaN away); one word per workgroup tells the repair launch what to redo
+    constexpr unsigned LO = 0x0D800000u, HI = std::is_same<T, __bf16>::value ? 0x71800000u : 0x47000000u;
     bool bad = false;
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) bad |= (g == 2) && (__float_as_uint(o[qt][2][0]) - 0x0D800000u) >= (0x71800000u - 0x0D800000u);
+    for (int qt = 0; qt < QT; ++qt) bad |= (g == 2) && (__float_as_uint(o[qt][2][0]) - LO) >= (HI - LO);
     const int wg_bad = __syncthreads_or((int)bad);
-    if (threadIdx.x == 0) p.flags[blockIdx.y * gridDim.x + blockIdx.x] = wg_bad ? 1u : 0u;
+    if (threadIdx.x == 0) {
+      p.flags[2 + wg_id] = wg_bad ? 1u : 0u;
+      if (wg_bad) atomicAdd(p.flags + 1, 1u);
+    }
   }
   sa_epilogue<T, 3, QT, true>(p, o, mrun, lrun, b, h, px0, g, c16, lane);
 }
@@ -727,7 +772,7 @@ int launch_sa_pipe(const SParams& p, hipStream_t st) {
   static StaLdsAttr attr, attr_opt;
   if (!attr.ensure((const void*)selfattn_fwd_pipe_kernel<T, NW, QT>, lds)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn pipe) failed");
   const int tiles = (p.N + 16 * QT * NW - 1) / (16 * QT * NW);
-  if constexpr (std::is_same<T, __bf16>::value) {
+  {
     if (p.optimistic) {
       // the optimistic loop (no running maximum behind a tile's first block: a tenth of the loop's instructions less), then the
       // standard loop for the workgroups it flagged — with ordinary logits every workgroup of the second launch returns at once
@@ -812,15 +857,15 @@ int dispatch_sa(const SParams& p, hipStream_t st) {
 
 }  // namespace
 
-// bf16 at the pipelined kernel's shapes (d = 40, 8 heads, whole 64-key blocks, q in log2 units), that kernel not switched off
+// both 16-bit types at the pipelined kernel's shapes (d = 40, 8 heads, whole 64-key blocks, q in log2 units), that kernel not switched off
 extern "C" int sta_selfattn_optimistic_supported(int N, int C, int heads, float scale, int dtype) {
   const float sl2e = scale * 1.4426950408889634f;
-  return dtype == STA_BF16 && heads == 8 && C == 320 && N >= KB && N % KB == 0 && fabsf(sl2e - 1.0f) < 1e-6f &&
+  return (dtype == STA_BF16 || dtype == STA_F16) && heads == 8 && C == 320 && N >= KB && N % KB == 0 && fabsf(sl2e - 1.0f) < 1e-6f &&
          g_sta_opt[STA_OPT_SELFATTN_PIPE] != 2 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 8;
 }
-// one word per workgroup of the widest grid the dispatcher may choose (128 queries per workgroup)
+// two state words + one word per workgroup of the widest grid the dispatcher may choose (128 queries per workgroup)
 extern "C" size_t sta_selfattn_optimistic_flags_bytes(int B, int N, int heads) {
-  return B > 0 && N > 0 && heads > 0 ? (size_t)B * heads * ((N + 127) / 128) * sizeof(unsigned) : 0;
+  return B > 0 && N > 0 && heads > 0 ? ((size_t)B * heads * ((N + 127) / 128) + 2) * sizeof(unsigned) : 0;      // + the two state words
 }
 
 static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int N, int C,
@@ -842,7 +887,7 @@ static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* 
     return sta_fail(STA_E_UNSUP, "self-attention out-fragment order: C = 320 with 8 heads and N %% 16 == 0 (C=%d heads=%d N=%d)", C, heads, N);
   SParams p{q, k, vt, out, B, N, C, heads, d, ldq, ldk, vt_row_stride, vt_batch_stride, sl2e, lse, sfrag, flags, flags ? 1 : 0};
   if (flags && !sta_selfattn_optimistic_supported(N, C, heads, scale, dtype))
-    return sta_fail(STA_E_UNSUP, "optimistic self-attention: bf16, d = 40 with 8 heads, N %% 64 == 0, q in log2 units (scale = ln 2)");
+    return sta_fail(STA_E_UNSUP, "optimistic self-attention: d = 40 with 8 heads, N %% 64 == 0, q in log2 units (scale = ln 2)");
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_sa<__bf16>(p, st) : dispatch_sa<_Float16>(p, st);
 }

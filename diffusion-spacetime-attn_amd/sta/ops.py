@@ -9,6 +9,7 @@ Mirrors (reference paths under attention_optimization/stable-diffusion/):
 PyTorch is used for device memory, the current HIP stream and autograd plumbing only; all arithmetic
 of the path happens in csrc/sta_xattn.hip. Nothing here falls back to eager PyTorch.
 """
+import os
 import torch
 
 from . import lib as _lib
@@ -399,7 +400,7 @@ def to_sfrag(x):
     return t.contiguous().view(x.shape)
 
 
-SELFATTN_OPTIMISTIC = True      # bf16 self-attention at level 0 through sta_selfattn_fwd_optimistic (profiles/r05_selfattn.md)
+SELFATTN_OPTIMISTIC = os.environ.get("STA_SELFATTN_OPTIMISTIC", "1") != "0"      # (env: A/B in tools/sa_opt_bench_ab.sh) self-attention at level 0 (both 16-bit types) through sta_selfattn_fwd_optimistic (profiles/r05_selfattn.md)
 _SA_FLAGS = {}
 
 
@@ -427,13 +428,13 @@ def self_attention(q, k, vt, heads, scale, sfrag=False):
     out = torch.empty((B, N, C), dtype=q.dtype, device=q.device)
     L = _lib.load()
     if SELFATTN_OPTIMISTIC and L.sta_selfattn_optimistic_supported(N, C, heads, float(scale), _dtype_code(q)):
-        # bf16 at the pipelined kernel's shapes: no running maximum behind a tile's first key block + a repair launch for the workgroups whose
+        # the pipelined kernel's shapes: key loop from the workgroup's own block, no running maximum behind a tile's first key block + a repair launch for the workgroups whose
         # denominators left the safe range (sta_selfattn_fwd_optimistic); one flag word per workgroup, cached per device
         nbytes = L.sta_selfattn_optimistic_flags_bytes(B, N, heads)
         key = (q.device, nbytes)
         flags = _SA_FLAGS.get(key)
         if flags is None:
-            flags = _SA_FLAGS[key] = torch.empty(nbytes, dtype=torch.uint8, device=q.device)
+            flags = _SA_FLAGS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=q.device)      # zero once: the leading state words live across calls
         _lib.check(L.sta_selfattn_fwd_optimistic(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), flags.data_ptr(), B, N, C, heads,
                                                  q.stride(1), k.stride(1), vt.stride(1), vt.stride(0), float(scale), _dtype_code(q), 1 if sfrag else 0,
                                                  _stream(q)), "sta_selfattn_fwd_optimistic")

@@ -242,13 +242,18 @@ int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, in
                      int ldq, int ldk, long vt_row_stride, long vt_batch_stride, float scale, int dtype, void* stream);
 
 /*
- * The same forward with an OPTIMISTIC softmax, bf16 at the shapes of the software-pipelined kernel (SD-v1 level 0: C = 320, 8 heads,
- * N % 64 == 0, q in log2 units — sta_selfattn_optimistic_supported): a bf16 P operand has fp32's exponent range, so behind a query tile's
- * first key block (whose exact maximum is subtracted) the loop keeps NO running maximum — a tenth of its instructions, in a loop whose
- * matrix and vector cycles add up (profiles/r05_level0.md). Every denominator is range-checked at the end ([2^-100, 2^100)); a workgroup
- * that fails writes flags[workgroup] = 1 and the SECOND launch this call issues — the standard loop — recomputes exactly those
- * workgroups (every other one returns at once): exact for any logits. flags: sta_selfattn_optimistic_flags_bytes(B, N, heads) bytes of
- * device memory, caller-owned, no initialisation needed. sfrag != 0: output in out-fragment order as sta_selfattn_fwd_sfrag.
+ * The same forward with an OPTIMISTIC softmax, both 16-bit types at the shapes of the software-pipelined kernel (SD-v1 level 0: C = 320,
+ * 8 heads, N % 64 == 0, q in log2 units — sta_selfattn_optimistic_supported). The key loop of a workgroup starts at its OWN 64-key block
+ * and wraps around; behind a query tile's first key block (whose exact maximum m_0 is subtracted) the loop keeps NO running maximum — a
+ * tenth of its instructions, in a loop whose matrix and vector cycles add up (profiles/r05_level0.md): P = exp2(S - m_0) has fp32's
+ * exponent range in bf16 and 2^16 of headroom over the query's own neighbourhood in fp16. Every denominator is range-checked at the end
+ * ([2^-100, 2^100) bf16, [2^-100, 2^15) fp16: one P at fp16's largest number is enough to fail); a workgroup that fails writes
+ * flags[workgroup] = 1 and the SECOND launch this call issues — the standard loop — recomputes exactly those workgroups (every other one
+ * returns at once): exact for any logits. A call in which more than an eighth of the workgroups failed switches the optimistic loop off
+ * for the next 64 calls on the same flags buffer (they cost the standard loop plus an empty launch), so activations that do not suit it
+ * cost 1 / 65 of a launch on average, not a second loop per call. flags: sta_selfattn_optimistic_flags_bytes(B, N, heads) bytes of
+ * device memory, caller-owned, ZERO before the first call (its first two words carry that state from call to call on one stream), then
+ * left alone. sfrag != 0: output in out-fragment order as sta_selfattn_fwd_sfrag.
  */
 int sta_selfattn_optimistic_supported(int N, int C, int heads, float scale, int dtype);
 size_t sta_selfattn_optimistic_flags_bytes(int B, int N, int heads);
