@@ -185,17 +185,22 @@ __device__ __forceinline__ typename Tr<T>::V4 cvt4(const f32x4& a) {
   return __builtin_bit_cast(typename Tr<T>::V4, U2{__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)});
 }
 
-// The OPTIMISTIC softmax of the bf16 instantiations (profiles/r05_level0.md: a SIMD's matrix and vector cycles add up in this kernel, and
+// The OPTIMISTIC softmax (both 16-bit types since the fp16 window below; first built for bf16: profiles/r05_level0.md: a SIMD's matrix and vector cycles add up in this kernel, and
 // 54 of a context's 175 ns of vector work are the running maximum — 9 v_max3, the row butterfly — and the scale-and-subtract FMAs).
 // A bf16 P operand has fp32's exponent range, so P = exp2(S) needs no maximum as long as the denominator (the ones row of V^T, summed
 // by the PV MFMAs in fp32) stays inside [2^-100, 2^100): |logit| < ~65. The scores arrive in log2 units (scale * log2 e is folded into the Wq
 // fragments in LDS, once per workgroup). The denominator's range is checked per context — outside it in any
 // lane sends the WAVE through the standard path for that context (K and V^T operands re-read from LDS: exact for any input,
-// tests/test_kernel_gpu.py::test_fwd_proj_pair_bf16_extreme_logits). fp16 keeps the maximum: its P overflows at 2^16.
+// tests/test_kernel_gpu.py::test_fwd_proj_pair_extreme_logits). fp16: the same with a narrower window (kDenLo / kDenHi).
 #ifndef STA_P3_OPTIMISTIC
 #define STA_P3_OPTIMISTIC 1      // 0: the standard softmax in both types (same-box A/B builds: tools/asm_patch_ab.py flag:-DSTA_P3_OPTIMISTIC=0)
 #endif
-template <typename T> constexpr bool kOptimistic = STA_P3_OPTIMISTIC && std::is_same<T, __bf16>::value;
+template <typename T> constexpr bool kOptimistic = STA_P3_OPTIMISTIC != 0;
+// the denominator's window, on the bits: bf16 [2^-100, 2^100); fp16 [2^-5, 2^15) — one P at fp16's largest number (inf or saturated) lifts the
+// sum past 2^15, and a sum of 2^-5 or more keeps the 77 keys' subnormal P (absolute error 2^-25 each) below 2^-13 of it: scores whose
+// maximum lies between about -5 and +15 log2 units (-3.5 .. +10 nats) take the optimistic path, everything else the standard one
+template <typename T> constexpr unsigned kDenLo = std::is_same<T, __bf16>::value ? 0x0D800000u : 0x3D000000u;
+template <typename T> constexpr unsigned kDenHi = std::is_same<T, __bf16>::value ? 0x71800000u : 0x47000000u;
 
 // One context of one head. kf holds its K operands on entry (requested a context earlier) and the NEXT context's on
 // exit (`knb`, `kns`: that block's per-lane K addresses). vb / vs: this context's per-lane V^T addresses; kcb / kcs: its K
@@ -243,12 +248,12 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int u = 0; u < 3; ++u) o[u] = M16<T>::mfma(vsm[u], p2, o[u]);
-    // the denominator sits in lane row 2 (lanes 32..47): anything outside [2^-100, 2^100) there -> the standard path. Tested on the
+    // the denominator sits in lane row 2 (lanes 32..47): anything outside [2^-100, 2^100) (fp16: [2^-5, 2^15)) there -> the standard path. Tested on the
     // BITS (this file is compiled with -ffinite-math-only: a floating-point class test of inf / NaN would be folded away): one unsigned
     // compare rejects negatives, zeros, denormals, infinities and NaNs as well; the margin of 2^27 to either end of the fp32 range keeps the
     // other rows of O^T (sums of P * v) finite whenever the ones row passes.
     const bool row2 = (threadIdx.x & 48) == 32;
-    const bool bad = row2 && (__float_as_uint(o[2][0]) - 0x0D800000u) >= (0x71800000u - 0x0D800000u);
+    const bool bad = row2 && (__float_as_uint(o[2][0]) - kDenLo<T>) >= (kDenHi<T> - kDenLo<T>);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
       load_k<T>(kf, kcb, kcs);                      // kf doubles as the buffer: the next context's operands are requested again below
 #pragma unroll
