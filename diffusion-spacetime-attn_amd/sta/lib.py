@@ -187,6 +187,25 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+# The hipcc release whose output the GPU parity suite ran against (the hazard windows sta/isa_lint.py enforces were measured with it,
+# tools/hazard_probe.py). A library built by another release still passes the lint, but its hot kernel is checked numerically on first use
+# (sta.ops.toolchain_self_check) instead of being trusted.
+VALIDATED_HIPCC = "HIP version: 7.2."
+
+
+def built_with():
+    """First line of csrc/.isa_lint.log: the `hipcc --version` headline of the build that produced the library ('' if unknown)."""
+    try:
+        with open(LINT_LOG) as fh:
+            return fh.readline().lstrip("# ").strip()
+    except OSError:
+        return ""
+
+
+def toolchain_validated():
+    return built_with().startswith(VALIDATED_HIPCC)
+
+
 _lib = None
 
 

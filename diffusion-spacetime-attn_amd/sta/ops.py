@@ -319,6 +319,56 @@ def proj_ofrag_supported(C, heads, dtype=torch.float16):
     return bool(_lib.load().sta_to_out_ln_packed_wo_bytes(C, heads))
 
 
+_TOOLCHAIN_CHECKED = None
+
+
+def toolchain_self_check(force=False):
+    """The head-pair kernel of level 0 (csrc/sta_xattn_proj3.hip) sits on MFMA hazard windows that hipcc does not pad by itself; the build's
+    lint enforces the ones measured with hipcc 7.2. A library built by ANOTHER release (lib.toolchain_validated() is False) is therefore
+    checked once per process before its first use — and always when `force`: a small level-0 problem through the pair kernel's three
+    layouts (row-major, query fragments, out fragments) against the one-head-per-workgroup kernel of csrc/sta_xattn_proj.hip. On a
+    mismatch the pair kernel and its fragment paths are switched off (STA_OPT_PROJ_PAIR = 2: sta_xattn_fwd_proj_qfrag_supported then
+    says no and the block takes the row-major chain) with a warning, instead of producing wrong attention silently. Returns True when
+    the pair kernel agrees."""
+    global _TOOLCHAIN_CHECKED
+    if _TOOLCHAIN_CHECKED is not None and not force:
+        return _TOOLCHAIN_CHECKED
+    import warnings
+    _TOOLCHAIN_CHECKED = True                      # (the launches below re-enter xattn_forward_proj)
+    ok = True
+    for dtype in (torch.float16, torch.bfloat16):
+        g = torch.Generator().manual_seed(11)
+        N, C, heads, K, M = 1024, 320, 8, 2, 77
+        y = torch.randn(2, N, C, generator=g).to(dtype).cuda()
+        wq = (torch.randn(C, C, generator=g) / C ** 0.5).to(dtype).cuda()
+        k = (torch.randn(K + 2, M, C, generator=g) * 0.7).to(dtype).cuda()
+        v = torch.randn(K + 2, M, C, generator=g).to(dtype).cuda()
+        mb = mask_bits(torch.rand(K, N, generator=g) < 0.3).cuda()
+        coef = (torch.rand(K, generator=g) * 3 + 0.5).cuda()
+        wqf, kvp = pack_wq(wq, heads), pack_kv_proj(k, v, heads, n_img=1)
+        scale = (C // heads) ** -0.5
+        prev = 0                                    # back to automatic afterwards (the option is a tests / tools override)
+        try:
+            _lib.set_option(_lib.OPT_PROJ_PAIR, 2)
+            ref = xattn_forward_proj(y, wqf, kvp, mb, coef, scale).float()
+            _lib.set_option(_lib.OPT_PROJ_PAIR, 1)
+            outs = [xattn_forward_proj(y, wqf, kvp, mb, coef, scale)]
+            if proj_qfrag_supported(C, heads, M, K, N, 1):
+                outs.append(xattn_forward_proj(to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True))
+                outs.append(from_ofrag(xattn_forward_proj(to_qfrag(y), wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True)))
+        finally:
+            _lib.set_option(_lib.OPT_PROJ_PAIR, prev)
+        eps = 2.0 ** -11 if dtype == torch.float16 else 2.0 ** -8
+        for o in outs:            # two kernels, two roundings of q (the pair kernel folds scale * log2 e into Wq): 16 eps; a broken instantiation is off by whole values
+            ok = ok and bool(torch.isfinite(o).all()) and bool(((o.float() - ref).abs() <= 16 * eps * (1.0 + ref.abs())).all())
+    if not ok:
+        _lib.set_option(_lib.OPT_PROJ_PAIR, 2)
+        warnings.warn("sta: the level-0 head-pair kernel built by '%s' disagrees with the reference kernel; it is switched off for this "
+                      "process (validated toolchain: '%s...')" % (_lib.built_with(), _lib.VALIDATED_HIPCC))
+    _TOOLCHAIN_CHECKED = ok
+    return ok
+
+
 def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofrag=False):
     """y [2I, N, C] = norm2(hidden) -> blended pre-projection output [2I, N, C]; the query projection happens inside
     the attention kernel (no autograd). `packed` comes from pack_kv_proj, `wq_packed` from pack_wq. `qfrag`: y is in
@@ -326,6 +376,11 @@ def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofr
     leaves in out-fragment order for fused.to_out_add_layernorm_ofrag (from_ofrag restores row-major)."""
     I, N, C, K = _check_inputs(y, packed, mask, coef)
     L = _lib.load()
+    if _TOOLCHAIN_CHECKED is None:
+        if _lib.toolchain_validated():
+            globals()["_TOOLCHAIN_CHECKED"] = True
+        elif not torch.cuda.is_current_stream_capturing():
+            toolchain_self_check()
     y = y.contiguous()
     coef32 = coef.detach().to(torch.float32).contiguous() if K else None
     maskc = mask.contiguous() if K else None

@@ -938,3 +938,13 @@ def test_fwd_proj_rejects_what_it_cannot_hold():
     finally:
         lib.set_option(lib.OPT_PROJ_LL2, 0)
     assert rc == -2 and "LDS" in err
+
+
+def test_toolchain_self_check_passes_and_is_wired():
+    """sta.ops.toolchain_self_check: the level-0 head-pair kernel in its three layouts against the one-head-per-workgroup kernel, both
+    16-bit types — what a library built by a hipcc release other than the validated one runs before its first projection-fused launch
+    (sta.lib.toolchain_validated reads the release from csrc/.isa_lint.log). The shipped library must pass it."""
+    from sta import lib, ops
+    assert lib.built_with().startswith("HIP version")
+    assert ops.toolchain_self_check(force=True) is True
+    assert ops._TOOLCHAIN_CHECKED is True
