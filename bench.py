@@ -259,7 +259,7 @@ def _selfattn_optimistic_state():
     res = []
     for (d_, nbytes), f in ops._SA_FLAGS.items():
         w = f.view(torch.int32).cpu()
-        res.append({"workgroups": (nbytes // 4) - 2, "sitting_out_calls": int(w[0]), "flagged_last_call": int(w[2:].sum())})
+        res.append({"workgroups": (nbytes // 4) - 32, "sitting_out_calls": int(w[0]), "flagged_last_call": int(w[32:].sum())})
     return {"enabled": bool(ops.SELFATTN_OPTIMISTIC), "buffers": res}
 
 

@@ -536,19 +536,20 @@ __device__ __forceinline__ void sa_half_step(const SaK<T>& ka, const typename Tr
 }
 
 constexpr unsigned SA_OPT_SITOUT = 64;
+constexpr unsigned SA_FLAG0 = 32;      // the per-workgroup flag words start one 128-byte line behind the two state words (which only atomics touch)
 template <typename T, int NW, int QT, bool OPT = false>
 __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   // flags (sta_selfattn_fwd_optimistic): word 0 = calls the optimistic loop still sits out, word 1 = workgroups flagged by this call,
-  // word 2 + w = workgroup w of this grid must be redone. The two leading words carry state from call to call: a call in which more than
+  // word 32 + w = workgroup w of this grid must be redone (the state words have a 128-byte line to themselves). The two leading words carry state from call to call: a call in which more than
   // an eighth of the workgroups failed (activations whose row maxima lie further than the type's headroom above the own neighbourhood's)
   // switches the optimistic loop off for the next SA_OPT_SITOUT calls — those cost the standard loop plus an empty launch — instead of
   // paying both loops every time.
   const unsigned wg_id = blockIdx.y * gridDim.x + blockIdx.x;
   if constexpr (!OPT) {      // the repair launch behind an optimistic one: only flagged workgroups run
     if (p.flags) {
-      const unsigned mine = p.flags[2 + wg_id];
+      const unsigned mine = p.flags[SA_FLAG0 + wg_id];
       if (wg_id == 0 && threadIdx.x == 0) {           // the call's bookkeeping (the optimistic launch of the next call is stream-ordered behind this one)
         // (device-scope atomics: the optimistic launch read word 0 through the scalar cache, and a plain load here was served the line it
         // left there — word 1 without the failures counted since)
@@ -560,7 +561,7 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
     }
   } else {
     if (__builtin_amdgcn_readfirstlane(__hip_atomic_load(p.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0) {      // sitting out: everything goes to the standard loop
-      if (threadIdx.x == 0) p.flags[2 + wg_id] = 1u;
+      if (threadIdx.x == 0) p.flags[SA_FLAG0 + wg_id] = 1u;
       return;
     }
   }
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(64 * NW, 2) void selfattn_fwd_pipe_kernel(const SPa
     for (int qt = 0; qt < QT; ++qt) bad |= (g == 2) && (__float_as_uint(o[qt][2][0]) - LO) >= (HI - LO);
     const int wg_bad = __syncthreads_or((int)bad);
     if (threadIdx.x == 0) {
-      p.flags[2 + wg_id] = wg_bad ? 1u : 0u;
+      p.flags[SA_FLAG0 + wg_id] = wg_bad ? 1u : 0u;
       if (wg_bad) atomicAdd(p.flags + 1, 1u);
     }
   }
@@ -863,9 +864,9 @@ extern "C" int sta_selfattn_optimistic_supported(int N, int C, int heads, float 
   return (dtype == STA_BF16 || dtype == STA_F16) && heads == 8 && C == 320 && N >= KB && N % KB == 0 && fabsf(sl2e - 1.0f) < 1e-6f &&
          g_sta_opt[STA_OPT_SELFATTN_PIPE] != 2 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 8;
 }
-// two state words + one word per workgroup of the widest grid the dispatcher may choose (128 queries per workgroup)
+// the state words' line (32 words) + one word per workgroup of the widest grid the dispatcher may choose (128 queries per workgroup)
 extern "C" size_t sta_selfattn_optimistic_flags_bytes(int B, int N, int heads) {
-  return B > 0 && N > 0 && heads > 0 ? ((size_t)B * heads * ((N + 127) / 128) + 2) * sizeof(unsigned) : 0;      // + the two state words
+  return B > 0 && N > 0 && heads > 0 ? ((size_t)B * heads * ((N + 127) / 128) + SA_FLAG0) * sizeof(unsigned) : 0;      // + the state words' 128-byte line
 }
 
 static int selfattn_fwd_any(const void* q, const void* k, const void* vt, void* out, float* lse, int B, int N, int C,

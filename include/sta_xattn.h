@@ -252,7 +252,7 @@ int sta_selfattn_fwd(const void* q, const void* k, const void* vt, void* out, in
  * returns at once): exact for any logits. A call in which more than an eighth of the workgroups failed switches the optimistic loop off
  * for the next 64 calls on the same flags buffer (they cost the standard loop plus an empty launch), so activations that do not suit it
  * cost 1 / 65 of a launch on average, not a second loop per call. flags: sta_selfattn_optimistic_flags_bytes(B, N, heads) bytes of
- * device memory, caller-owned, ZERO before the first call (its first two words carry that state from call to call on one stream), then
+ * device memory, caller-owned, ZERO before the first call (its first two words carry that state from call to call on one stream; the per-workgroup words start 128 bytes in), then
  * left alone. sfrag != 0: output in out-fragment order as sta_selfattn_fwd_sfrag.
  */
 int sta_selfattn_optimistic_supported(int N, int C, int heads, float scale, int dtype);

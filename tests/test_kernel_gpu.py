@@ -509,18 +509,18 @@ def test_self_attention_optimistic_and_its_repair_launch(sfrag, dtype):
         k = k.to(dtype)
         qd, kd, vtd = qs.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda()
         fkey = (qd.device, lib.load().sta_selfattn_optimistic_flags_bytes(B, N, heads))
-        assert fkey[1] == (B * heads * ((N + 127) // 128) + 2) * 4
+        assert fkey[1] == (B * heads * ((N + 127) // 128) + 32) * 4      # the two state words have a 128-byte line to themselves
         ops._SA_FLAGS[fkey] = torch.zeros(fkey[1], dtype=torch.uint8, device=qd.device)      # words beyond the chosen grid stay zero
         out = ops.self_attention(qd, kd, vtd, heads, ops.LN2, sfrag=sfrag)
         torch.cuda.synchronize()
         words = ops._SA_FLAGS[fkey].view(torch.int32).cpu()
-        state, flags = words[:2].tolist(), words[2:]       # (calls to sit out, failures counted: reset), one flag word per workgroup of the grid the dispatcher chose
+        state, flags = words[:2].tolist(), words[32:]       # (calls to sit out, failures counted: reset), one flag word per workgroup of the grid the dispatcher chose
         assert state[1] == 0 and state[0] == (64 if 8 * int(flags.sum()) > 128 else 0), (state, int(flags.sum()))
         if state[0]:            # more than an eighth failed: the next call sits the optimistic loop out (all workgroups through the standard loop), exact all the same
             again = ops.self_attention(qd, kd, vtd, heads, ops.LN2, sfrag=sfrag)
             torch.cuda.synchronize()
             w2 = ops._SA_FLAGS[fkey].view(torch.int32).cpu()
-            assert w2[:2].tolist() == [63, 0] and int(w2[2:2 + 128].sum()) == 128
+            assert w2[:2].tolist() == [63, 0] and int(w2[32:32 + 128].sum()) == 128 and int(w2[2:32].sum()) == 0
             ops.SELFATTN_OPTIMISTIC = False
             try:
                 assert torch.equal(again, ops.self_attention(qd, kd, vtd, heads, ops.LN2, sfrag=sfrag))

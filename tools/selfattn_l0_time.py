@@ -24,5 +24,5 @@ run = lambda: ops.self_attention(qk[..., :C], qk[..., C:], vt, h, ops.LN2)
 lib.set_option(lib.OPT_SELFATTN_PIPE, int(os.environ.get("STA_SA_MODE", "0")))
 lib.set_option(lib.OPT_SELFATTN_WAVES, int(os.environ.get("STA_SA_WAVES", "0")))
 t1, t2 = timed(run), timed(run)
-st = [(int(w[0]), int(w[1]), int(w[2:].sum())) for w in (f.view(torch.int32).cpu() for f in ops._SA_FLAGS.values())]
+st = [(int(w[0]), int(w[1]), int(w[32:].sum())) for w in (f.view(torch.int32).cpu() for f in ops._SA_FLAGS.values())]
 print("level-0 self-attention forward %s optimistic=%s qscale=%s: %.1f %.1f us; (sit-out, failures, flagged) = %s" % (dt, ops.SELFATTN_OPTIMISTIC, os.environ.get("STA_SA_QSCALE", "1.0"), t1, t2, st))
