@@ -510,432 +510,6 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
 }
 
 // --------------------------------------------------------------------------------------------------
-// backward (dq, dcoef)
-// --------------------------------------------------------------------------------------------------
-// For one context with probabilities P (normalised), upstream gradient G on A = P V:
-//   dP = G V^T ; delta = sum_key P dP ; dS = P (dP - delta) ; dQ = scale * dS K
-// Returns (optionally) A in o[] for the dcoef dot product and accumulates dQ^T tiles into dq[].
-template <typename T, int NDT, bool WANT_A>
-__device__ __forceinline__ void attend_bwd(const char* buf, const typename Tr<T>::V8 (&qf)[nks_of(NDT)],
-                                           const typename Tr<T>::V8 (&gf)[nks_of(NDT)], float gscale,
-                                           f32x4 (&o)[NDT], f32x4 (&dq)[NDT], int lane, int g, int M,
-                                           float sl2e) {
-  using V8 = typename Tr<T>::V8;
-  constexpr int NKS = nks_of(NDT);
-  constexpr int NKF = NKT * NKS, NVF = NPS * NDT;
-  constexpr int NFWD = NKF + NVF;
-  const V8* frag = (const V8*)buf + lane;
-  // Fragments are hoisted from LDS into registers ahead of the MFMAs that consume them (no ds_read -> wait ->
-  // mfma chains). Small head dims hoist a whole phase; from d = 112 up that would not fit the register file
-  // (scratch spills measured at d = 144/160), so the hoisting granularity drops to one operand set at a time.
-  constexpr bool BIG = NDT > 6 || NDT == 3;   // d = 40 (NDT 3): whole-phase hoisting costs the second wave per SIMD
-  // phase 1: S^T = KQ.q and dP^T = VQ.G^T
-  f32x4 st[NKT], dp[NKT];
-#pragma unroll
-  for (int t = 0; t < NKT; ++t) {
-    st[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  if constexpr (!BIG) {
-    V8 ka[NKF], vq[NKF];
-#pragma unroll
-    for (int f = 0; f < NKF; ++f) ka[f] = frag[f * 64];
-#pragma unroll
-    for (int f = 0; f < NKF; ++f) vq[f] = frag[(NFWD + f) * 64];
-#pragma unroll
-    for (int t = 0; t < NKT; ++t)
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        st[t] = Tr<T>::mfma(ka[t * NKS + s], qf[s], st[t]);
-        dp[t] = Tr<T>::mfma(vq[t * NKS + s], gf[s], dp[t]);
-      }
-  } else {
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      V8 ka[NKS], vq[NKS];
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) ka[s] = frag[(t * NKS + s) * 64];
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) vq[s] = frag[(NFWD + t * NKS + s) * 64];
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        st[t] = Tr<T>::mfma(ka[s], qf[s], st[t]);
-        dp[t] = Tr<T>::mfma(vq[s], gf[s], dp[t]);
-      }
-    }
-  }
-  const float inv = softmax_keys_fast(st, g, M, sl2e);
-  V8 pb[NPS];
-  if (WANT_A) {   // phase 2: A = P V (needed for the dcoef dot product)
-    tiles_to_b<T>(st, pb);
-    if constexpr (!BIG) {
-      V8 va[NVF];
-#pragma unroll
-      for (int f = 0; f < NVF; ++f) va[f] = frag[(NKF + f) * 64];
-#pragma unroll
-      for (int u = 0; u < NDT; ++u) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s * NDT + u], pb[s], acc);
-        o[u] = acc * inv;
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < NDT; ++u) {
-        V8 va[NPS];
-#pragma unroll
-        for (int s = 0; s < NPS; ++s) va[s] = frag[(NKF + s * NDT + u) * 64];
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(va[s], pb[s], acc);
-        o[u] = acc * inv;
-      }
-    }
-  }
-  // phase 3: delta, dS (in place in st; padded keys have st == 0) and dQ^T += KP.dS^T
-  float delta = 0.f;
-#pragma unroll
-  for (int t = 0; t < NKT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      st[t][r] *= inv;
-      delta += st[t][r] * dp[t][r];
-    }
-  delta = bfly_sum(delta);
-#pragma unroll
-  for (int t = 0; t < NKT; ++t)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) st[t][r] = st[t][r] * (dp[t][r] - delta) * gscale;
-  tiles_to_b<T>(st, pb);
-  if constexpr (!BIG) {
-    V8 kp[NVF];
-#pragma unroll
-    for (int f = 0; f < NVF; ++f) kp[f] = frag[(NFWD + NKF + f) * 64];
-#pragma unroll
-    for (int u = 0; u < NDT; ++u)
-#pragma unroll
-      for (int s = 0; s < NPS; ++s) dq[u] = Tr<T>::mfma(kp[s * NDT + u], pb[s], dq[u]);
-  } else {
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      V8 kp[NPS];
-#pragma unroll
-      for (int s = 0; s < NPS; ++s) kp[s] = frag[(NFWD + NKF + s * NDT + u) * 64];
-#pragma unroll
-      for (int s = 0; s < NPS; ++s) dq[u] = Tr<T>::mfma(kp[s], pb[s], dq[u]);
-    }
-  }
-}
-
-template <typename T, int NDT>
-__global__ __launch_bounds__(256) void xattn_bwd_kernel(const Params pin) {
-  using V8 = typename Tr<T>::V8;
-  using V4 = typename Tr<T>::V4;
-  const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)pin.K * gridDim.x * (blockDim.x >> 6));
-  constexpr int NKS = nks_of(NDT);
-  constexpr int NALL = all_frags(NDT);
-  constexpr int CB = NALL * FRAG;
-  constexpr bool DB = bwd_double_buffered(NDT);  // forward+backward images of two contexts in LDS?
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int nw = blockDim.x >> 6;
-  const int g = lane >> 4, c16 = lane & 15;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  int tile, h;
-  if (p.H == 8) { tile = L >> 3; h = L & 7; } else { tile = L / p.H; h = L % p.H; }
-  const int px = (tile * nw + wv) * 16 + c16;
-  const bool valid = px < p.N;
-  const int N = p.N, C = p.C, d = p.d, K = p.K;
-
-  // disc membership of the workgroup's pixels (lane <-> pixel of the 16*nw-pixel tile) and the blend weights
-  // in one vector load each; every wave derives the same workgroup bits by ballots — no LDS flag, no barrier
-  // (with K == 0 the host points mask/coef at q: readable, ignored)
-  const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
-  unsigned tb = p.mask[min(tile * nw * 16 + lane, N - 1)];
-  tb = (lane < 16 * nw && tile * nw * 16 + lane < N) ? (tb & ((1u << K) - 1u)) : 0u;
-  float w[MAXK], dc[MAXK];
-  float wsum = 0.f;
-  unsigned mybits = 0, wgbits = 0;
-  const unsigned ownbits = (unsigned)__shfl((int)tb, 16 * wv + c16);       // this lane's own pixel
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i) {
-    const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
-    w[i] = 0.f;
-    dc[i] = 0.f;
-    if (i < K) {
-      const unsigned long long bl = __ballot((tb >> i) & 1u);
-      if (bl) wgbits |= 1u << i;
-      if ((bl >> (16 * wv)) & 0xffffull) mybits |= 1u << i;
-      w[i] = ((ownbits >> i) & 1u) ? ci : 0.f;
-      wsum += w[i];
-    }
-  }
-
-  const size_t row1 = (size_t)N * C;
-  const T* qbase = (const T*)p.q + (size_t)px * C + h * d;
-  const T* gbase = (const T*)p.dout + (size_t)px * C + h * d;
-  V8 qf[NKS], gf[NKS], g1[NKS];
-  // row 0: upstream of A_u is dO0 - (sum_i coef_i mask_i) dO1
-  load_b_frags<T, NKS>(qbase, valid, g, d, qf);
-  load_b_frags<T, NKS>(gbase, valid, g, d, gf);
-  load_b_frags<T, NKS>(gbase + row1, valid, g, d, g1);
-#pragma unroll
-  for (int s = 0; s < NKS; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gf[s][j] = (T)((float)gf[s][j] - wsum * (float)g1[s][j]);
-  // dO1 in accumulator (O^T) order for the dcoef dot products
-  f32x4 g1t[NDT];
-#pragma unroll
-  for (int u = 0; u < NDT; ++u) {
-    const int dd = 16 * u + 4 * g;
-    g1t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (valid && dd < d) {
-      const V4 t4 = *(const V4*)(gbase + row1 + dd);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) g1t[u][r] = (float)t4[r];
-    }
-  }
-
-  const size_t ctx_stride = (size_t)p.H * NALL * FRAG;
-  const char* img_h = p.packed + (size_t)h * NALL * FRAG;
-  T* dqbase = (T*)p.out + (size_t)px * C + h * d;
-
-  f32x4 au[NDT], o[NDT], dq[NDT];
-#pragma unroll
-  for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  int c = 0, b = 0;
-  stage_frags(img_h, smem, NALL, wv, nw, lane);
-  while (c >= 0) {
-    int cn = -1;
-    for (int cc = c + 1; cc < K + 2; ++cc)
-      if (cc < 2 || ((wgbits >> (cc - 2)) & 1u)) { cn = cc; break; }
-    wait_dma_and_sync();
-    if (DB && cn >= 0) stage_frags(img_h + cn * ctx_stride, smem + (b ^ 1) * CB, NALL, wv, nw, lane);
-    const char* buf = smem + b * CB;
-    if (c == 0) {
-      if (mybits)
-        attend_bwd<T, NDT, true>(buf, qf, gf, p.scale, au, dq, lane, g, p.M, p.sl2e);
-      else
-        attend_bwd<T, NDT, false>(buf, qf, gf, p.scale, au, dq, lane, g, p.M, p.sl2e);
-      // dq row 0 is complete: store it and switch to row 1 operands
-      if (valid) {
-#pragma unroll
-        for (int u = 0; u < NDT; ++u) {
-          const int dd = 16 * u + 4 * g;
-          if (dd < d) {
-            V4 r0;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) r0[r] = (T)dq[u][r];
-            *(V4*)(dqbase + dd) = r0;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      load_b_frags<T, NKS>(qbase + row1, valid, g, d, qf);
-    } else if (c == 1) {
-      attend_bwd<T, NDT, false>(buf, qf, g1, p.scale, o, dq, lane, g, p.M, p.sl2e);
-    } else if ((mybits >> (c - 2)) & 1u) {
-      float wc = 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXK; ++i) wc = (i == c - 2) ? w[i] : wc;
-      // G_i = w_i dO1: linear, so feed dO1 and scale dS by w_i (exact in fp32, no re-rounding)
-      attend_bwd<T, NDT, true>(buf, qf, g1, p.scale * wc, o, dq, lane, g, p.M, p.sl2e);
-      // dcoef_i += mask_i(px) * sum_d dO1 (A_i - A_u)
-      float part = 0.f;
-#pragma unroll
-      for (int u = 0; u < NDT; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part += g1t[u][r] * (o[u][r] - au[u][r]);
-      part = ((ownbits >> (c - 2)) & 1u) ? part : 0.f;
-#pragma unroll
-      for (int i = 0; i < MAXK; ++i) dc[i] += (i == c - 2) ? part : 0.f;
-    }
-    if (!DB && cn >= 0) {  // single buffer: refill only after every wave has finished reading it
-      __syncthreads();
-      stage_frags(img_h + cn * ctx_stride, smem, NALL, wv, nw, lane);
-    }
-    c = cn;
-    if (DB) b ^= 1;
-  }
-
-  if (valid) {
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      const int dd = 16 * u + 4 * g;
-      if (dd < d) {
-        V4 r1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) r1[r] = (T)dq[u][r];
-        *(V4*)(dqbase + row1 + dd) = r1;
-      }
-    }
-  }
-  // per-wave dcoef partials -> workspace [K][gridDim.x * nw] (fixed slot per wave: deterministic)
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i) {
-    if (i < K) {
-      float v = dc[i];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) p.aux[(size_t)i * gridDim.x * nw + (size_t)blockIdx.x * nw + wv] = v;
-    }
-  }
-}
-
-// Backward on the LDS-RESIDENT structure of the staged forward: when the forward AND backward fragment images of all
-// K+2 contexts fit one CU's LDS together (d <= 48 with K <= 2: 4 x 38 KiB), a workgroup copies them once, passes ONE
-// barrier and walks `p.iters` strided pixel tiles with them — no barrier and no re-staging per context or per tile
-// (the kernel above stages one context at a time: 4 barriers and 152 KiB of LDS-DMA per 64 pixels). dcoef partials
-// accumulate in registers over the tiles; one fixed workspace slot per wave keeps the reduction deterministic.
-template <typename T, int NDT, int NWV>
-__global__ __launch_bounds__(64 * NWV, NWV == 8 ? 2 : 1) void xattn_bwd_staged_kernel(const Params pin) {
-  using V8 = typename Tr<T>::V8;
-  using V4 = typename Tr<T>::V4;
-  const Params p = for_image<T, NDT>(pin, blockIdx.y, (size_t)pin.K * gridDim.x * NWV);
-  constexpr int NKS = nks_of(NDT);
-  constexpr int CB = all_frags(NDT) * FRAG;
-  constexpr int TP = 16 * NWV;
-  const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int g = lane >> 4, c16 = lane & 15;
-  const int L = xcd_remap(blockIdx.x, gridDim.x);
-  int wt, h;
-  if (p.H == 8) { wt = L >> 3; h = L & 7; } else { wt = L / p.H; h = L % p.H; }
-  const int N = p.N, C = p.C, d = p.d, K = p.K, W = p.ntiles;
-  const int mine = (p.tiles - wt + W - 1) / W;
-  const int iters = mine < p.iters ? mine : p.iters;
-
-  const float coef_lane = p.coef[min(lane, K > 0 ? K - 1 : 0)];
-  const size_t ctx_stride = (size_t)p.H * CB;
-  const char* img_h = p.packed + (size_t)h * CB;
-  for (int c = 0; c < K + 2; ++c) stage_frags(img_h + c * ctx_stride, smem + (size_t)c * CB, all_frags(NDT), wv, NWV, lane);
-  float dc[MAXK];
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i) dc[i] = 0.f;
-  const size_t row1 = (size_t)N * C;
-  wait_dma_and_sync();
-
-  for (int it = 0; it < iters; ++it) {
-    const int px = (wt + it * W) * TP + wv * 16 + c16;
-    const bool valid = px < N;
-    const unsigned ownbits = valid ? ((unsigned)p.mask[px] & ((1u << K) - 1u)) : 0u;
-    float w[MAXK];
-    float wsum = 0.f;
-    unsigned mybits = 0;
-#pragma unroll
-    for (int i = 0; i < MAXK; ++i) {
-      w[i] = 0.f;
-      if (i < K) {
-        const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
-        if (__ballot((ownbits >> i) & 1u)) mybits |= 1u << i;
-        w[i] = ((ownbits >> i) & 1u) ? ci : 0.f;
-        wsum += w[i];
-      }
-    }
-    const T* qbase = (const T*)p.q + (size_t)(valid ? px : 0) * C + h * d;
-    const T* gbase = (const T*)p.dout + (size_t)(valid ? px : 0) * C + h * d;
-    V8 qf[NKS], gf[NKS], g1[NKS];
-    load_b_frags<T, NKS>(qbase, valid, g, d, qf);
-    load_b_frags<T, NKS>(gbase, valid, g, d, gf);
-    load_b_frags<T, NKS>(gbase + row1, valid, g, d, g1);
-#pragma unroll
-    for (int s = 0; s < NKS; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gf[s][j] = (T)((float)gf[s][j] - wsum * (float)g1[s][j]);
-    f32x4 g1t[NDT];
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      const int dd = 16 * u + 4 * g;
-      g1t[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (valid && dd < d) {
-        const V4 t4 = *(const V4*)(gbase + row1 + dd);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) g1t[u][r] = (float)t4[r];
-      }
-    }
-    T* dqbase = (T*)p.out + (size_t)px * C + h * d;
-    f32x4 au[NDT], o[NDT], dq[NDT];
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // row 0: context 0 against dO0 - (sum_i coef_i mask_i) dO1; A_u is needed only where a disc touches the wave
-    if (mybits)
-      attend_bwd<T, NDT, true>(smem, qf, gf, p.scale, au, dq, lane, g, p.M, p.sl2e);
-    else
-      attend_bwd<T, NDT, false>(smem, qf, gf, p.scale, au, dq, lane, g, p.M, p.sl2e);
-    if (valid) {
-#pragma unroll
-      for (int u = 0; u < NDT; ++u) {
-        const int dd = 16 * u + 4 * g;
-        if (dd < d) {
-          V4 r0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) r0[r] = (T)dq[u][r];
-          *(V4*)(dqbase + dd) = r0;
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    load_b_frags<T, NKS>(qbase + row1, valid, g, d, qf);
-    attend_bwd<T, NDT, false>(smem + CB, qf, g1, p.scale, o, dq, lane, g, p.M, p.sl2e);
-    for (int i = 0; i < K; ++i) {
-      if (!((mybits >> i) & 1u)) continue;
-      float wc = 0.f;
-#pragma unroll
-      for (int j = 0; j < MAXK; ++j) wc = (j == i) ? w[j] : wc;
-      attend_bwd<T, NDT, true>(smem + (size_t)(2 + i) * CB, qf, g1, p.scale * wc, o, dq, lane, g, p.M, p.sl2e);
-      float part = 0.f;
-#pragma unroll
-      for (int u = 0; u < NDT; ++u)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) part += g1t[u][r] * (o[u][r] - au[u][r]);
-      part = ((ownbits >> i) & 1u) ? part : 0.f;
-#pragma unroll
-      for (int j = 0; j < MAXK; ++j) dc[j] += (j == i) ? part : 0.f;
-    }
-    if (valid) {
-#pragma unroll
-      for (int u = 0; u < NDT; ++u) {
-        const int dd = 16 * u + 4 * g;
-        if (dd < d) {
-          V4 r1;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) r1[r] = (T)dq[u][r];
-          *(V4*)(dqbase + row1 + dd) = r1;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < MAXK; ++i) {
-    if (i < K) {
-      float v = dc[i];
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-      if (lane == 0) p.aux[(size_t)i * gridDim.x * NWV + (size_t)blockIdx.x * NWV + wv] = v;
-    }
-  }
-}
-
-// Sum the per-wave partials in a fixed order: one block of 256 threads per object.
-__global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restrict__ part, float* dcoef,
-                                                           int n) {
-  __shared__ float sm[256];
-  const float* src = part + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * n;
-  float acc = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) acc += src[i];
-  sm[threadIdx.x] = acc;
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if ((int)threadIdx.x < s) sm[threadIdx.x] += sm[threadIdx.x + s];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) dcoef[blockIdx.y * gridDim.x + blockIdx.x] = sm[0];
-}
-
-// --------------------------------------------------------------------------------------------------
 // host side
 // --------------------------------------------------------------------------------------------------
 }  // namespace
@@ -955,26 +529,6 @@ int sta_fail(int code, const char* fmt, ...) {
 namespace {
 #define g_err g_sta_err
 #define fail sta_fail
-
-// waves per workgroup: the largest of {4,2,1} that still gives >= 256 workgroups (one per CU);
-// small levels (N = 64..256) fall to 1 wave so the launch spreads over as many CUs as possible.
-int pick_waves(int N, int heads) {
-  for (int nw = 4; nw > 1; nw >>= 1) {
-    const long wgs = (long)((N + 16 * nw - 1) / (16 * nw)) * heads;
-    if (wgs >= 256) return nw;
-  }
-  return 1;
-}
-
-int check_shape(int N, int C, int heads, int M, int K) {
-  if (N <= 0 || C <= 0 || heads <= 0 || M <= 0 || K < 0) return fail(STA_E_ARG, "non-positive dimension");
-  if (C % heads) return fail(STA_E_ARG, "C=%d not divisible by heads=%d", C, heads);
-  const int d = C / heads;
-  if (d % 8 || d > STA_MAX_HEAD_DIM) return fail(STA_E_UNSUP, "head dim %d unsupported (need d%%8==0, d<=%d)", d, STA_MAX_HEAD_DIM);
-  if (M > STA_MAX_KEYS) return fail(STA_E_UNSUP, "M=%d keys unsupported (max %d)", M, STA_MAX_KEYS);
-  if (K > STA_MAX_OBJECTS) return fail(STA_E_UNSUP, "K=%d objects unsupported (max %d)", K, STA_MAX_OBJECTS);
-  return STA_OK;
-}
 
 // Pixel tiles per wave of the wave-per-context kernel. QT > 1 reuses each fragment for more pixels but
 // measured slower at every level (register pressure: N=1024 d=80 7.2 -> 8.7 us; 8 images 39.8 -> 52.8 us),
@@ -1093,57 +647,6 @@ int launch_fwd_qt(const Params& p, int qt, hipStream_t st) {
   return launch_fwd<T, NDT, 1>(p, st);
 }
 
-// LDS-resident backward: shapes whose K+2 full (forward + backward) images fit 160 KiB together.
-template <typename T, int NDT>
-int launch_bwd_staged(const Params& p0, float* dcoef, hipStream_t st) {
-  constexpr int NWV = 4;                                    // one wave per SIMD: the backward keeps > 256 registers live
-  constexpr int TP = 16 * NWV;
-  Params p = p0;
-  const int lds = (p.K + 2) * all_frags(NDT) * FRAG;
-  p.tiles = (p.N + TP - 1) / TP;
-  long wg_per_head = 256L / ((long)p.H * p.n_img);          // one workgroup per CU (its image takes the whole LDS)
-  if (wg_per_head < 1) wg_per_head = 1;
-  if (wg_per_head > p.tiles) wg_per_head = p.tiles;
-  p.iters = (int)((p.tiles + wg_per_head - 1) / wg_per_head);
-  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
-  p.ntiles = (p.tiles + p.iters - 1) / p.iters;            // workgroups per head
-  static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_bwd_staged_kernel<T, NDT, NWV>, 160 * 1024)) return fail(STA_E_LAUNCH, "hipFuncSetAttribute(bwd staged) failed");
-  const int nwg = p.ntiles * p.H;
-  hipLaunchKernelGGL((xattn_bwd_staged_kernel<T, NDT, NWV>), dim3(nwg, p.n_img), dim3(64 * NWV), lds, st, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(STA_E_LAUNCH, "bwd staged launch: %s", hipGetErrorString(e));
-  if (p.K > 0) {
-    hipLaunchKernelGGL(dcoef_reduce_kernel, dim3(p.K, p.n_img), dim3(256), 0, st, p.aux, dcoef, nwg * NWV);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(STA_E_LAUNCH, "dcoef reduce launch: %s", hipGetErrorString(e));
-  }
-  return STA_OK;
-}
-
-template <typename T, int NDT>
-int launch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
-  if constexpr (NDT <= 3) {
-    const bool fits = (p.K + 2) * all_frags(NDT) * FRAG <= 160 * 1024;
-    const long tiles64 = (long)((p.N + 63) / 64) * p.H * p.n_img;
-    if (fits && g_sta_opt[STA_OPT_FWD_KERNEL] != 2 && (tiles64 >= 512 || g_sta_opt[STA_OPT_FWD_KERNEL] == 1))
-      return launch_bwd_staged<T, NDT>(p, dcoef, st);
-  }
-  constexpr int lds = (bwd_double_buffered(NDT) ? 2 : 1) * all_frags(NDT) * FRAG + 16;
-  static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_bwd_kernel<T, NDT>, lds)) return fail(STA_E_LAUNCH, "hipFuncSetAttribute(bwd) failed");
-  const int nwg = p.ntiles * p.H;
-  hipLaunchKernelGGL((xattn_bwd_kernel<T, NDT>), dim3(nwg, p.n_img), dim3(64 * nw), lds, st, p);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return fail(STA_E_LAUNCH, "bwd launch: %s", hipGetErrorString(e));
-  if (p.K > 0) {
-    hipLaunchKernelGGL(dcoef_reduce_kernel, dim3(p.K, p.n_img), dim3(256), 0, st, p.aux, dcoef, nwg * nw);
-    e = hipGetLastError();
-    if (e != hipSuccess) return fail(STA_E_LAUNCH, "dcoef reduce launch: %s", hipGetErrorString(e));
-  }
-  return STA_OK;
-}
-
 template <typename T>
 int dispatch_fwd(const Params& p, hipStream_t st) {
   const int ndt = (p.d + 15) / 16;
@@ -1174,23 +677,6 @@ int dispatch_fwd(const Params& p, hipStream_t st) {
     case 8: return launch_fwd_qt<T, 8>(p, qt, st);
     case 9: return launch_fwd_qt<T, 9>(p, qt, st);
     case 10: return launch_fwd_qt<T, 10>(p, qt, st);
-  }
-  return fail(STA_E_UNSUP, "head dim %d unsupported", p.d);
-}
-
-template <typename T>
-int dispatch_bwd(const Params& p, int nw, float* dcoef, hipStream_t st) {
-  switch ((p.d + 15) / 16) {
-    case 1: return launch_bwd<T, 1>(p, nw, dcoef, st);
-    case 2: return launch_bwd<T, 2>(p, nw, dcoef, st);
-    case 3: return launch_bwd<T, 3>(p, nw, dcoef, st);
-    case 4: return launch_bwd<T, 4>(p, nw, dcoef, st);
-    case 5: return launch_bwd<T, 5>(p, nw, dcoef, st);
-    case 6: return launch_bwd<T, 6>(p, nw, dcoef, st);
-    case 7: return launch_bwd<T, 7>(p, nw, dcoef, st);
-    case 8: return launch_bwd<T, 8>(p, nw, dcoef, st);
-    case 9: return launch_bwd<T, 9>(p, nw, dcoef, st);
-    case 10: return launch_bwd<T, 10>(p, nw, dcoef, st);
   }
   return fail(STA_E_UNSUP, "head dim %d unsupported", p.d);
 }
@@ -1263,32 +749,5 @@ int sta_xattn_fwd(const void* q, const void* packed, const uint8_t* mask, const 
   return dtype == STA_BF16 ? dispatch_fwd<__bf16>(p, st) : dispatch_fwd<_Float16>(p, st);
 }
 
-size_t sta_xattn_bwd_workspace_bytes(int n_img, int N, int heads, int K) {
-  if (n_img <= 0 || N <= 0 || heads <= 0 || K <= 0) return 16;
-  return (size_t)n_img * K * ((N + 15) / 16 + 4) * heads * sizeof(float);
-}
-
-int sta_xattn_bwd(const void* q, const void* packed, const uint8_t* mask, const float* coef,
-                  const void* dout, void* dq, float* dcoef, void* workspace, int n_img, int N, int C, int heads,
-                  int M, int K, float scale, int dtype, void* stream) {
-  g_err[0] = 0;
-  if (!q || !packed || !dout || !dq) return fail(STA_E_ARG, "null pointer");
-  if (n_img < 1 || n_img > 65535) return fail(STA_E_ARG, "n_img=%d", n_img);
-  if (int rc = check_shape(N, C, heads, M, K)) return rc;
-  if (K > 0 && (!mask || !coef || !dcoef || !workspace)) return fail(STA_E_ARG, "mask/coef/dcoef/workspace required when K > 0");
-  if (dtype != STA_BF16 && dtype != STA_F16) return fail(STA_E_UNSUP, "dtype %d", dtype);
-  const int nw = pick_waves(N, heads);
-  Params p{};
-  p.q = q; p.packed = (const char*)packed; p.mask = mask; p.coef = coef; p.out = dq; p.dout = dout;
-  if (K == 0) {  // unconditional prologue loads: readable (ignored) bytes
-    p.mask = (const uint8_t*)q;
-    p.coef = (const float*)q;
-  }
-  p.aux = (float*)workspace; p.N = N; p.C = C; p.H = heads; p.d = C / heads; p.M = M; p.K = K; p.n_img = n_img;
-  p.ntiles = (N + 16 * nw - 1) / (16 * nw);
-  p.scale = scale; p.sl2e = scale * 1.4426950408889634f;
-  hipStream_t st = (hipStream_t)stream;
-  return dtype == STA_BF16 ? dispatch_bwd<__bf16>(p, nw, dcoef, st) : dispatch_bwd<_Float16>(p, nw, dcoef, st);
-}
 
 }  // extern "C"

@@ -42,10 +42,6 @@ template <> struct Tr<_Float16> {
 __host__ __device__ constexpr int nks_of(int ndt) { return (ndt + 1) / 2; }
 __host__ __device__ constexpr int fwd_frags(int ndt) { return NKT * nks_of(ndt) + NPS * ndt; }
 __host__ __device__ constexpr int all_frags(int ndt) { return 2 * fwd_frags(ndt); }
-// The backward stages both halves of a context; two of them fit the 160 KiB LDS only up to d = 96.
-__host__ __device__ constexpr bool bwd_double_buffered(int ndt) {
-  return 2 * all_frags(ndt) * 1024 + 16 <= 160 * 1024;
-}
 
 // Key held by k-slot (g, j) of PV step s: slots follow the S^T accumulator order.
 __host__ __device__ __forceinline__ int pv_key(int s, int g, int j) {
@@ -447,6 +443,29 @@ __device__ __forceinline__ void attend_staged(const FR fr, const typename Tr<T>:
       else ac[qt][u] = o[qt][u] * wi + (ac[qt][u] - au[qt][u] * w[qt]);
     }
   }
+}
+
+// --------------------------------------------------------------------------------------------------
+// host-side helpers shared by sta_xattn.hip (pack, forward) and sta_xattn_bwd.hip (backward)
+// --------------------------------------------------------------------------------------------------
+// waves per workgroup: the largest of {4,2,1} that still gives >= 256 workgroups (one per CU);
+// small levels (N = 64..256) fall to 1 wave so the launch spreads over as many CUs as possible.
+inline int pick_waves(int N, int heads) {
+  for (int nw = 4; nw > 1; nw >>= 1) {
+    const long wgs = (long)((N + 16 * nw - 1) / (16 * nw)) * heads;
+    if (wgs >= 256) return nw;
+  }
+  return 1;
+}
+
+inline int check_shape(int N, int C, int heads, int M, int K) {
+  if (N <= 0 || C <= 0 || heads <= 0 || M <= 0 || K < 0) return sta_fail(STA_E_ARG, "non-positive dimension");
+  if (C % heads) return sta_fail(STA_E_ARG, "C=%d not divisible by heads=%d", C, heads);
+  const int d = C / heads;
+  if (d % 8 || d > STA_MAX_HEAD_DIM) return sta_fail(STA_E_UNSUP, "head dim %d unsupported (need d%%8==0, d<=%d)", d, STA_MAX_HEAD_DIM);
+  if (M > STA_MAX_KEYS) return sta_fail(STA_E_UNSUP, "M=%d keys unsupported (max %d)", M, STA_MAX_KEYS);
+  if (K > STA_MAX_OBJECTS) return sta_fail(STA_E_UNSUP, "K=%d objects unsupported (max %d)", K, STA_MAX_OBJECTS);
+  return STA_OK;
 }
 
 }  // namespace

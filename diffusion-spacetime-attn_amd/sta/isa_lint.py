@@ -44,6 +44,11 @@ Finding = namedtuple("Finding", "kernel line rule producer consumer have need")
 _MFMA_RE = re.compile(r"^v_mfma_(?:f32|i32|f64)_(\d+)x(\d+)x(\d+)")
 _TRANS = ("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_", "v_rcp_iflag")
 MAX_WINDOW = 13
+# round 6 (profiles/r06_bwd_race.md): an optional rule — wait states between an MFMA and an LDS / vector-memory load whose DESTINATION
+# overlaps the MFMA's C or D registers. It was one hypothesis for the eight-wave backward's non-reproducible bits; the probes
+# (tools/hazard_probe.py ^ld) found no such hazard for the 16x16 shapes and 900+ such sites in kernels that have always been bit-stable,
+# so it is OFF (0) in the build; tools can switch it on to count sites.
+LOAD_RETURN_STATES = 0
 
 
 def _mfma_info(mn):
@@ -162,6 +167,11 @@ class Ins:
         return self.mn.startswith(_TRANS)
 
     @property
+    def is_load(self):
+        """LDS / vector-memory instruction whose result comes back into vector registers some time after it was issued."""
+        return bool(self.defs) and self.mn.startswith(("ds_read", "ds_load", "buffer_load", "global_load", "flat_load", "scratch_load"))
+
+    @property
     def is_vmem_or_lds(self):
         return self.mn.startswith(("global_", "buffer_", "flat_", "ds_", "scratch_"))
 
@@ -246,6 +256,8 @@ def lint_text(text, strict=False, only=None):
                 need_waw = (4 if small else 5) if four else P + 1
                 rules.append(("mfma D -> read", p.defs, need_raw, lambda c, R: bool(c.uses & R) and not (c.mfma is not None and not ((c.a | c.b) & R)), False))
                 rules.append(("mfma D -> write", p.defs, need_waw, lambda c, R: c.mfma is None and bool(c.defs & R), False))
+                if LOAD_RETURN_STATES:
+                    rules.append(("mfma C / D -> a load returns into it", p.defs | p.c, LOAD_RETURN_STATES, lambda c, R: c.is_load and bool(c.defs & R), False))
                 rules.append(("mfma D -> C of an mfma of another shape", p.defs, 6, lambda c, R, pm=_shape(p.mn): c.mfma is not None and bool(c.c & R) and _shape(c.mn) != pm, True))
                 if not four:
                     late = {r for r in p.c if r not in p.defs and (r[1] - min(x[1] for x in p.c)) >= 4}

@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(PKG_ROOT)
 CSRC = os.path.join(PKG_ROOT, "csrc")
 INCLUDE = os.path.join(REPO_ROOT, "include")
 LIB_PATH = os.path.join(CSRC, "libsta_xattn.so")
-SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip", "sta_xattn_proj3.hip", "sta_rowgemm.hip", "sta_ffgemm.hip", "sta_conv.hip", "sta_gemm.hip", "sta_selfattn.hip", "sta_selfattn_bwd.hip", "sta_unet.hip", "sta_unet_bwd.hip", "sta_fp8.hip")]
+SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_bwd.hip", "sta_xattn_proj.hip", "sta_xattn_proj3.hip", "sta_rowgemm.hip", "sta_ffgemm.hip", "sta_conv.hip", "sta_gemm.hip", "sta_selfattn.hip", "sta_selfattn_bwd.hip", "sta_unet.hip", "sta_unet_bwd.hip", "sta_fp8.hip")]
 
 # Self-attention keeps its MFMA accumulators in VGPRs: hipcc otherwise parks them in AGPRs and brackets the
 # online-softmax rescale with v_accvgpr_read/write pairs (120 extra VALU instructions per key block in a kernel
@@ -27,11 +27,11 @@ SOURCES = [os.path.join(CSRC, n) for n in ("sta_xattn.hip", "sta_xattn_proj.hip"
 # (Self-attention likewise: 1387 -> 1325 us at B=32, N=4096, d=40.)
 PER_SOURCE_FLAGS = {"sta_selfattn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
                     "sta_selfattn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form", "-ffinite-math-only"],
-                    "sta_xattn.hip": ["-ffinite-math-only"], "sta_xattn_proj.hip": ["-ffinite-math-only"],
+                    "sta_xattn.hip": ["-ffinite-math-only"], "sta_xattn_bwd.hip": ["-ffinite-math-only"], "sta_xattn_proj.hip": ["-ffinite-math-only"],
                     "sta_xattn_proj3.hip": ["-ffinite-math-only"], "sta_rowgemm.hip": ["-ffinite-math-only"], "sta_ffgemm.hip": ["-ffinite-math-only"], "sta_conv.hip": ["-ffinite-math-only"], "sta_gemm.hip": ["-ffinite-math-only"]}
 
 STA_BF16, STA_F16 = 0, 1
-OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_SELFATTN_32, OPT_PROJ_PAIR, OPT_SELFATTN_WAVES, OPT_SELFATTN_PIPE, OPT_PROJ_LL2 = range(11)
+OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_SELFATTN_32, OPT_PROJ_PAIR, OPT_SELFATTN_WAVES, OPT_SELFATTN_PIPE, OPT_PROJ_LL2, OPT_BWD_KERNEL, OPT_BWD_SLOTS, OPT_BWD_WAVES = range(14)
 FWD_STAGED, FWD_SPLIT = 1, 2
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
 

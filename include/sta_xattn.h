@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define STA_VERSION 0x000400 /* 0.4.0: fragment-order entry points, trunk convolution / row GEMM / producer-side GroupNorm statistics (round 4) */
+#define STA_VERSION 0x000500 /* 0.5.0: one LDS-resident backward kernel for every head dim (round 6); 0.4.0: fragment-order entry points, trunk convolution / row GEMM / producer-side GroupNorm statistics (round 4) */
 
 enum { STA_BF16 = 0, STA_F16 = 1 };
 
@@ -59,9 +59,8 @@ const char* sta_last_error(void);
  * variables. Process-global, takes effect at the next launch; value 0 restores the automatic choice.
  */
 enum {
-  STA_OPT_FWD_KERNEL = 0,   /* 1: LDS-resident ("staged") kernel, 2: wave-per-context ("split") kernel; the backward reads it
-                               the same way: 1 = LDS-resident multi-tile backward where it fits, 2 = one context at a time */
-  STA_OPT_STAGED_TILES = 1, /* pixel tiles a staged workgroup walks (1..12) */
+  STA_OPT_FWD_KERNEL = 0,   /* 1: LDS-resident ("staged") kernel, 2: wave-per-context ("split") kernel */
+  STA_OPT_STAGED_TILES = 1, /* pixel tiles a staged workgroup walks (forward: 1..12, backward: 1..16) */
   STA_OPT_STAGED_WAVES = 2, /* waves per staged workgroup: 4, 8 or 12 (sta_xattn_fwd_proj, one head per workgroup: 4 or 8) */
   STA_OPT_STAGED_QT = 3,    /* 2: two 16-pixel sub-tiles per wave */
   STA_OPT_HEAD_MAJOR = 4,   /* 1: block b -> head b % heads; 2: XCD-contiguous tile ranges */
@@ -73,7 +72,10 @@ enum {
   STA_OPT_SELFATTN_PIPE = 9, /* sta_selfattn_fwd at d = 40, 8 heads, log2-domain q, N % 64 == 0: 2 = the plain loop instead of the software-pipelined one; 3 = three query tiles per wave (192 queries per workgroup), 4 / 8 = four / eight waves x two tiles */
   STA_OPT_PROJ_LL2 = 10,    /* sta_xattn_fwd_proj where Wq + every context do not fit a CU's LDS but Wq + the two mandatory ones do (SD-v1 level 1,
                                C = 640, d = 80): 2 = refuse (the block then takes the GEMM + sta_xattn_fwd); default: local contexts from L2 */
-  STA_OPT_COUNT = 11
+  STA_OPT_BWD_KERNEL = 11,  /* unused since 0.5.0 (one backward kernel) */
+  STA_OPT_BWD_SLOTS = 12,   /* sta_xattn_bwd: at most this many contexts in LDS (>= 2), the other local ones from L2 */
+  STA_OPT_BWD_WAVES = 13,   /* experiment builds only (-DSTA_EXPERIMENT_BWD8): 8 = eight waves per workgroup */
+  STA_OPT_COUNT = 14
 };
 int sta_set_option(int key, int value);
 

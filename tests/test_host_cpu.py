@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(sta_[a-z_0-9]+)\s*\(", header))
     assert declared == set(lib.SYMBOLS), (declared, set(lib.SYMBOLS))
     L = lib.load()                       # raises if the .so is missing or a symbol is absent
-    assert L.sta_version() == 0x000400
+    assert L.sta_version() == 0x000500
     assert L.sta_last_error() == b""
     # host-only entry points (no GPU work)
     assert L.sta_xattn_packed_kv_bytes(4, 8, 40) == 4 * 8 * 2 * (5 * 2 + 3 * 3) * 1024

@@ -15,6 +15,8 @@ patches (applied to the instruction stream of the kernels whose mangled name mat
   lgkm0                every s_waitcnt lgkmcnt(N) / vmcnt(N) becomes a full wait
   cvt_nop              s_nop 1 behind every v_cvt_pk_bf16_f32
   perm_nop             s_nop 7 in front of and behind every v_permlane*_swap
+  before:PREFIX:TEXT / after:PREFIX:TEXT   TEXT in front of / behind every instruction that starts with PREFIX
+  range:A:B:TEXT       TEXT behind every instruction of kernel lines A..B (1-based inside the kernel)
   line:N:TEXT          insert TEXT in front of line N of the kernel's text (1-based inside the kernel)
   flag:-DNAME=V        not a text patch: an extra hipcc flag for this build of the source (ablation switches); the text then passes
                        the library's own lint + cure (sta/isa_lint.py) like a product build
@@ -32,11 +34,31 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 OUT = os.path.join(ROOT, "build", "asm")
 
 
+def _regs(tok):
+    m = re.match(r"v\[(\d+):(\d+)\]$", tok)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", tok)
+    return {int(m.group(1))} if m else set()
+
+
 def patch_kernel(lines, patches):
     out = []
+    recent = []          # (kernel line, role -> registers) of the MFMAs seen so far
     for n, l in enumerate(lines, 1):
         s = l.strip()
         pre, post = [], []
+        if s.startswith("v_mfma"):
+            ops = [t.strip() for t in s.split(None, 1)[1].split(",")]
+            recent.append((n, {"D": _regs(ops[0]), "A": _regs(ops[1]), "B": _regs(ops[2]), "C": _regs(ops[3])}))
+        for p in patches:
+            # dswar:ROLES:N:TEXT  TEXT in front of every ds_read / buffer_load whose destination overlaps a register that one of the
+            # MFMAs of the previous N lines uses in one of ROLES (e.g. ABCD, D, AB)
+            if p.startswith("dswar:") and s.startswith(("ds_read", "buffer_load", "global_load")):
+                _, roles, dist, text = p.split(":", 3)
+                dst = _regs(s.split(None, 1)[1].split(",")[0].strip())
+                if any(n - ln <= int(dist) and any(dst & r[k] for k in roles) for ln, r in recent):
+                    pre += ["\t" + t for t in text.split(";")]
         for p in patches:
             if p == "none":
                 continue
@@ -59,6 +81,14 @@ def patch_kernel(lines, patches):
             elif p == "perm_nop" and s.startswith("v_permlane"):
                 pre.append("\ts_nop 7")
                 post.append("\ts_nop 7")
+            elif p.startswith(("before:", "after:")):      # before:PREFIX:TEXT / after:PREFIX:TEXT around every instruction that starts with PREFIX
+                kind, prefix, text = p.split(":", 2)
+                if s.startswith(prefix):
+                    (pre if kind == "before" else post).append("\t" + text)
+            elif p.startswith("range:"):          # range:A:B:TEXT  TEXT behind every instruction of kernel lines A..B
+                _, a, b, text = p.split(":", 3)
+                if int(a) <= n <= int(b) and s and not s.startswith((";", ".", "//")) and not s.endswith(":"):
+                    post.append("\t" + text.replace("\\n", "\n\t"))
             elif p.startswith("line:"):
                 _, ln, text = p.split(":", 2)
                 if int(ln) == n:

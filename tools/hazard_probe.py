@@ -36,6 +36,10 @@ FILLERS = {"nop": "s_nop 0", "valu": "v_mov_b32 v%d, v%d" % (F_V, F_VS), "ds": "
 # independent MFMAs as fillers (they serialise on the matrix pipe: one of them is worth several issue slots to a following MFMA)
 FILLERS["mfma32"] = "v_mfma_f32_16x16x32_bf16 v[194:197], v[10:13], v[18:21], v[194:197]"
 FILLERS["mfma16"] = "v_mfma_f32_16x16x16_bf16 v[198:201], v[10:11], v[18:19], v[198:201]"
+# round 6: transcendental and packed-fp32 vector instructions as fillers (the LDS-resident backward's softmax sits between an MFMA and
+# the vector instruction that reads its result: profiles/r06_bwd.md)
+FILLERS["trans"] = "v_exp_f32 v106, v%d" % F_VS
+FILLERS["pkf32"] = "v_pk_mul_f32 v[106:107], v[%d:%d], v[%d:%d]" % (F_V, F_VS, F_V, F_VS)
 GOLD = "s_nop 15\ns_nop 15"
 
 
@@ -106,6 +110,23 @@ def probes_for(name):
         out[("acg_half", 0)] = (m, mfma(half, D0, A0, B0, D0), copy_d)
         # the kernel's shape: M1 -> D (k = 32); 7 states; M2 = A B + D -> E (k = 32); FILL; M3 accumulates into E (k = 16)
         out[("acg_k3", 0)] = (m + "\n" + "\n".join(["s_nop 0"] * 7) + "\n" + mfma(name, E0, A0, B0, D0), mfma(half, E0, A0, B0, E0), copy_e)
+    # round 6: a two-step ACCUMULATING chain (M1 -> D; k1 vector fillers; M2 = A B + D -> D), then a vector read of D[r]: is the distance
+    # hipcc keeps behind M2 (the plain raw_d figure) enough when M2 itself has to wait for M1 (inside the pipe, or queued behind another wave's)?
+    for k1 in (0, 1, 2, 4, 7):
+        for r in sorted({0, 1, nc - 1}):
+            gap = "\n".join(["v_mov_b32 v%d, v%d" % (F_V, F_VS)] * k1)
+            out[("chr%d" % k1, r)] = (m + "\n" + gap + "\n" + mfma(name, D0, A0, B0, D0), "v_mov_b32 v%d, v%d" % (TMP, D0 + r), "v_mov_b32 v%d, v%d" % (R0, TMP))
+    # round 6: an LDS read that RETURNS INTO registers of an MFMA issued shortly before it (profiles/r06_bwd.md): the data comes back
+    # some 64+ cycles after the request, which is what hipcc (4 states for a late C read, nothing for D) and round 5's table (vector
+    # writes only) rely on — is that enough when the MFMA has to wait for a predecessor, or for the matrix pipe?
+    #   ldc: M reads C, ds_read into C[r]            ldcd: M1 -> D; M2 = A B + D -> E (has to wait for M1); ds_read into D[r] (M2's C)
+    #   ldd: M writes D, ds_read into D[r] (the LDS data must survive)      lddd: M1 -> D; M2 accumulates into D; ds_read into D[r]
+    for r in sorted({0, nc - 1}):
+        ld = "ds_read_b32 v%d, v%d"
+        out[("ldc", r)] = (m, ld % (C0 + r, F_DSA), copy_d)
+        out[("ldcd", r)] = (m + "\n" + mfma(name, E0, A0, B0, D0), ld % (D0 + r, F_DSA), copy_e)
+        out[("ldd", r)] = (m, ld % (D0 + r, F_DSA), copy_d)
+        out[("lddd", r)] = (m + "\n" + mfma(name, D0, A0, B0, D0), ld % (D0 + r, F_DSA), copy_d)
     out[("xd_a", 0)] = (m, mfma(name, E0, D0, B0, C0), copy_e)                                 # MFMA D -> next MFMA's A
     out[("xd_c", 0)] = (m, mfma(name, E0, A0, B0, D0), copy_e)                                 # MFMA D -> next MFMA's C, other destination
     return out
