@@ -106,6 +106,11 @@ def launch_units(kind, n_img, N, C, K):
       + projection    the to_q GEMM inside the kernel (sta_xattn_fwd_proj): + 2*2*N*C*C flop per image, + 2*C*C bytes (Wq) once."""
     flops = 4.0 * M_KEYS * C * N * (K + 2) * n_img
     byts = (8.0 * N * C + 4.0 * (K + 2) * M_KEYS * C + K * N) * n_img
+    if kind == "bwd":
+        # backward unit (SURVEY.md section 8d): F_bwd = 2 F (S = Q K^T, dP = dO V^T, dQ = dS K and the P V-sized products behind dcoef —
+        # the kernel gets those from sum_key P dP and issues THREE phases; the dense definition stays 2 F); bytes = 12 N C (read q and
+        # dO, write dq) + K, V once + the mask bytes + K floats
+        return 2.0 * flops, (12.0 * N * C + 4.0 * (K + 2) * M_KEYS * C + K * N) * n_img
     if kind == "proj":
         flops += 4.0 * N * C * C * n_img
         byts += 2.0 * C * C
@@ -175,20 +180,22 @@ def cpu_baseline(res, ddim_steps, K, n_calls):
     # 16 threads — one CCD's worth — and the median of 9 after 2 warm-ups do
     per_level, runs, level_threads = {}, 9, min(cores, 16)
     torch.set_num_threads(level_threads)
-    with torch.no_grad():
-        for name, N, C in LEVELS:
-            dim = int(N ** 0.5)
-            q = torch.randn(2, N, C)
-            k, v = torch.randn(K + 2, M_KEYS, C) * 0.78, torch.randn(K + 2, M_KEYS, C)
-            mask = orc.disc_masks([list(cc) for cc in DEFAULT_CENTRES[:K]], dim).reshape(K, N) if K else torch.zeros(0, N, dtype=torch.bool)
-            coef = torch.full((K,), 5.0 / max(K, 1))
-            ts = []
-            for r in range(runs + 2):
-                t0 = time.perf_counter()
-                orc.fused_xattn(q, k, v, mask, coef, 8, (C // 8) ** -0.5)
-                ts.append(time.perf_counter() - t0)
-            per_level["%s_N%d_C%d" % (name, N, C)] = round(statistics.median(ts[2:]) * 1e6, 1)
-    torch.set_num_threads(cores)
+    try:
+        with torch.no_grad():
+            for name, N, C in LEVELS:
+                dim = int(N ** 0.5)
+                q = torch.randn(2, N, C)
+                k, v = torch.randn(K + 2, M_KEYS, C) * 0.78, torch.randn(K + 2, M_KEYS, C)
+                mask = orc.disc_masks([list(cc) for cc in DEFAULT_CENTRES[:K]], dim).reshape(K, N) if K else torch.zeros(0, N, dtype=torch.bool)
+                coef = torch.full((K,), 5.0 / max(K, 1))
+                ts = []
+                for r in range(runs + 2):
+                    t0 = time.perf_counter()
+                    orc.fused_xattn(q, k, v, mask, coef, 8, (C // 8) ** -0.5)
+                    ts.append(time.perf_counter() - t0)
+                per_level["%s_N%d_C%d" % (name, N, C)] = round(statistics.median(ts[2:]) * 1e6, 1)
+    finally:
+        torch.set_num_threads(cores)
     # (2) configs[0] end to end on the reduced-width UNet
     small = build_sd_v1("cpu", torch.float32, with_vae=True, init_weights=False, unet_overrides=dict(model_channels=64))
     for p in small.parameters():
@@ -257,7 +264,7 @@ def _selfattn_optimistic_state():
     rate belongs to the optimistic loop only if both are 0."""
     from sta import ops
     res = []
-    for (d_, nbytes), f in ops._SA_FLAGS.items():
+    for (d_, _stream_, nbytes), f in ops._SA_FLAGS.items():
         w = f.view(torch.int32).cpu()
         res.append({"workgroups": (nbytes // 4) - 32, "sitting_out_calls": int(w[0]), "flagged_last_call": int(w[32:].sum())})
     return {"enabled": bool(ops.SELFATTN_OPTIMISTIC), "buffers": res}
@@ -351,7 +358,98 @@ def roofline_leg(model, dev, dt, dtype_name, I, K, lat, rec, centres):
     return roof
 
 
-def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps, K, checkpoint="auto", find=True, roofline=False):
+def roofline_bwd_leg(model, dev, dt, dtype_name, I, K, lat, rec, centres, n_calls=3, reps=20):
+    """`roofline_bwd` of the weight-optimisation leg: every sta_xattn_bwd launch (dq, dcoef of the fused op) of a TRACKED CFG UNet
+    call — forward under autograd exactly as the tracked epochs run it (sta.fused.tracked, the model's recomputation policy), then
+    backward of a scalar of its output — bracketed in situ by its own HIP-event pair on the launch stream, and re-issued warm.
+    Units: launch_units("bwd"). The forward launches of the same call (sta_xattn_fwd: the tracked path keeps q) are timed beside it."""
+    from sta import fused, ops, prompt_state
+    from sta.pipeline import conditionings
+    names = (rec["objects"] + ["object"] * K)[:K]
+    uc, c, local_c = conditionings(model, rec["prompt"], names, dt)
+    pair = lambda u, v: torch.stack([u, v], dim=1).reshape(2 * I, *u.shape[1:])
+    c_in = pair(uc.expand(I, -1, -1), c.expand(I, -1, -1)).contiguous()
+    t_in = torch.full((2 * I,), 981, device=dev, dtype=torch.long)
+    boxes = [centres] * I if I > 1 else centres
+    prompt_state.begin_prompt([local_c] * I if I > 1 else local_c, first_timestep=981)
+    by_call = bool(getattr(model, "sta_call_recompute", False))
+
+    def call():
+        x = torch.randn(I, 4, lat, lat, device=dev, requires_grad=True)
+        coef = (torch.full((I, K), 5.0 / max(K, 1), device=dev) if I > 1 else torch.full((K,), 5.0 / max(K, 1), device=dev)).requires_grad_(True)
+        with torch.enable_grad(), fused.tracked(by_call):
+            out = model.apply_model_extra(pair(x, x), 0, t_in, c_in, coef=coef, bboxs_curr=boxes)
+            out.float().square().mean().backward()
+
+    call()
+    ops.LAUNCH_LOG = []
+    try:
+        for _ in range(n_calls):
+            call()
+        torch.cuda.synchronize()
+        log = ops.LAUNCH_LOG
+    finally:
+        ops.LAUNCH_LOG = None
+    shapes = {}
+    for kind, n_img, N, C, K_, e0, e1, relaunch in log:
+        s = shapes.setdefault((kind, N, C), dict(us=[], relaunch=relaunch, n_img=n_img, K=K_))
+        s["us"].append(e0.elapsed_time(e1) * 1e3)
+    rows = {}
+    for (kind, N, C), s in shapes.items():
+        for _ in range(3):
+            s["relaunch"]()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            s["relaunch"]()
+        e1.record()
+        torch.cuda.synchronize()
+        flops, byts = launch_units(kind, s["n_img"], N, C, s["K"])
+        us = sum(s["us"]) / len(s["us"])
+        rows[(kind, N, C)] = dict(us=us, warm_us=e0.elapsed_time(e1) * 1e3 / reps, launches_per_call=len(s["us"]) // n_calls, flops=flops, bytes=byts)
+    bwd = {k_: v for k_, v in rows.items() if k_[0] == "bwd"}
+    if not bwd:
+        return {"error": "no sta_xattn_bwd launch was recorded in a tracked UNet call"}
+    dom = max(bwd, key=lambda k_: bwd[k_]["us"] * bwd[k_]["launches_per_call"])
+    d = bwd[dom]
+    traffic, traffic_note = None, "no committed PMC measurement for this launch"
+    pmc = os.path.join(REPO, "profiles", "xattn_bwd_hbm_traffic.json")
+    sha = source_sha(("sta_xattn_bwd.hip", "sta_xattn_dev.h"))
+    if os.path.exists(pmc):
+        ent = json.load(open(pmc)).get("by_kernel", {}).get("bwd_N%d_C%d_I%d" % (dom[1], dom[2], I) + ("" if dtype_name == "fp16" else "_" + dtype_name))
+        if ent and ent.get("source_sha") == sha:
+            traffic, traffic_note = ent["bytes_per_launch"], "rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate passes, kernel sources %s" % sha
+        elif ent:
+            traffic_note = "the committed PMC measurement belongs to other kernel sources (%s): refused as stale" % ent.get("source_sha")
+    t_hbm, t_mfma = d["bytes"] / (HBM_PEAK_GBS * 1e3), d["flops"] / (MFMA_PEAK_TFLOPS * 1e6)
+    table = {}
+    for (kind, N, C), v in sorted(bwd.items(), key=lambda kv: -kv[0][1]):
+        f = rows.get(("attn", N, C))
+        table["N%d_C%d" % (N, C)] = {"bwd_us": round(v["us"], 2), "bwd_warm_us": round(v["warm_us"], 2), "launches_per_call": v["launches_per_call"],
+                                     "hbm_frac": round(v["bytes"] / v["us"] / 1e3 / HBM_PEAK_GBS, 4), "mfma_frac": round(v["flops"] / v["us"] / 1e6 / MFMA_PEAK_TFLOPS, 4),
+                                     "fwd_us": round(f["us"], 2) if f else None, "fwd_warm_us": round(f["warm_us"], 2) if f else None,
+                                     "bwd_over_fwd": round(v["us"] / f["us"], 2) if f else None, "bwd_over_fwd_warm": round(v["warm_us"] / f["warm_us"], 2) if f else None}
+    all_us = sum(v["us"] * v["launches_per_call"] for v in bwd.values())
+    all_b = sum(v["bytes"] * v["launches_per_call"] for v in bwd.values())
+    all_f = sum(v["flops"] * v["launches_per_call"] for v in bwd.values())
+    bound = "hbm" if t_hbm >= t_mfma else "mfma"
+    return {"bound": bound, "achieved": d["bytes"] / d["us"] / 1e3 if bound == "hbm" else d["flops"] / d["us"] / 1e6,
+            "peak": HBM_PEAK_GBS if bound == "hbm" else MFMA_PEAK_TFLOPS, "unit": "GB/s" if bound == "hbm" else "TFLOP/s",
+            "frac": max(t_hbm, t_mfma) / d["us"], "traffic": traffic, "traffic_note": traffic_note, "dtype": dtype_name,
+            "kernel": "xattn_bwd_res_kernel + dcoef_reduce_kernel (sta_xattn_bwd: dq and dcoef of the fused op; S^T, dP^T, dQ^T per context, no attention "
+                      "outputs formed), N=%d C=%d, %d image(s) per launch, %d of the %d backward launches of a tracked UNet call"
+                      % (dom[1], dom[2], I, d["launches_per_call"], sum(v["launches_per_call"] for v in bwd.values())),
+            "bytes_per_launch": d["bytes"], "flops_per_launch": d["flops"], "avg_launch_us": d["us"], "warm_launch_us": d["warm_us"],
+            "hbm_gbps": d["bytes"] / d["us"] / 1e3, "hbm_frac": t_hbm / d["us"], "mfma_tflops": d["flops"] / d["us"] / 1e6, "mfma_frac": t_mfma / d["us"],
+            "how": "in situ: %d tracked CFG UNet calls (forward under autograd with the leg's recomputation policy, then backward), one HIP-event pair per "
+                   "sta_xattn_bwd call on the launch stream — the pair covers the backward kernel AND its dcoef reduction launch, RAW event times (an empty "
+                   "pair measures ~4.6 us here; nothing subtracted); warm: the same call re-issued %dx back to back" % (n_calls, reps),
+            "per_level": table,
+            "all_launches": {"n": sum(v["launches_per_call"] for v in bwd.values()), "sum_us": all_us, "hbm_frac": all_b / all_us / 1e3 / HBM_PEAK_GBS,
+                             "mfma_frac": all_f / all_us / 1e6 / MFMA_PEAK_TFLOPS}}
+
+
+def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps, K, checkpoint="auto", find=True, roofline=False, roofline_bwd=False):
     """A bounded side measurement on rank 0 after the headline run: the same workload with another 16-bit type, or
     BASELINE configs[2] (3 weight-optimisation epochs: two tracked trajectories with backward + one fixed-weight one).
     Builds its own model, reports images/s over `steps` timed steps after `warmup` untimed ones."""
@@ -406,6 +504,8 @@ def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps
            "warmup": warmup, "ms_per_step": 1e3 * el / steps}
     if roofline:
         out["roofline"] = roofline_leg(model, dev, dt, dtype_name, images, K, lat, prompts[0], centres)
+    if roofline_bwd and opt_epochs > 1 and K > 0:
+        out["roofline_bwd"] = roofline_bwd_leg(model, dev, dt, dtype_name, images, K, lat, prompts[0], centres)
     if opt_epochs:
         w0 = sampler.weight_init / max(K, 1)
         moved = float((r["W"] - w0).abs().max()) if K else 0.0
@@ -605,6 +705,8 @@ def main():
     out["config"]["selfattn_optimistic"] = _selfattn_optimistic_state()
     if not a.no_roofline:
         out["roofline"] = roofline_leg(model, dev, dt, a.dtype, I, K, lat, prompts[mine(0)[0]], centres)
+    if not a.no_roofline and a.opt_epochs > 1 and K > 0:
+        out["roofline_bwd"] = roofline_bwd_leg(model, dev, dt, a.dtype, I, K, lat, prompts[mine(0)[0]], centres)
     _phase("roofline leg done")
     if world == 1 and not a.no_side_runs and a.opt_epochs == 0:
         # reported beside the headline, never part of `value`: the other 16-bit type, and BASELINE configs[2]
@@ -630,7 +732,8 @@ def main():
             out["config3_shard"] = guarded(lambda: side_run(dev, a.dtype, 0, 8, a.steps, a.warmup, a.res, a.ddim_steps, K, roofline=not a.no_roofline))
             out["config3_shard"]["config"] = ("BASELINE configs[3] per-GPU shard: 64 mscoco prompts / 8 GPUs = 8 prompts per step on this GPU "
                                               "(--scaling strong at world 8), %d PLMS steps, %d objects, fixed weights" % (a.ddim_steps, K))
-        out["weight_optimisation"] = guarded(lambda: side_run(dev, a.dtype, 3, 16 if a.res <= 512 else 2, 3, 1, a.res, a.ddim_steps, K, find=find))
+        out["weight_optimisation"] = guarded(lambda: side_run(dev, a.dtype, 3, 16 if a.res <= 512 else 2, 3, 1, a.res, a.ddim_steps, K, find=find,
+                                                              roofline_bwd=not a.no_roofline))
         out["weight_optimisation"]["config"] = "BASELINE configs[2]: %dx%d, %d PLMS steps, %d objects, 3 epochs of per-step blend-weight optimisation" % (
             a.res, a.res, a.ddim_steps, K)
     _phase("side runs done")

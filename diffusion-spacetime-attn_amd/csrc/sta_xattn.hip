@@ -694,6 +694,11 @@ int sta_debug_set_trace(void* buf) {
 
 int sta_version(void) { return STA_VERSION; }
 
+#ifndef STA_BUILT_WITH
+#define STA_BUILT_WITH ""
+#endif
+const char* sta_built_with(void) { return STA_BUILT_WITH; }
+
 int sta_set_option(int key, int value) {
   g_err[0] = 0;
   if (key < 0 || key >= STA_OPT_COUNT) return fail(STA_E_ARG, "unknown option %d", key);

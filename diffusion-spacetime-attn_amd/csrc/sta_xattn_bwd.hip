@@ -61,13 +61,8 @@ __global__ __launch_bounds__(256) void dcoef_reduce_kernel(const float* __restri
 // the attention outputs A_i, A_u are not needed (see the file header), and the upstream of context 0,
 // dO0 - (sum_i coef_i mask_i) dO1, is formed in fp32 from the two dP^T products instead of being rounded to 16 bits.
 //
-// ONE WAVE PER SIMD, by construction (4 waves per workgroup, one workgroup per CU: the launch asks for more than half the LDS).
-// The eight-wave build of this kernel (two waves per SIMD; 86 vs 110 us at level 0, 16 images) was NOT bit-reproducible from run to
-// run at d = 40 with several tiles per workgroup: key 30's dS (tile 1, accumulator register 2) in the lanes of row 3 only, in
-// context 0's two-upstream walk only, off by +-2^-7, a handful of pixels per launch. Assembly-level bisection (tools/asm_patch_ab.py,
-// profiles/r06_bwd_race.md) showed it is no pair the measured hazard table knows (s_nop 7 behind every MFMA, every wait a full
-// wait: still there) and that any two wait states anywhere in front of one v_pk_add_f32 hide it; with one wave per SIMD every
-// build was bit-stable. Until that is understood the product does not run this code with a second wave on the SIMD.
+// ONE WAVE PER SIMD, by construction (4 waves per workgroup, one workgroup per CU: the launch asks for more than half the LDS), one
+// 16-pixel tile per wave: see launch_bwd_any for the wider builds that are not shipped and why.
 constexpr int BWD_MAXIT = 16;
 __host__ __device__ constexpr int bwd_frags(int ndt) { return 2 * NKT * nks_of(ndt) + NPS * ndt; }
 
@@ -88,21 +83,23 @@ struct SrdBwdFrags {
   __device__ __forceinline__ V8 kp(int f) const { return srd_load16<V8>(r, voff, soff + 1024u * (unsigned)(NFWD + NKF + f)); }
 };
 
-// One context for one 16-pixel tile: S^T and dP^T per key tile, softmax, delta, dS, dQ^T += KP dS^T.
+// One context for the QT 16-pixel tiles of a wave: S^T and dP^T per key tile, softmax, delta, dS, dQ^T += KP dS^T. Every operand
+// fragment that comes out of LDS (or L2) serves the QT tiles: with one wave per SIMD the second tile is what fills the first
+// one's LDS round trips and MFMA dependencies, and it halves the LDS reads per MFMA.
 // DUAL (context 0 where a disc touches the wave): a second walk over the VQ tiles with dO1 gives, tile by tile,
 // du1 = sum_key P (VQ.dO1) and dP^T -= wsum (VQ.dO1) in fp32 — four accumulator registers instead of a third S^T-sized set.
-// `gscale` is per lane (softmax scale x the pixel's blend weight); returns delta = sum_key P dP of the UNWEIGHTED upstream.
-// Operand fragments are requested per key tile / per head-dim tile right in front of their MFMAs and left to the compiler's
-// scheduler (two waves per SIMD cover the LDS round trips): explicit double buffers put every head dim over 256 registers.
-template <typename T, int NDT, bool FAST, bool DUAL, typename FR>
-__device__ __forceinline__ float attend_bwd_res(const FR fr, const typename Tr<T>::V8 (&qf)[nks_of(NDT)],
-                                                const typename Tr<T>::V8 (&gf)[nks_of(NDT)],
-                                                const typename Tr<T>::V8 (&g1)[nks_of(NDT)], const f32x4 kb4,
-                                                const float sl2e, const int g, const int M, const float gscale,
-                                                const float wsum, f32x4 (&dq)[NDT], float& du1) {
+// `gscale` is per lane (softmax scale x the pixel's blend weight); delta = sum_key P dP of the UNWEIGHTED upstream.
+template <typename T, int NDT, int QT, bool FAST, bool DUAL, typename FR>
+__device__ __forceinline__ void attend_bwd_res(const FR fr, const typename Tr<T>::V8 (&qf)[QT][nks_of(NDT)],
+                                               const typename Tr<T>::V8 (&gf)[QT][nks_of(NDT)],
+                                               const typename Tr<T>::V8 (&g1)[QT][nks_of(NDT)], const f32x4 kb4,
+                                               const float sl2e, const int g, const int M, const float (&gscale)[QT],
+                                               const float (&wsum)[QT], f32x4 (&dq)[QT][NDT], float (&delta)[QT], float (&du1)[QT]) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
-  f32x4 st[NKT], dp[NKT];
+  // (fragments are requested per key tile / head-dim tile right in front of their MFMAs and left to the compiler's scheduler, which
+  // hoists them as far as the registers allow: an explicit double buffer measured the same, 106.9 vs 105.0 us at level 0)
+  f32x4 st[QT][NKT], dp[QT][NKT];
 #pragma unroll
   for (int t = 0; t < NKT; ++t) {
     V8 kt[NKS], vt[NKS];
@@ -111,66 +108,81 @@ __device__ __forceinline__ float attend_bwd_res(const FR fr, const typename Tr<T
       kt[s] = fr.kq(t * NKS + s);
       vt[s] = fr.vq(t * NKS + s);
     }
-    f32x4 as = (FAST && t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 ap = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      as = Tr<T>::mfma(kt[s], qf[s], as);
-      ap = Tr<T>::mfma(vt[s], gf[s], ap);
+    for (int qt = 0; qt < QT; ++qt) {
+      f32x4 as = (FAST && t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 ap = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        as = Tr<T>::mfma(kt[s], qf[qt][s], as);
+        ap = Tr<T>::mfma(vt[s], gf[qt][s], ap);
+      }
+      st[qt][t] = as;
+      dp[qt][t] = ap;
     }
-    st[t] = as;
-    dp[t] = ap;
   }
-  const float inv = FAST ? softmax_biased(st, sl2e) : softmax_keys_fast(st, g, M, sl2e);
+  float inv[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) inv[qt] = FAST ? softmax_biased(st[qt], sl2e) : softmax_keys_fast(st[qt], g, M, sl2e);
   if constexpr (DUAL) {
-    float a = 0.f;
+    float a[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) a[qt] = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
       V8 vt[NKS];
 #pragma unroll
       for (int s = 0; s < NKS; ++s) vt[s] = fr.vq(t * NKS + s);
-      f32x4 ab = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int s = 0; s < NKS; ++s) ab = Tr<T>::mfma(vt[s], g1[s], ab);
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 ab = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a = __builtin_fmaf(st[t][r], ab[r], a);
-        dp[t][r] = __builtin_fmaf(-wsum, ab[r], dp[t][r]);
+        for (int s = 0; s < NKS; ++s) ab = Tr<T>::mfma(vt[s], g1[qt][s], ab);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[qt] = __builtin_fmaf(st[qt][t][r], ab[r], a[qt]);
+          dp[qt][t][r] = __builtin_fmaf(-wsum[qt], ab[r], dp[qt][t][r]);
+        }
       }
     }
-    du1 = bfly_sum(a) * inv;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) du1[qt] = bfly_sum(a[qt]) * inv[qt];
   }
-  float dl = 0.f;
+  V8 pb[QT][NPS];
 #pragma unroll
-  for (int t = 0; t < NKT; ++t)
+  for (int qt = 0; qt < QT; ++qt) {
+    float dl = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dl = __builtin_fmaf(st[t][r], dp[t][r], dl);
-  const float delta = bfly_sum(dl) * inv;
-  const float sc = inv * gscale;
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
-  for (int t = 0; t < NKT; ++t)
+      for (int r = 0; r < 4; ++r) dl = __builtin_fmaf(st[qt][t][r], dp[qt][t][r], dl);
+    delta[qt] = bfly_sum(dl) * inv[qt];
+    const float sc = inv[qt] * gscale[qt];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) st[t][r] = st[t][r] * sc * (dp[t][r] - delta);   // padded keys: st == 0
-  V8 pb[NPS];
-  tiles_to_b<T>(st, pb);
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) st[qt][t][r] = st[qt][t][r] * sc * (dp[qt][t][r] - delta[qt]);   // padded keys: st == 0
+    tiles_to_b<T>(st[qt], pb[qt]);
+  }
 #pragma unroll
   for (int u = 0; u < NDT; ++u) {
     V8 kp[NPS];
 #pragma unroll
     for (int s = 0; s < NPS; ++s) kp[s] = fr.kp(s * NDT + u);
 #pragma unroll
-    for (int s = 0; s < NPS; ++s) dq[u] = Tr<T>::mfma(kp[s], pb[s], dq[u]);
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int s = 0; s < NPS; ++s) dq[qt][u] = Tr<T>::mfma(kp[s], pb[qt][s], dq[qt][u]);
   }
-  return delta;
 }
 
-template <typename T, int NDT, int NWV, bool FAST>
+template <typename T, int NDT, int NWV, int QT, bool FAST>
 __global__ __launch_bounds__(64 * NWV, 1) void xattn_bwd_res_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
   constexpr int NKS = nks_of(NDT);
   constexpr int NKF = NKT * NKS, NFWD = fwd_frags(NDT), NALL = all_frags(NDT);
   constexpr int SB = bwd_frags(NDT) * FRAG;        // bytes of one LDS slot
-  constexpr int TP = 16 * NWV;
+  constexpr int TP = 16 * NWV * QT;                // pixels per tile: NWV waves x QT sub-tiles x 16
   constexpr int CPT = TP / 64;                     // 64-pixel chunks per tile
   constexpr int MAXCH = BWD_MAXIT * CPT;
   // block -> (image, tile group, head): XCD-contiguous over the whole grid (see xattn_fwd_staged_kernel)
@@ -233,78 +245,101 @@ __global__ __launch_bounds__(64 * NWV, 1) void xattn_bwd_res_kernel(const Params
   float dc[MAXK];
 #pragma unroll
   for (int i = 0; i < MAXK; ++i) dc[i] = 0.f;
+
+  // B operands of a tile: 16 B per lane at head-dim offset 32 s + 8 g of the pixel's head row, both rows of q and of dO; pixels
+  // >= N and offsets >= d are pushed out of the descriptor's range and read as zero. With ONE wave per SIMD nobody else covers the
+  // HBM round trip of these loads, so the operands (and the mask byte) of tile it + 1 are requested before tile it is computed.
+  struct TileOps {
+    V8 q0[QT][NKS], g0[QT][NKS], g1[QT][NKS], q1[QT][NKS];
+    unsigned own[QT];
+  };
+  auto request = [&](int it, TileOps& o) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      const int px = (wt + it * W) * TP + (wv * QT + qt) * 16 + c16;
+      const bool ok = it < iters && px < N;
+      o.own[qt] = p.mask[ok ? px : 0];
+      const unsigned base = ok ? (unsigned)px * row_bytes + (unsigned)(h * d + 8 * g) * (unsigned)sizeof(T) : 0xfffffff0u;
+#pragma unroll
+      for (int s = 0; s < NKS; ++s) {
+        const unsigned vo = (32 * s + 8 * g < d) ? base : 0xfffffff0u;
+        o.q0[qt][s] = srd_load16<V8>(q_srd, vo, 64u * s);
+        o.g0[qt][s] = srd_load16<V8>(g_srd, vo, 64u * s);
+        o.g1[qt][s] = srd_load16<V8>(g_srd, vo, row1 + 64u * s);
+        o.q1[qt][s] = srd_load16<V8>(q_srd, vo, row1 + 64u * s);
+      }
+    }
+  };
+  TileOps cur, nxt;
+  request(0, cur);
   wait_dma_and_sync();
 
   for (int it = 0; it < iters; ++it) {
-    const int px = (wt + it * W) * TP + wv * 16 + c16;
-    const bool valid = px < N;
-    unsigned ownbits = p.mask[valid ? px : 0];
-    // B operands: 16 B per lane at head-dim offset 32 s + 8 g of the pixel's head row; pixels >= N and offsets >= d are pushed
-    // out of the descriptor's range and read as zero
-    const unsigned base = valid ? (unsigned)px * row_bytes + (unsigned)(h * d + 8 * g) * (unsigned)sizeof(T) : 0xfffffff0u;
-    V8 q0[NKS], g0[NKS], g1[NKS], q1[NKS];
+    request(it + 1, nxt);
+    bool valid[QT];
+    unsigned ownbits[QT];
+    T* dqbase[QT];
+    float wsum[QT], gs[QT], zero[QT], delta[QT], du1[QT], unused[QT];
+    unsigned anybits = 0;                          // discs that touch this wave's pixels (wave-uniform)
 #pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      const unsigned vo = (32 * s + 8 * g < d) ? base : 0xfffffff0u;
-      q0[s] = srd_load16<V8>(q_srd, vo, 64u * s);
-      g0[s] = srd_load16<V8>(g_srd, vo, 64u * s);
-      if (NDT <= 8) g1[s] = srd_load16<V8>(g_srd, vo, row1 + 64u * s);
+    for (int qt = 0; qt < QT; ++qt) {
+      const int px = (wt + it * W) * TP + (wv * QT + qt) * 16 + c16;
+      valid[qt] = px < N;
+      dqbase[qt] = (T*)p.out + (size_t)(valid[qt] ? px : 0) * C + h * d;
+      ownbits[qt] = valid[qt] ? (cur.own[qt] & tile_bits) : 0u;
+      wsum[qt] = 0.f;
+      gs[qt] = scale;
+      zero[qt] = 0.f;
+      du1[qt] = 0.f;
+      for (unsigned bits = tile_bits; bits; bits &= bits - 1) {
+        const int i = __builtin_ctz(bits);
+        const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+        if (__ballot((ownbits[qt] >> i) & 1u)) anybits |= 1u << i;
+        wsum[qt] += ((ownbits[qt] >> i) & 1u) ? ci : 0.f;
+      }
     }
-    ownbits = valid ? (ownbits & tile_bits) : 0u;
-    float wsum = 0.f;
-    unsigned mybits = 0;                           // discs that touch this wave's 16 pixels (wave-uniform)
-    for (unsigned bits = tile_bits; bits; bits &= bits - 1) {
-      const int i = __builtin_ctz(bits);
-      const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
-      if (__ballot((ownbits >> i) & 1u)) mybits |= 1u << i;
-      wsum += ((ownbits >> i) & 1u) ? ci : 0.f;
-    }
-    T* dqbase = (T*)p.out + (size_t)(valid ? px : 0) * C + h * d;
-    f32x4 dq[NDT];
+    f32x4 dq[QT][NDT];
 #pragma unroll
-    for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float du1 = 0.f, unused = 0.f;
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) dq[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     // row 0: context 0 under dO0 - (sum_i coef_i mask_i) dO1
     const LdsBwdFrags<V8, NKF> f0{(const V8*)smem + lane};
-    if (mybits) {
-      if constexpr (NDT > 8) {   // d > 128: dO1 is requested for this walk and again for row 1 (a set held across context 0 spills)
+    if (anybits) attend_bwd_res<T, NDT, QT, FAST, true>(f0, cur.q0, cur.g0, cur.g1, kb4, sl2e, g, p.M, gs, wsum, dq, delta, du1);
+    else attend_bwd_res<T, NDT, QT, FAST, false>(f0, cur.q0, cur.g0, cur.g0, kb4, sl2e, g, p.M, gs, zero, dq, delta, unused);
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) g1[s] = srd_load16<V8>(g_srd, (32 * s + 8 * g < d) ? base : 0xfffffff0u, row1 + 64u * s);
-      }
-      attend_bwd_res<T, NDT, FAST, true>(f0, q0, g0, g1, kb4, sl2e, g, p.M, scale, wsum, dq, du1);
-    } else {
-      attend_bwd_res<T, NDT, FAST, false>(f0, q0, g0, g0, kb4, sl2e, g, p.M, scale, 0.f, dq, unused);
+    for (int qt = 0; qt < QT; ++qt) {
+      if (valid[qt]) store_row16<T, NDT>(dqbase[qt], dq[qt], g, d);
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) dq[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (valid) store_row16<T, NDT>(dqbase, dq, g, d);
-#pragma unroll
-    for (int u = 0; u < NDT; ++u) dq[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // row 1: the global prompt, then the local prompts whose disc touches the wave (q row 1 is requested only now: a fourth
-    // operand set held through context 0 is what spills at d >= 80)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) {
-      q1[s] = srd_load16<V8>(q_srd, (32 * s + 8 * g < d) ? base : 0xfffffff0u, row1 + 64u * s);
-      if (NDT > 8) g1[s] = srd_load16<V8>(g_srd, (32 * s + 8 * g < d) ? base : 0xfffffff0u, row1 + 64u * s);
-    }
+    // row 1: the global prompt, then the local prompts whose disc touches the wave
     const LdsBwdFrags<V8, NKF> f1{(const V8*)(smem + SB) + lane};
-    attend_bwd_res<T, NDT, FAST, false>(f1, q1, g1, g1, kb4, sl2e, g, p.M, scale, 0.f, dq, unused);
-    for (unsigned bits = mybits; bits; bits &= bits - 1) {
+    attend_bwd_res<T, NDT, QT, FAST, false>(f1, cur.q1, cur.g1, cur.g1, kb4, sl2e, g, p.M, gs, zero, dq, delta, unused);
+    for (unsigned bits = anybits; bits; bits &= bits - 1) {
       const int i = __builtin_ctz(bits);
       const int rank = __builtin_popcount(tile_bits & ((1u << i) - 1u));
-      const float wi = ((ownbits >> i) & 1u) ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i)) : 0.f;
-      float delta;
+      const float ci = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+      float gl[QT];
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) gl[qt] = ((ownbits[qt] >> i) & 1u) ? scale * ci : 0.f;
       if (rank < G - 2) {
         const LdsBwdFrags<V8, NKF> fl{(const V8*)(smem + (size_t)(2 + rank) * SB) + lane};
-        delta = attend_bwd_res<T, NDT, FAST, false>(fl, q1, g1, g1, kb4, sl2e, g, p.M, scale * wi, 0.f, dq, unused);
+        attend_bwd_res<T, NDT, QT, FAST, false>(fl, cur.q1, cur.g1, cur.g1, kb4, sl2e, g, p.M, gl, zero, dq, delta, unused);
       } else {
         const SrdBwdFrags<V8, NKF, NFWD> fl{kv_srd, (unsigned)lane * 16u, (unsigned)(2 + i) * (unsigned)ctx_stride};
-        delta = attend_bwd_res<T, NDT, FAST, false>(fl, q1, g1, g1, kb4, sl2e, g, p.M, scale * wi, 0.f, dq, unused);
+        attend_bwd_res<T, NDT, QT, FAST, false>(fl, cur.q1, cur.g1, cur.g1, kb4, sl2e, g, p.M, gl, zero, dq, delta, unused);
       }
-      const float part = (g == 0 && ((ownbits >> i) & 1u)) ? delta - du1 : 0.f;   // the sums are replicated over the four lane rows
+      float part = 0.f;                            // the sums are replicated over the four lane rows: row 0 speaks
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) part += (g == 0 && ((ownbits[qt] >> i) & 1u)) ? delta[qt] - du1[qt] : 0.f;
 #pragma unroll
       for (int j = 0; j < MAXK; ++j) dc[j] += (j == i) ? part : 0.f;
     }
-    if (valid) store_row16<T, NDT>(dqbase + (size_t)N * C, dq, g, d);
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+      if (valid[qt]) store_row16<T, NDT>(dqbase[qt] + (size_t)N * C, dq[qt], g, d);
+    cur = nxt;
   }
   // per-wave dcoef partials -> workspace [K][gridDim.x * NWV] (fixed slot per wave: deterministic)
 #pragma unroll
@@ -320,10 +355,10 @@ __global__ __launch_bounds__(64 * NWV, 1) void xattn_bwd_res_kernel(const Params
 
 // Launch geometry of the LDS-resident backward: slots by LDS capacity, one workgroup per CU, enough strided tiles per
 // workgroup that one round of workgroups covers the launch (at most BWD_MAXIT).
-template <typename T, int NDT, int NWV>
+template <typename T, int NDT, int NWV, int QT>
 int launch_bwd_res(const Params& p0, float* dcoef, hipStream_t st) {
   constexpr int SB = bwd_frags(NDT) * FRAG;
-  constexpr int TP = 16 * NWV;
+  constexpr int TP = 16 * NWV * QT;
   static_assert(2 * SB <= 160 * 1024, "contexts 0 and 1 must fit");
   Params p = p0;
   int G = (160 * 1024) / SB;
@@ -350,8 +385,8 @@ int launch_bwd_res(const Params& p0, float* dcoef, hipStream_t st) {
     return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "bwd resident launch: %s", hipGetErrorString(e));
   };
   static StaLdsAttr attr_fast, attr_any;
-  const int rc = p.M > 16 * (NKT - 1) ? launch(xattn_bwd_res_kernel<T, NDT, NWV, true>, attr_fast)
-                                      : launch(xattn_bwd_res_kernel<T, NDT, NWV, false>, attr_any);
+  const int rc = p.M > 16 * (NKT - 1) ? launch(xattn_bwd_res_kernel<T, NDT, NWV, QT, true>, attr_fast)
+                                      : launch(xattn_bwd_res_kernel<T, NDT, NWV, QT, false>, attr_any);
   if (rc) return rc;
   if (p.K > 0) {
     hipLaunchKernelGGL(dcoef_reduce_kernel, dim3(p.K, p.n_img), dim3(256), 0, st, p.aux, dcoef, nwg * NWV);
@@ -361,14 +396,21 @@ int launch_bwd_res(const Params& p0, float* dcoef, hipStream_t st) {
   return STA_OK;
 }
 
-
-// STA_OPT_BWD_WAVES = 8 reaches the eight-wave build where the library was compiled with -DSTA_EXPERIMENT_BWD8 (tools/dbg only).
+// The product launches 4 waves x ONE 16-pixel tile per wave, one workgroup per CU. The two wider builds — eight waves (two per SIMD),
+// or two tiles per wave — are 14 - 27 % faster at level 0 (101 / 86 vs 117 us at 16 images) and are NOT shipped: both give a handful
+// of wrong values per launch, at ONE dS element of the tile (lane row 3, accumulator register 2 of one key tile: key 30 in one
+// build, key 62 in the other), different pixels every run in the eight-wave build. profiles/r06_bwd_race.md holds what was ruled out
+// (every pair of the measured hazard table, waits, the packed-fp32 chain replayed alone, LDS-return and chained-MFMA probes) and
+// tools/dbg/ the scripts; -DSTA_EXPERIMENT_BWD_WIDE compiles them in for that work (STA_OPT_BWD_WAVES = 8, STA_OPT_STAGED_QT = 2).
 template <typename T, int NDT>
 int launch_bwd_any(const Params& p, float* dcoef, hipStream_t st) {
-#ifdef STA_EXPERIMENT_BWD8
-  if (g_sta_opt[STA_OPT_BWD_WAVES] == 8) return launch_bwd_res<T, NDT, 8>(p, dcoef, st);
+#ifdef STA_EXPERIMENT_BWD_WIDE
+  if (g_sta_opt[STA_OPT_BWD_WAVES] == 8) return launch_bwd_res<T, NDT, 8, 1>(p, dcoef, st);
+  if constexpr (NDT <= 6) {
+    if (g_sta_opt[STA_OPT_STAGED_QT] == 2) return launch_bwd_res<T, NDT, 4, 2>(p, dcoef, st);
+  }
 #endif
-  return launch_bwd_res<T, NDT, 4>(p, dcoef, st);
+  return launch_bwd_res<T, NDT, 4, 1>(p, dcoef, st);
 }
 
 template <typename T>

@@ -179,11 +179,21 @@ def to_out_add_layernorm_ofrag(x, blended_ofrag, wo_packed, bias, ln_weight, ln_
 ROWGEMM_MIN_ROWS = 65536
 
 
+def _version(t):
+    """t._version, or None for tensors without a version counter (tensors created under torch.inference_mode() raise on the
+    attribute): without one an in-place update cannot be noticed, so nothing that depends on it is cached or trusted."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 def _producer_stats(x):
     """The per-channel sums the producing kernel left on `x` — only while x still holds what that kernel wrote (an in-place update
     since then bumps the tensor's version and the sums are ignored: the consumer then takes its own statistics pass)."""
     st = getattr(x, "_sta_stats", None)
-    return st[1] if st is not None and st[0] == x._version else None
+    v = _version(x)
+    return st[1] if st is not None and v is not None and st[0] == v else None
 
 
 ROWGEMM_MAX_BYTES = 0xfffffff0 - 1     # what one launch of these passes addresses per tensor (32-bit buffer offsets)
@@ -330,14 +340,15 @@ def conv3x3_nhwc(x, w_packed, Cout, up2=False, bias=None, res=None, stats=False)
                                      0 if part is None else part.data_ptr() + b0 * slots * Cout * 8, n, H, W, Cin, Cout,
                                      int(bool(up2)), _DT[x.dtype], _stream()), "sta_conv3x3_nhwc")
     if part is not None:
-        out._sta_stats = (out._version, _finalize_stats(part, B, slots, Cout))
+        if _version(out) is not None:           # (inference tensors: no producer statistics, the consumer takes its own pass)
+            out._sta_stats = (out._version, _finalize_stats(part, B, slots, Cout))
     return out
 
 
 def packed_conv_weight(owner, conv):
     """conv.weight as sta_conv3x3_nhwc streams it, cached on the owning module and repacked only when the weight tensor changes."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.dtype)
+    key = (w.data_ptr(), _version(w), w.dtype)
     cache = owner.__dict__.setdefault("_sta_conv_cache", {})
     hit = cache.get(id(conv))
     if hit is None or hit[0] != key:
@@ -467,7 +478,8 @@ def linear_rows(x, w_packed, N, bias=None, res=None, stats_rows=None):
         part = torch.empty((n_img + 1, slots, N, 2), dtype=torch.float32, device=x.device)
         lib.check(lib.load().sta_linear_rows_stats(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(),
                                                    part.data_ptr(), stats_rows, R, K, N, _DT[x.dtype], _stream()), "sta_linear_rows_stats")
-        out._sta_stats = (out._version, _finalize_stats(part, n_img, slots, N))
+        if _version(out) is not None:
+            out._sta_stats = (out._version, _finalize_stats(part, n_img, slots, N))
         return out
     lib.check(lib.load().sta_linear_rows(x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(bias), _ptr(res), out.data_ptr(), R, K, N,
                                          _DT[x.dtype], _stream()), "sta_linear_rows")
@@ -476,7 +488,7 @@ def linear_rows(x, w_packed, N, bias=None, res=None, stats_rows=None):
 
 def packed_linear_weight(owner, key_obj, weight):
     """weight as sta_linear_rows streams it, cached on the owning module and repacked only when the weight tensor changes."""
-    key = (weight.data_ptr(), weight._version, weight.dtype)
+    key = (weight.data_ptr(), _version(weight), weight.dtype)
     cache = owner.__dict__.setdefault("_sta_linear_cache", {})
     hit = cache.get(id(key_obj))
     if hit is None or hit[0] != key:
@@ -665,7 +677,7 @@ def conv3x3_tracked_supported(x, weight):
 def conv3x3_tracked(owner, conv, x):
     """conv(x) WITHOUT its bias for a frozen 3x3 nn.Conv2d under autograd (callers fold the bias into the pass that follows)."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.dtype)
+    key = (w.data_ptr(), _version(w), w.dtype)
     cache = owner.__dict__.setdefault("_sta_conv_bwd_cache", {})
     hit = cache.get(id(conv))
     if hit is None or hit[0] != key:

@@ -40,6 +40,7 @@ _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_s
 SYMBOLS = {
     "sta_version": (_i, []),
     "sta_last_error": (ctypes.c_char_p, []),
+    "sta_built_with": (ctypes.c_char_p, []),
     "sta_set_option": (_i, [_i, _i]),
     "sta_xattn_packed_kv_bytes": (_sz, [_i, _i, _i]),
     "sta_xattn_pack_kv": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
@@ -109,12 +110,24 @@ def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    deps = SOURCES + [os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h"), os.path.join(CSRC, "sta_xattn_proj3.h"), os.path.join(CSRC, "sta_selfattn_dev.h")]
+    deps = SOURCES + [os.path.join(_HERE, "isa_lint.py"), os.path.join(INCLUDE, "sta_xattn.h"), os.path.join(INCLUDE, "sta_unet.h"), os.path.join(CSRC, "sta_internal.h"), os.path.join(CSRC, "sta_xattn_dev.h"), os.path.join(CSRC, "sta_xattn_proj3.h"), os.path.join(CSRC, "sta_selfattn_dev.h")]
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
 LINT_LOG = os.path.join(CSRC, ".isa_lint.log")
-_LLVM_BIN = "/opt/rocm/lib/llvm/bin"
+
+
+def _llvm_bin(hipcc):
+    """Directory of the clang / lld / clang-offload-bundler that belong to `hipcc` (the same ROCm prefix: no mixed toolchain)."""
+    for root in (os.environ.get("ROCM_PATH"), os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "/opt/rocm"):
+        if root and os.path.exists(os.path.join(root, "lib", "llvm", "bin", "clang")):
+            return os.path.join(root, "lib", "llvm", "bin")
+    raise StaLibraryError("no lib/llvm/bin/clang beside %s (set ROCM_PATH)" % hipcc)
+
+
+def _hipcc_headline(hipcc):
+    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
+    return ver[0] if ver else "hipcc ?"
 
 
 def _run(cmd):
@@ -129,6 +142,7 @@ def _compile_checked(hipcc, base, flags, src, obj, workdir, verbose):
     of another shape), then assembler -> lld -> bundle -> host compile with that device image: the steps `hipcc -c` runs itself,
     with the text pass in the middle. -> [(line, wait states inserted, rule)]"""
     from . import isa_lint
+    _LLVM_BIN = _llvm_bin(hipcc)
     stem = os.path.join(workdir, os.path.basename(src))
     if verbose:
         print(" ".join(base + flags + ["--cuda-device-only", "-S", src]))
@@ -145,7 +159,8 @@ def _compile_checked(hipcc, base, flags, src, obj, workdir, verbose):
     _run([_LLVM_BIN + "/lld", "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", stem + ".dev.o", "-o", stem + ".dev.out"])
     _run([_LLVM_BIN + "/clang-offload-bundler", "-type=o", "-bundle-align=4096", "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950",
           "-input=/dev/null", "-input=" + stem + ".dev.out", "-output=" + stem + ".hipfb"])
-    _run(base + flags + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb", "-o", obj])
+    host_defs = ['-DSTA_BUILT_WITH="%s"' % _hipcc_headline(hipcc).replace('"', "'")] if os.path.basename(src) == "sta_xattn.hip" else []
+    _run(base + flags + host_defs + ["--cuda-host-only", "-c", src, "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb", "-o", obj])
     return log
 
 
@@ -175,9 +190,8 @@ def build(force=False, verbose=False):
         os.replace(LIB_PATH + ".tmp", LIB_PATH)
     finally:
         shutil.rmtree(workdir, ignore_errors=True)
-    ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
     with open(LINT_LOG, "w") as fh:
-        fh.write("# %s\n" % (ver[0] if ver else "hipcc ?"))
+        fh.write("# %s\n" % _hipcc_headline(hipcc))
         for src, log in zip(SOURCES, logs):
             fh.write("%s: %d site(s) padded\n" % (os.path.basename(src), len(log)))
             for ln, states, rule in sorted(log):
@@ -194,16 +208,16 @@ VALIDATED_HIPCC = "HIP version: 7.2."
 
 
 def built_with():
-    """First line of csrc/.isa_lint.log: the `hipcc --version` headline of the build that produced the library ('' if unknown)."""
+    """The `hipcc --version` headline of the build that produced the LOADED library, read back from the library itself (sta_built_with;
+    csrc/.isa_lint.log — what the lint padded — is a by-product of the build, not tracked and not what is trusted). '' if unknown."""
     try:
-        with open(LINT_LOG) as fh:
-            return fh.readline().lstrip("# ").strip()
-    except OSError:
+        return load().sta_built_with().decode()
+    except (StaLibraryError, AttributeError):
         return ""
 
 
-def toolchain_validated():
-    return built_with().startswith(VALIDATED_HIPCC)
+def toolchain_validated(headline=None):
+    return (built_with() if headline is None else headline).startswith(VALIDATED_HIPCC)
 
 
 _lib = None
@@ -236,9 +250,18 @@ def load():
     return lib
 
 
+_options = {}
+
+
 def set_option(key, value):
     """sta_set_option: override a launch heuristic (tests / tools only; 0 = automatic)."""
     check(load().sta_set_option(int(key), int(value)), "sta_set_option")
+    _options[int(key)] = int(value)
+
+
+def get_option(key):
+    """The value this process last gave sta_set_option for `key` (0 = automatic / never set; the C-ABI has no getter)."""
+    return _options.get(int(key), 0)
 
 
 def last_error():

@@ -128,7 +128,7 @@ def _check_inputs(q, packed, mask, coef):
 
 SELFATTN_ENABLED = True      # A/B switch for tools/ (False: attn1 through PyTorch SDPA); nothing reads the environment
 
-# bench.py's roofline leg: when set to a list, every forward launch is bracketed IN SITU (inside a real UNet call) by its
+# bench.py's roofline legs: when set to a list, every forward launch (and every sta_xattn_bwd call: kind "bwd") is bracketed IN SITU (inside a real UNet call) by its
 # own HIP-event pair on the launch stream and (kind, n_img, N, C, K, e0, e1, relaunch) is appended; `relaunch()` re-issues
 # exactly that C-ABI call on the same tensors (for warm, back-to-back timing beside the in-situ figure).
 LAUNCH_LOG = None
@@ -174,9 +174,11 @@ def xattn_backward(q, packed, mask, coef, dout, scale):
     dq = torch.empty_like(q)
     dcoef = torch.empty(I * K, dtype=torch.float32, device=q.device)
     ws = torch.empty(L.sta_xattn_bwd_workspace_bytes(I, N, packed.heads, K), dtype=torch.uint8, device=q.device)
-    _lib.check(L.sta_xattn_bwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), dout.data_ptr(),
-                               dq.data_ptr(), _ptr(dcoef) if K else 0, ws.data_ptr(), I, N, C, packed.heads,
-                               packed.M, K, float(scale), _dtype_code(q), _stream(q)), "sta_xattn_bwd")
+    def launch():
+        _lib.check(L.sta_xattn_bwd(q.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32), dout.data_ptr(),
+                                   dq.data_ptr(), _ptr(dcoef) if K else 0, ws.data_ptr(), I, N, C, packed.heads,
+                                   packed.M, K, float(scale), _dtype_code(q), _stream(q)), "sta_xattn_bwd")
+    _logged("bwd", I, N, C, K, launch)
     return dq, dcoef
 
 
@@ -245,8 +247,22 @@ def pack_kv_proj(k, v, heads, out=None, n_img=1):
     return PackedKV(buf, n_ctx, heads, M, C, k.dtype, n_img)
 
 
+def _ensure_toolchain_checked():
+    """Run the head-pair kernel's self-check (once per process) BEFORE any producer is told to write fragment order: a library built by
+    an unvalidated hipcc release whose pair kernel disagrees switches the pair kernel off (STA_OPT_PROJ_PAIR = 2), and
+    sta_xattn_fwd_proj_qfrag_supported then answers no — so the block takes the row-major chain from its first call on."""
+    global _TOOLCHAIN_CHECKED
+    if _TOOLCHAIN_CHECKED is None:
+        if _lib.toolchain_validated():
+            _TOOLCHAIN_CHECKED = True
+        elif torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            toolchain_self_check()
+
+
 def proj_qfrag_supported(C, heads, M, K, N, n_img):
-    """Launches whose y the head-pair kernel reads in query-fragment order (sta_xattn_fwd_proj_qfrag_supported)."""
+    """Launches whose y the head-pair kernel reads in query-fragment order (sta_xattn_fwd_proj_qfrag_supported). This is where a block
+    decides its layouts (ldm.modules.attention prepare step), so the toolchain self-check runs here, not at the first launch."""
+    _ensure_toolchain_checked()
     return bool(_lib.load().sta_xattn_fwd_proj_qfrag_supported(n_img, N, C, heads, M, K))
 
 
@@ -322,7 +338,7 @@ def proj_ofrag_supported(C, heads, dtype=torch.float16):
 _TOOLCHAIN_CHECKED = None
 
 
-def toolchain_self_check(force=False):
+def toolchain_self_check(force=False, device=None):
     """The head-pair kernel of level 0 (csrc/sta_xattn_proj3.hip) sits on MFMA hazard windows that hipcc does not pad by itself; the build's
     lint enforces the ones measured with hipcc 7.2. A library built by ANOTHER release (lib.toolchain_validated() is False) is therefore
     checked once per process before its first use — and always when `force`: a small level-0 problem through the pair kernel's three
@@ -336,18 +352,19 @@ def toolchain_self_check(force=False):
     import warnings
     _TOOLCHAIN_CHECKED = True                      # (the launches below re-enter xattn_forward_proj)
     ok = True
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    prev = _lib.get_option(_lib.OPT_PROJ_PAIR)      # a tests / tools override of the pair-kernel switch survives the check
     for dtype in (torch.float16, torch.bfloat16):
         g = torch.Generator().manual_seed(11)
         N, C, heads, K, M = 1024, 320, 8, 2, 77
-        y = torch.randn(2, N, C, generator=g).to(dtype).cuda()
-        wq = (torch.randn(C, C, generator=g) / C ** 0.5).to(dtype).cuda()
-        k = (torch.randn(K + 2, M, C, generator=g) * 0.7).to(dtype).cuda()
-        v = torch.randn(K + 2, M, C, generator=g).to(dtype).cuda()
-        mb = mask_bits(torch.rand(K, N, generator=g) < 0.3).cuda()
-        coef = (torch.rand(K, generator=g) * 3 + 0.5).cuda()
+        y = torch.randn(2, N, C, generator=g).to(dtype).to(dev)
+        wq = (torch.randn(C, C, generator=g) / C ** 0.5).to(dtype).to(dev)
+        k = (torch.randn(K + 2, M, C, generator=g) * 0.7).to(dtype).to(dev)
+        v = torch.randn(K + 2, M, C, generator=g).to(dtype).to(dev)
+        mb = mask_bits(torch.rand(K, N, generator=g) < 0.3).to(dev)
+        coef = (torch.rand(K, generator=g) * 3 + 0.5).to(dev)
         wqf, kvp = pack_wq(wq, heads), pack_kv_proj(k, v, heads, n_img=1)
         scale = (C // heads) ** -0.5
-        prev = 0                                    # back to automatic afterwards (the option is a tests / tools override)
         try:
             _lib.set_option(_lib.OPT_PROJ_PAIR, 2)
             ref = xattn_forward_proj(y, wqf, kvp, mb, coef, scale).float()
@@ -376,11 +393,8 @@ def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofr
     leaves in out-fragment order for fused.to_out_add_layernorm_ofrag (from_ofrag restores row-major)."""
     I, N, C, K = _check_inputs(y, packed, mask, coef)
     L = _lib.load()
-    if _TOOLCHAIN_CHECKED is None:
-        if _lib.toolchain_validated():
-            globals()["_TOOLCHAIN_CHECKED"] = True
-        elif not torch.cuda.is_current_stream_capturing():
-            toolchain_self_check()
+    if not qfrag:                  # (fragment-order callers asked proj_qfrag_supported first; a row-major first call checks here)
+        _ensure_toolchain_checked()
     y = y.contiguous()
     coef32 = coef.detach().to(torch.float32).contiguous() if K else None
     maskc = mask.contiguous() if K else None
@@ -455,6 +469,12 @@ def to_sfrag(x):
     return t.contiguous().view(x.shape)
 
 
+def reset_selfattn_optimistic_state():
+    """Forget the optimistic self-attention kernel's per-(device, stream, shape) state words (calls still sitting the optimistic loop out):
+    the next call of every shape starts optimistic again. Results never depend on the state — it only selects between two exact loops."""
+    _SA_FLAGS.clear()
+
+
 SELFATTN_OPTIMISTIC = os.environ.get("STA_SELFATTN_OPTIMISTIC", "1") != "0"      # (env: A/B in tools/sa_opt_bench_ab.sh) self-attention at level 0 (both 16-bit types) through sta_selfattn_fwd_optimistic (profiles/r05_selfattn.md)
 _SA_FLAGS = {}
 
@@ -486,7 +506,7 @@ def self_attention(q, k, vt, heads, scale, sfrag=False):
         # the pipelined kernel's shapes: key loop from the workgroup's own block, no running maximum behind a tile's first key block + a repair launch for the workgroups whose
         # denominators left the safe range (sta_selfattn_fwd_optimistic); one flag word per workgroup, cached per device
         nbytes = L.sta_selfattn_optimistic_flags_bytes(B, N, heads)
-        key = (q.device, nbytes)
+        key = (q.device, _stream(q), nbytes)     # per stream: two concurrent calls must not share flag words or the two state words
         flags = _SA_FLAGS.get(key)
         if flags is None:
             flags = _SA_FLAGS[key] = torch.zeros(nbytes, dtype=torch.uint8, device=q.device)      # zero once: the leading state words live across calls

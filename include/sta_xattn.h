@@ -46,6 +46,11 @@ enum {
 #define STA_MAX_HEAD_DIM 160 /* d = C / heads <= 160, d % 8 == 0     */
 #define STA_MAX_OBJECTS 8   /* K <= 8                                 */
 
+/* The `hipcc --version` headline of the toolchain that built this library ("" if the build did not record it). The level-0 kernels sit on
+ * MFMA hazard windows measured with one hipcc release; the host side (sta.lib.toolchain_validated) checks a library built by another
+ * release numerically before its first use instead of trusting the lint alone. */
+const char* sta_built_with(void);
+
 /* Library version (STA_VERSION of the build). */
 int sta_version(void);
 
@@ -74,7 +79,7 @@ enum {
                                C = 640, d = 80): 2 = refuse (the block then takes the GEMM + sta_xattn_fwd); default: local contexts from L2 */
   STA_OPT_BWD_KERNEL = 11,  /* unused since 0.5.0 (one backward kernel) */
   STA_OPT_BWD_SLOTS = 12,   /* sta_xattn_bwd: at most this many contexts in LDS (>= 2), the other local ones from L2 */
-  STA_OPT_BWD_WAVES = 13,   /* experiment builds only (-DSTA_EXPERIMENT_BWD8): 8 = eight waves per workgroup */
+  STA_OPT_BWD_WAVES = 13,   /* experiment builds only (-DSTA_EXPERIMENT_BWD_WIDE): 8 = eight waves per workgroup */
   STA_OPT_COUNT = 14
 };
 int sta_set_option(int key, int value);

@@ -171,7 +171,7 @@ def test_bwd_lds_resident_matches_oracle(N, C, heads, K, I, tiles, slots, M, dty
 def test_bwd_is_bit_reproducible(N, C, heads, K, I, dtype):
     """Eight launches of one backward problem give identical bits (dq and dcoef). The eight-wave build of this kernel did not, at
     d = 40 with several tiles per workgroup (a handful of row-0 pixels inside the discs, different ones every run:
-    profiles/r06_bwd_race.md) — which is why the product runs it with one wave per SIMD, and why this test exists."""
+    profiles/r06_bwd_race.md) — which is why the product runs four waves x one tile, and why this test exists."""
     from sta import ops
     dev = "cuda"
     cases = [_case(N, C, heads, K, dtype, seed=1 + i) for i in range(min(I, 2))]
@@ -548,9 +548,9 @@ def test_self_attention_optimistic_and_its_repair_launch(sfrag, dtype):
                 k[:, key] = (20.0 if bf else 3.0) * q[:, px]
         k = k.to(dtype)
         qd, kd, vtd = qs.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda()
-        fkey = (qd.device, lib.load().sta_selfattn_optimistic_flags_bytes(B, N, heads))
-        assert fkey[1] == (B * heads * ((N + 127) // 128) + 32) * 4      # the two state words have a 128-byte line to themselves
-        ops._SA_FLAGS[fkey] = torch.zeros(fkey[1], dtype=torch.uint8, device=qd.device)      # words beyond the chosen grid stay zero
+        fkey = (qd.device, torch.cuda.current_stream(qd.device).cuda_stream, lib.load().sta_selfattn_optimistic_flags_bytes(B, N, heads))
+        assert fkey[2] == (B * heads * ((N + 127) // 128) + 32) * 4      # the two state words have a 128-byte line to themselves
+        ops._SA_FLAGS[fkey] = torch.zeros(fkey[2], dtype=torch.uint8, device=qd.device)      # words beyond the chosen grid stay zero
         out = ops.self_attention(qd, kd, vtd, heads, ops.LN2, sfrag=sfrag)
         torch.cuda.synchronize()
         words = ops._SA_FLAGS[fkey].view(torch.int32).cpu()
@@ -983,7 +983,7 @@ def test_fwd_proj_rejects_what_it_cannot_hold():
 def test_toolchain_self_check_passes_and_is_wired():
     """sta.ops.toolchain_self_check: the level-0 head-pair kernel in its three layouts against the one-head-per-workgroup kernel, both
     16-bit types — what a library built by a hipcc release other than the validated one runs before its first projection-fused launch
-    (sta.lib.toolchain_validated reads the release from csrc/.isa_lint.log). The shipped library must pass it."""
+    (sta.lib.toolchain_validated reads the release from the library: sta_built_with). The shipped library must pass it."""
     from sta import lib, ops
     assert lib.built_with().startswith("HIP version")
     assert ops.toolchain_self_check(force=True) is True

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd")); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sta import lib, ops
 from test_kernel_gpu import _case
-N, C, heads, K, dtype = 9216, 320, 8, 2, torch.float16
+N, C, heads, K, dtype = int(os.environ.get("DN", "9216")), 320, 8, 2, torch.float16
 d = C // heads
 q, k, v, mask, coef = _case(N, C, heads, K, dtype, seed=1)
 scale = d ** -0.5
@@ -14,9 +14,9 @@ g = torch.Generator().manual_seed(7)
 dout = torch.randn(2, N, C, generator=g).to(dtype)
 packed = ops.pack_kv(k.cuda(), v.cuda(), heads)
 mb = ops.mask_bits(mask).cuda()
-lib.set_option(lib.OPT_BWD_KERNEL, 2)
+lib.set_option(lib.OPT_STAGED_QT, 1)
 ref = ops.xattn_backward(q.cuda(), packed, mb, coef.cuda(), dout.cuda(), scale)[0][0].float().cpu()
-lib.set_option(lib.OPT_BWD_KERNEL, 1)
+lib.set_option(lib.OPT_STAGED_QT, 0)
 wsum = (mask.double() * coef.double()[:, None]).sum(0)
 K0, V0 = k[0].double().view(77, heads, d), v[0].double().view(77, heads, d)
 for rep in range(2):
@@ -82,7 +82,27 @@ for rep in range(2):
                     bestg = (float(rr_), t, gg, (sol / scale).tolist(), dS_true[idx].tolist(), P[idx].tolist())
         print("     single key: k=%d unexplained %.2f (dS err %.3g, true dS %.3g, P %.3g) | group tile %d row %d unexplained %.2f dS err %s true %s P %s" % (
             kb, rem[kb], c[kb] / scale, dS_true[kb], P[kb], bestg[1], bestg[2], bestg[0], ["%.3g" % x for x in bestg[3]], ["%.3g" % x for x in bestg[4]], ["%.3g" % x for x in bestg[5]]))
-        k30 = 30
+        k30 = kb
+        # which other value would key kb's (dp - delta) have to be replaced by to explain the error? candidates: the same quantity of the
+        # other keys of the lane row (r = 0..3 of every tile: 16 t + 4 g + r)
+        delta_true = (P * dp_true).sum()
+        need = (dS_true[kb] + c[kb] / scale) / P[kb]            # the (dp - delta) the kernel must have used, if P is right
+        gg = (kb % 16) // 4
+        cands = {"t%d r%d" % (t, rr): float(dp_true[16 * t + 4 * gg + rr] - delta_true) for t in range(5) for rr in range(4) if 16 * t + 4 * gg + rr < 77}
+        bestc = min(cands, key=lambda n_: abs(cands[n_] - need))
+        needP = (dS_true[kb] + c[kb] / scale) / (dp_true[kb] - delta_true)     # or the P it must have used, if dp - delta is right
+        candP = {"t%d r%d" % (t, rr): float(P[16 * t + 4 * gg + rr]) for t in range(5) for rr in range(4) if 16 * t + 4 * gg + rr < 77}
+        bestP = min(candP, key=lambda n_: abs(candP[n_] - needP))
+        vg_lo, vg_hi = float(V0[kb, h, :32] @ g0[:32]), float(V0[kb, h, 32:] @ g0[32:])
+        kq_lo, kq_hi = float(scale * (Kh[kb, :32] @ qv[:32])), float(scale * (Kh[kb, 32:] @ qv[32:]))
+        import math as _m
+        print("     key %d: if dp is off: delta_dp = %+.4f  [V.g0 dims 0..31 = %+.4f, dims 32..39 = %+.4f] | if P is off: ln(P'/P) = %+.4f  [scale K.q dims 0..31 = %+.4f, dims 32..39 = %+.4f]" % (
+            kb, need - float(dp_true[kb] - delta_true), vg_lo, vg_hi, _m.log(max(float(needP / P[kb]), 1e-9)), kq_lo, kq_hi))
+        tv = torch.tensor([float(dS_true[kb] * scale), float(dS_true[kb] * scale + c[kb])], dtype=torch.float32)
+        hv = tv.to(torch.float16).view(torch.int16).tolist()
+        print("     key %d: scaled dS true %.6f (fp16 0x%04x)  used %.6f (fp16 0x%04x)  xor 0x%04x  diff %.6f = 2^%.2f" % (kb, tv[0], hv[0] & 0xffff, tv[1], hv[1] & 0xffff, (hv[0] ^ hv[1]) & 0xffff, tv[1] - tv[0], _m.log2(abs(float(tv[1] - tv[0])) + 1e-30)))
+        print("     key %d = tile %d row %d r %d: needs (dp - delta) = %.4f (true %.4f); closest other key of the lane row: %s = %.4f | or P = %.5f (true %.5f); closest: %s = %.5f" % (
+            kb, kb // 16, gg, kb % 4, need, dp_true[kb] - delta_true, bestc, cands[bestc], needP, P[kb], bestP, candP[bestP]))
         def dS_with(P_, dp_):
             return P_ * (dp_ - (P_ * dp_).sum())
         hyp = {}
@@ -99,4 +119,4 @@ for rep in range(2):
             c[k30] / scale, "; ".join("%s %.4g" % kv for kv in hyp.items()), dp_true[k30], need_dp, dpa[k30], dpb[k30], wsum[p] * dpb[k30]))
         best = min(res, key=res.get)
         print("  px %5d (tile %2d wave %d c16 %2d) head %d wsum %.2f: best %-8s %.2e | full %.2e none %.2e" % (p, p // 128, (p % 128) // 16, p % 16, h, wsum[p], best, res[best], res["full"], res["none"]))
-lib.set_option(lib.OPT_BWD_KERNEL, 0)
+lib.set_option(lib.OPT_STAGED_QT, 0)
