@@ -461,7 +461,7 @@ static bool takes_pair_kernel(int n_img, int N, int C, int heads, int M, int K) 
 
 static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                          const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
-                         int dtype, void* stream, bool qfrag, bool ofrag = false);
+                         int dtype, void* stream, bool qfrag, bool ofrag = false, void* stats = nullptr);
 
 int sta_xattn_fwd_proj_qfrag_supported(int n_img, int N, int C, int heads, int M, int K) {
   const int rc = n_img < 1 ? STA_E_ARG : check_proj_shape(N, C, heads, M, K);
@@ -483,6 +483,13 @@ int sta_xattn_fwd_proj_qfrag_ofrag(const void* y, const void* packed_wq, const v
   return fwd_proj_impl(y, packed_wq, packed_kv, mask, coef, out, n_img, N, C, heads, M, K, scale, dtype, stream, true, true);
 }
 
+int sta_xattn_fwd_proj_ex(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                          const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
+                          int dtype, int layout, void* stats, void* stream) {
+  if (layout < 0 || layout > 2) return sta_fail(STA_E_ARG, "layout %d (0 row-major, 1 query fragments in, 2 + out fragments out)", layout);
+  return fwd_proj_impl(y, packed_wq, packed_kv, mask, coef, out, n_img, N, C, heads, M, K, scale, dtype, stream, layout >= 1, layout == 2, stats);
+}
+
 int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                        const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
                        int dtype, void* stream) {
@@ -493,7 +500,7 @@ int sta_xattn_fwd_proj(const void* y, const void* packed_wq, const void* packed_
 
 static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                          const float* coef, void* out, int n_img, int N, int C, int heads, int M, int K, float scale,
-                         int dtype, void* stream, bool qfrag, bool ofrag) {
+                         int dtype, void* stream, bool qfrag, bool ofrag, void* stats) {
   g_sta_err[0] = 0;
   if (!y || !packed_wq || !packed_kv || !out) return sta_fail(STA_E_ARG, "null pointer");
   if (n_img < 1 || n_img > 65535) return sta_fail(STA_E_ARG, "n_img=%d", n_img);
@@ -519,7 +526,7 @@ static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packe
     const int ndt = (p.d + 15) / 16;
     const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
     const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
-    return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st, qfrag, ofrag);
+    return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st, qfrag, ofrag, (unsigned*)stats);
   }
   if (ll2) {      // SD-v1 level 1: Wq + the two mandatory contexts resident, local contexts from L2
     if (qfrag && N % 16) return sta_fail(STA_E_UNSUP, "query-fragment order needs N %% 16 == 0 (N=%d)", N);

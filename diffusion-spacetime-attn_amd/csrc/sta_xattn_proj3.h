@@ -19,6 +19,19 @@ constexpr int BLK = KBYTES + VBYTES;        // 13952 bytes per (ctx, head); a pa
 constexpr int CTXB = 2 * BLK;
 static_assert(KBYTES % 16 == 0 && BLK % 16 == 0, "16-byte LDS reads need aligned blocks");
 
+// Where lane row g's operand sits inside row `row` of an operand image (round 6). An MFMA operand read is one ds_read_b128 / ds_read_b64
+// per lane at row pitch 96 B (K) or 160 B (V^T): 24 / 40 banks, so rows c and c + 4 of a 16-row tile started on the same banks and
+// 40.6 % of the kernel's LDS cycles were bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05_pmc_proj_levels.txt).
+// XOR-ing the slot with bits of the row index spreads the 8 (16-byte) or 16 (8-byte) lanes the LDS serves per cycle over all 32 banks:
+//   16-byte chunks: slot = g ^ ((row >> 2) & 1)    8-byte units: slot = g ^ ((row >> 2) & 3)
+// (an involution: the same function maps a stored slot back to the lane row, which is how pack_kv_p3_kernel uses it). Same bytes per
+// block, no padding: 162816 of the CU's 163840 B stay as they were.
+#ifndef STA_P3_SWIZZLE
+#define STA_P3_SWIZZLE 1      // 0: the round-3 layout (same-box A/B builds: tools/lib_ab.py ... noswz=-DSTA_P3_SWIZZLE=0)
+#endif
+__host__ __device__ constexpr int swz_big(int g, int row) { return STA_P3_SWIZZLE ? g ^ ((row >> 2) & 1) : g; }
+__host__ __device__ constexpr int swz_small(int g, int row) { return STA_P3_SWIZZLE ? g ^ ((row >> 2) & 3) : g; }
+
 inline bool shape_ok(int C, int heads) { return heads > 0 && heads % 2 == 0 && C == heads * D && (C == 160 || C == 320); }
 __host__ __device__ constexpr int kv_region(int K) { return ((K + 2) * CTXB + 1023) / 1024 * 1024; }   // LDS bytes in front of the Wq fragments
 inline int lds_bytes(int C, int K) { return kv_region(K) + NT * (C / 32) * 1024 + 16; }     // + the work-item counter
@@ -53,6 +66,7 @@ __host__ __device__ constexpr int ofrag_channel(int f, int g, int j) {
 
 int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C, int heads, int dtype, hipStream_t st);
 int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* mask, const float* coef, void* out, int n_img,
-            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag = false, bool ofrag = false);
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag = false, bool ofrag = false,
+            unsigned* stats = nullptr);
 }  // namespace sta_p3
 #endif

@@ -64,10 +64,10 @@ __global__ __launch_bounds__(256) void pack_kv_p3_kernel(const T* __restrict__ k
       const int key = i / (KROW / 2), pos = i % (KROW / 2);
       int dim = -1;
       if (pos < 32) {
-        const int g = pos >> 3, j = pos & 7;
+        const int g = swz_big(pos >> 3, key), j = pos & 7;            // the 16-byte chunk at slot (pos >> 3) holds lane row g's operand
         dim = hp == 0 ? (j < 4 ? 4 * g + j : 16 + 4 * g + (j - 4)) : (j < 4 ? 8 + 4 * g + j : 24 + 4 * g + (j - 4));
       } else {
-        const int g = (pos - 32) >> 2, j = (pos - 32) & 3;
+        const int g = swz_small((pos - 32) >> 2, key), j = (pos - 32) & 3;
         if (hp == 0) { if (g < 2) dim = 32 + 4 * g + j; } else { if (g >= 2) dim = 4 * (g - 2) + j; }
       }
       if (key < M && dim >= 0) x = kh[(size_t)key * C + dim];
@@ -77,10 +77,10 @@ __global__ __launch_bounds__(256) void pack_kv_p3_kernel(const T* __restrict__ k
       const int dim = vrow_dim(r, hp);
       int key;
       if (pos < 64) {
-        const int s = pos >> 5, g = (pos >> 3) & 3, j = pos & 7;
+        const int s = pos >> 5, g = swz_big((pos >> 3) & 3, r), j = pos & 7;
         key = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3);
       } else {
-        const int g = (pos - 64) >> 2, j = (pos - 64) & 3;
+        const int g = swz_small((pos - 64) >> 2, r), j = (pos - 64) & 3;
         key = 64 + 4 * g + j;
       }
       if (key < M) x = dim >= 0 ? vh[(size_t)key * C + dim] : (T)1.0f;
@@ -98,6 +98,7 @@ struct P3 {
   void* out;
   int N, C, H, M, K, W, tiles, iters;
   float sl2e;
+  unsigned* stats;       // null, or the caller's STA_P3_STATS_WORDS words (include/sta_xattn.h: sta_xattn_fwd_proj_ex)
 };
 
 template <typename T> struct KFr {            // the K operands of one (context, head): 5 key tiles
@@ -128,11 +129,15 @@ __device__ __forceinline__ void load_k(KFr<T>& kf, const char* kb, const char* k
 // instantiation: wrong; three vector instructions in eight others: right by one state). sta.lib.build() compiles every source to
 // assembly, runs sta/isa_lint.py over it and pads what it finds (csrc/.isa_lint.log); all six instantiations are then oracle-exact.
 __device__ __forceinline__ float bcast_row2(float x) {
-  unsigned t0, t1;
-  asm volatile("s_nop 1\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\t"
-               "v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %1, %0\n\ts_nop 1"
-               : "=&v"(t0), "=&v"(t1) : "v"(x));
-  return __uint_as_float(t1);
+  // Round 6: the two swaps as builtins again. Rounds 3 - 5 kept them inside one asm statement with five `s_nop 1` (10 wait states per
+  // context, ~1.5 % of the kernel's issue slots) because "hipcc let LDS reads stand in for the wait states and the second swap read stale
+  // registers" — what was really wrong there was the mixed-shape MFMA chain (profiles/r05_hazard_table.md), and the measured table
+  // (tools/hazard_probe.py ^perm: vector write -> swap 1 state by ANY filler, swap -> vector read 0, swap -> swap 1) says the compiler's
+  // own padding (2 states, filled with whatever it can schedule there) is enough; sta/isa_lint.py re-checks every site.
+  const unsigned u = __float_as_uint(x);
+  auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);        // second operand: lane rows (2, 3, 2, 3)
+  auto b = __builtin_amdgcn_permlane16_swap(a[1], a[1], false, false);  // first operand: lane rows (2, 2, 2, 2)
+  return __uint_as_float(b[0]);
 }
 
 // What a head leaves for the stores of one batch row: `main` = the lane's tile-0 | tile-1 outputs (8 consecutive dims, 16 bytes),
@@ -211,12 +216,16 @@ template <typename T, int KIND>
 __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* vs, const char* knb, const char* kns,
                                         const typename Tr<T>::V8& qbig, const typename Tr<T>::V4& qsm, const f32x4 kb4,
                                         const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3],
-                                        const char* kcb = nullptr, const char* kcs = nullptr) {
+                                        const char* kcb = nullptr, const char* kcs = nullptr, const bool opt_on = true,
+                                        unsigned* n_att = nullptr, unsigned* n_fb = nullptr) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   if constexpr (kOptimistic<T>) {
     V8 vbig[3][2];
     V4 vsm[3];
+    f32x4 st[NKT], o[3];
+    bool need_std = true;                            // wave-uniform: the standard path runs when the optimistic one is sitting out or failed its check
+    if (opt_on) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       vbig[u][0] = *(const V8*)(vb + u * 16 * VROW);
@@ -225,7 +234,6 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     }
     // the k = 32 steps of all tiles first, then the k = 16 steps: four other MFMAs between a tile's two shapes (no mixed-shape hazard,
     // nothing for sta/isa_lint.py to pad)
-    f32x4 st[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) st[t] = Tr<T>::mfma(kf.big[t], qbig, (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f});
     __builtin_amdgcn_sched_barrier(0);               // hipcc otherwise moves a tile's k = 16 step right behind its k = 32 step again
@@ -240,7 +248,6 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     const V4 p2 = cvt4<T>(st[4]);
     __builtin_amdgcn_sched_barrier(0);
     load_k<T>(kf, knb, kns);
-    f32x4 o[3];
 #pragma unroll
     for (int u = 0; u < 3; ++u) o[u] = Tr<T>::mfma(vbig[u][0], p0, f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
@@ -254,7 +261,13 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     // other rows of O^T (sums of P * v) finite whenever the ones row passes.
     const bool row2 = (threadIdx.x & 48) == 32;
     const bool bad = row2 && (__float_as_uint(o[2][0]) - kDenLo<T>) >= (kDenHi<T> - kDenLo<T>);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+    need_std = __builtin_amdgcn_ballot_w64(bad) != 0;
+    if (n_att) {                                     // (scalar counters of the wave: sta_xattn_fwd_proj_ex's statistics)
+      *n_att += 1u;
+      *n_fb += need_std ? 1u : 0u;
+    }
+    }
+    if (__builtin_expect(need_std, 0)) {
       load_k<T>(kf, kcb, kcs);                      // kf doubles as the buffer: the next context's operands are requested again below
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
@@ -413,7 +426,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   const int mine = (p.tiles - wt + W - 1) / W;
   const int iters = mine < p.iters ? mine : p.iters;
   const int nitems = iters * NWV;
-  unsigned* qcount = (unsigned*)(lds_wq + (size_t)nwq * FRAG);     // behind the Wq fragments
+  unsigned* qcount = (unsigned*)(lds_wq + (size_t)nwq * FRAG);     // behind the Wq fragments: [0] the item queue, [1], [2] this workgroup's
+                                                                     // optimistic-softmax attempts / fall-backs (statistics)
   if (threadIdx.x == 0) *qcount = 2u * NWV;                          // items 0 .. 2 NWV - 1 are handed out statically below
   const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
   const __amdgpu_buffer_rsrc_t o_srd = make_srd(ob, (unsigned)act);
@@ -452,9 +466,14 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   const float sl2e = p.sl2e;
   const unsigned kmask = (1u << K) - 1u;
   // per-lane byte offsets into a (ctx, head) block
-  const int koffb = c16 * KROW + 16 * g, koffs = c16 * KROW + 64 + 8 * g;
-  const int voffb = KBYTES + c16 * VROW + 16 * g, voffs = KBYTES + c16 * VROW + 128 + 8 * g;
+  // (slot of lane row g inside row c16 of a 16-row tile: sta_p3::swz_big / swz_small — bank-conflict-free operand reads)
+  const int koffb = c16 * KROW + 16 * swz_big(g, c16), koffs = c16 * KROW + 64 + 8 * swz_small(g, c16);
+  const int voffb = KBYTES + c16 * VROW + 16 * swz_big(g, c16), voffs = KBYTES + c16 * VROW + 128 + 8 * swz_small(g, c16);
   const V8* wf = (const V8*)lds_wq + lane;
+  // optimistic softmax or not: the caller's state word (launches still to sit out; sta_xattn_fwd_proj_ex) — one value per launch
+  const bool opt_on = p.stats == nullptr || __builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(p.stats)) == 0;
+  unsigned n_att = 0, n_fb = 0;
+  if (threadIdx.x == 0) { qcount[1] = 0u; qcount[2] = 0u; }
   wait_dma_and_sync();
   if constexpr (kOptimistic<T>) {
     // scores in log2 units: scale * log2 e goes into the pair's Wq fragments, once per workgroup, in LDS (nwq fragments of 64 lanes x 8
@@ -468,6 +487,8 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     __syncthreads();
   }
 
+  unsigned* const cnt_a = p.stats ? &n_att : nullptr;
+  unsigned* const cnt_f = p.stats ? &n_fb : nullptr;
   while (qcur < nitems) {
     // ---- projection: 5 column tiles x both batch rows; Wq fragments one k-step ahead -------------------------------
     f32x4 qa0[NT], qa1[NT];
@@ -570,10 +591,10 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const unsigned rest = wneed >> first_local;
         return rest ? blk + (size_t)(2 + first_local + __builtin_ctz(rest)) * CTXB : other;
       };
-      attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sm_scale, 0.f, au, ac, blk + koffb, blk + koffs);
+      attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sm_scale, 0.f, au, ac, blk + koffb, blk + koffs, opt_on, cnt_a, cnt_f);
       {
         const char* nx = next_of(0);
-        attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, 0.f, au, ac, blk + CTXB + koffb, blk + CTXB + koffs);
+        attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, 0.f, au, ac, blk + CTXB + koffb, blk + CTXB + koffs, opt_on, cnt_a, cnt_f);
       }
       for (int i = 0; i < K; ++i) {
         if (!((wneed >> i) & 1u)) continue;
@@ -581,7 +602,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const float w = ((mbits >> i) & 1u) ? cw : 0.f;
         const char* cb = blk + (size_t)(2 + i) * CTXB;
         const char* nx = next_of(i + 1);
-        attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, w, au, ac, cb + koffb, cb + koffs);
+        attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, w, au, ac, cb + koffb, cb + koffs, opt_on, cnt_a, cnt_f);
       }
       ou = pack_out<T>(au);
       oc = pack_out<T>(ac);
@@ -620,6 +641,23 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
       voffhn = voff_of(qnext, 1);
     }
   }
+  if (p.stats) {      // per-wave counts -> LDS -> one pair of global atomics per workgroup
+    if (lane == 0 && n_att) { atomicAdd(qcount + 1, n_att); atomicAdd(qcount + 2, n_fb); }
+    __syncthreads();
+    if (threadIdx.x == 0 && qcount[1]) { atomicAdd(p.stats + 1, qcount[1]); atomicAdd(p.stats + 2, qcount[2]); }
+  }
+}
+
+// Behind every launch that was given statistics words: fold the launch's counts into the totals and decide whether the next launches sit
+// the optimistic softmax out — more than an eighth of the wave-level context evaluations fell back: the next 64 launches run the standard
+// softmax only (every context through what is otherwise the fall-back: exact, ~4 % slower than the optimistic path on friendly logits
+// instead of both paths per context on hostile ones). One thread; stream-ordered, works inside a replayed hipGraph.
+__global__ void p3_stats_kernel(unsigned* s) {
+  const unsigned att = s[1], fb = s[2];
+  s[4] += att; s[5] += fb; s[6] += 1u;
+  if (s[0] > 0u) { s[0] -= 1u; s[7] += 1u; }
+  else if (fb * 8u > att) s[0] = 64u;
+  s[1] = 0u; s[2] = 0u;
 }
 
 template <typename T, int NKC, int YL, bool OF = false>
@@ -638,6 +676,7 @@ int launch_p3(P3 p, int n_img, hipStream_t st) {
   if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YL, OF>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj p3) failed");
   hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YL, OF>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
+  if (p.stats && kOptimistic<T>) hipLaunchKernelGGL(p3_stats_kernel, dim3(1), dim3(1), 0, st, p.stats);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj p3 launch: %s", hipGetErrorString(e));
 }
@@ -657,8 +696,9 @@ int pack_kv(const void* k, const void* v, void* packed, int n_ctx, int M, int C,
 }
 
 int forward(const void* y, const void* wq_pair, const void* kv, const uint8_t* mask, const float* coef, void* out, int n_img,
-            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag, bool ofrag) {
+            int N, int C, int heads, int M, int K, float sl2e, int dtype, hipStream_t st, bool qfrag, bool ofrag, unsigned* stats) {
   P3 p{};
+  p.stats = stats;
   p.y = y; p.wq = (const char*)wq_pair; p.kv = (const char*)kv; p.mask = mask; p.coef = coef; p.out = out;
   p.N = N; p.C = C; p.H = heads; p.M = M; p.K = K; p.sl2e = sl2e;
   if (ofrag && !(qfrag && C == 320)) return sta_fail(STA_E_UNSUP, "out-fragment order needs y in query-fragment order and C = 320");

@@ -34,6 +34,7 @@ STA_BF16, STA_F16 = 0, 1
 OPT_FWD_KERNEL, OPT_STAGED_TILES, OPT_STAGED_WAVES, OPT_STAGED_QT, OPT_HEAD_MAJOR, OPT_SPLIT_QT, OPT_SELFATTN_32, OPT_PROJ_PAIR, OPT_SELFATTN_WAVES, OPT_SELFATTN_PIPE, OPT_PROJ_LL2, OPT_BWD_KERNEL, OPT_BWD_SLOTS, OPT_BWD_WAVES = range(14)
 FWD_STAGED, FWD_SPLIT = 1, 2
 MAX_KEYS, MAX_HEAD_DIM, MAX_OBJECTS = 80, 160, 8
+P3_STATS_WORDS = 8
 
 # every symbol include/sta_xattn.h and include/sta_unet.h declare: (restype, argtypes)
 _vp, _i, _f, _sz, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
@@ -53,6 +54,7 @@ SYMBOLS = {
     "sta_xattn_pack_kv_proj": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sta_xattn_fwd_proj": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_fwd_proj_qfrag_supported": (_i, [_i, _i, _i, _i, _i, _i]),
+    "sta_xattn_fwd_proj_ex": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp, _vp]),
     "sta_xattn_fwd_proj_qfrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_xattn_fwd_proj_qfrag_ofrag": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "sta_to_out_ln_packed_wo_bytes": (_sz, [_i, _i]),

@@ -386,11 +386,13 @@ def toolchain_self_check(force=False, device=None):
     return ok
 
 
-def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofrag=False):
+def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofrag=False, stats=True):
     """y [2I, N, C] = norm2(hidden) -> blended pre-projection output [2I, N, C]; the query projection happens inside
     the attention kernel (no autograd). `packed` comes from pack_kv_proj, `wq_packed` from pack_wq. `qfrag`: y is in
     query-fragment order (fused.add_layernorm(..., qfrag=True) / to_qfrag); only where proj_qfrag_supported. `ofrag`: the result
-    leaves in out-fragment order for fused.to_out_add_layernorm_ofrag (from_ofrag restores row-major)."""
+    leaves in out-fragment order for fused.to_out_add_layernorm_ofrag (from_ofrag restores row-major). `stats`: True = the per-(device,
+    stream) words of proj_stats() (the head-pair kernel counts its optimistic-softmax fall-backs there and sits the optimistic path out
+    when they pile up), None = no statistics and always optimistic, or an own int32 tensor of lib.P3_STATS_WORDS words."""
     I, N, C, K = _check_inputs(y, packed, mask, coef)
     L = _lib.load()
     if not qfrag:                  # (fragment-order callers asked proj_qfrag_supported first; a row-major first call checks here)
@@ -401,13 +403,42 @@ def xattn_forward_proj(y, wq_packed, packed, mask, coef, scale, qfrag=False, ofr
     out = torch.empty_like(y)
     if ofrag and not qfrag:
         raise ValueError("out-fragment order rides on the query-fragment path (qfrag=True)")
-    fn, name = (L.sta_xattn_fwd_proj_qfrag_ofrag, "sta_xattn_fwd_proj_qfrag_ofrag") if ofrag else \
-        (L.sta_xattn_fwd_proj_qfrag, "sta_xattn_fwd_proj_qfrag") if qfrag else (L.sta_xattn_fwd_proj, "sta_xattn_fwd_proj")
+    layout = 2 if ofrag else (1 if qfrag else 0)
+    stats = proj_stats(y.device) if stats is True else stats
     def launch():
-        _lib.check(fn(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
-                      out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y), _stream(y)), name)
+        _lib.check(L.sta_xattn_fwd_proj_ex(y.data_ptr(), wq_packed.data_ptr(), packed.buf.data_ptr(), _ptr(maskc), _ptr(coef32),
+                                           out.data_ptr(), I, N, C, packed.heads, packed.M, K, float(scale), _dtype_code(y), layout,
+                                           _ptr(stats), _stream(y)), "sta_xattn_fwd_proj_ex")
     _logged("proj", I, N, C, K, launch)
     return out
+
+
+_PROJ_STATS = {}
+
+
+def proj_stats(device=None):
+    """The statistics / adaptive-switch words the head-pair kernel keeps across launches (include/sta_xattn.h: sta_xattn_fwd_proj_ex), one
+    buffer per device: int32 tensor of lib.P3_STATS_WORDS words — [0] launches still sitting the optimistic softmax out, [4] / [5]
+    wave-level context evaluations / fall-backs so far, [6] launches, [7] launches that sat out. The words only steer which of two exact
+    softmax paths runs, so launches of several streams may share them. Never created while a stream is being captured (the zero-fill
+    would become a node of the graph and wipe the words at every replay): a capture without a buffer runs without statistics."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    t = _PROJ_STATS.get(device)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        t = _PROJ_STATS[device] = torch.zeros(_lib.P3_STATS_WORDS, dtype=torch.int32, device=device)
+    return t
+
+
+def proj_stats_summary():
+    """{evaluations, fallbacks, rate, launches, launches_sat_out, sitting_out_now} over every statistics buffer of the process."""
+    tot = [0] * _lib.P3_STATS_WORDS
+    for t in _PROJ_STATS.values():
+        for i, v in enumerate(t.cpu().tolist()):
+            tot[i] += v & 0xffffffff
+    return {"evaluations": tot[4], "fallbacks": tot[5], "fallback_rate": (tot[5] / tot[4]) if tot[4] else 0.0, "launches": tot[6],
+            "launches_sat_out": tot[7], "sitting_out_now": tot[0]}
 
 
 class _XAttnBlend(torch.autograd.Function):

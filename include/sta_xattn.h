@@ -198,6 +198,24 @@ int sta_xattn_fwd_proj_qfrag(const void* y_frag, const void* packed_wq, const vo
 int sta_xattn_fwd_proj_qfrag_ofrag(const void* y_frag, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
                                    const float* coef, void* out_frag,
                                    int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, void* stream);
+
+/*
+ * sta_xattn_fwd_proj / _qfrag / _qfrag_ofrag behind ONE entry point (`layout` 0 / 1 / 2) plus the head-pair kernel's STATISTICS AND
+ * ADAPTIVE SWITCH (round 6). The pair kernel's softmax is optimistic (no running maximum; a per-context range check of the denominator
+ * sends a wave through the standard softmax when it fails) — tuned to logits whose largest score lies in a window (fp16: about -3.5 .. +10
+ * nats), which holds for the synthetic weights of the bench and is NOT known for real SD-v1-4 weights (a large BOS-token logit is typical).
+ * `stats`: NULL (the three entry points above: always optimistic, nothing counted), or STA_P3_STATS_WORDS uint32 words in device memory,
+ * zeroed once by the caller and then owned by the library across launches on one stream:
+ *   [0] launches still to sit the optimistic softmax out     [1], [2] this launch's wave-level context evaluations / fall-backs
+ *   [4], [5] totals of [1], [2]      [6] launches counted     [7] launches that sat out
+ * After every launch a one-thread kernel folds the counts and, when more than an eighth of the evaluations fell back, makes the next 64
+ * launches run the standard softmax only (device side: no host synchronisation, valid inside a captured graph) — hostile logits then cost
+ * the standard kernel's time, not both paths per context. Shapes that do not take the pair kernel ignore `stats`.
+ */
+#define STA_P3_STATS_WORDS 8
+int sta_xattn_fwd_proj_ex(const void* y, const void* packed_wq, const void* packed_kv, const uint8_t* mask,
+                          const float* coef, void* out,
+                          int n_img, int N, int C, int heads, int M, int K, float scale, int dtype, int layout, void* stats, void* stream);
 size_t sta_to_out_ln_packed_wo_bytes(int C, int heads);
 int sta_to_out_ln_pack_wo(const void* wo, void* packed, int C, int heads, int kind, int dtype, void* stream);
 int sta_to_out_ln_ofrag(const void* blended_ofrag, const void* packed_wo, const void* bias, const void* x,

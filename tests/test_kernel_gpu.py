@@ -959,6 +959,58 @@ def test_fwd_proj_pair_extreme_logits(mode, dtype):
             assert frac(ref) == 1.0, (i, frac(ref))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fwd_proj_pair_counts_fallbacks_and_sits_out(dtype):
+    """sta_xattn_fwd_proj_ex's statistics words: friendly logits count evaluations and no fall-back; with a key that leads by +16 nats
+    ("BOS") every evaluation of the fp16 window falls back, the launch after it sits the optimistic softmax out (state word 64 -> 63 ...),
+    a launch without statistics words gives the optimistic launch's bits and the sitting-out launch the same values to output rounding."""
+    from sta import lib, ops
+    dev, N, C, heads, K, I = "cuda", 4096, 320, 8, 2, 2
+    g = torch.Generator().manual_seed(6)
+    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).to(dtype).to(dev)
+    cases = [list(_case(N, C, heads, K, dtype, seed=120 + i)) for i in range(I)]
+    y = torch.cat([c[0] for c in cases]).to(dev)
+    v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    scale = (C // heads) ** -0.5
+    wqf = ops.pack_wq(wq, heads)
+    q = (y.float() @ wq.float().t())                                       # [2I, N, C]
+    lib.set_option(lib.OPT_PROJ_PAIR, 1)
+    try:
+        for hostile in (False, True):
+            k = torch.cat([c[1] for c in cases]).float()
+            if hostile:
+                # key 0 of every context follows the mean query of its head, scaled so that its logit leads by ~ +16 nats (fp16's window
+                # ends near +10, bf16's near +65: bf16 keeps the optimistic path)
+                qm = q.view(2 * I, N, heads, C // heads).mean((0, 1))          # [heads, d]
+                qm = qm / qm.norm(dim=-1, keepdim=True)
+                lead = 16.0 / scale / (q.view(2 * I, N, heads, C // heads).float() * qm).sum(-1).abs().mean().item()
+                k[:, 0] = (qm * lead).reshape(C).cpu()
+            kvp = ops.pack_kv_proj(k.to(dtype).to(dev), v, heads, n_img=I)
+            stats = torch.zeros(lib.P3_STATS_WORDS, dtype=torch.int32, device=dev)
+            yq = ops.to_qfrag(y)
+            first = ops.xattn_forward_proj(yq, wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True, stats=stats)
+            s1 = stats.cpu().tolist()
+            second = ops.xattn_forward_proj(yq, wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True, stats=stats)
+            s2 = stats.cpu().tolist()
+            plain = ops.xattn_forward_proj(yq, wqf, kvp, mb, coef, scale, qfrag=True, ofrag=True, stats=None)
+            torch.cuda.synchronize()
+            assert s1[1] == 0 and s1[2] == 0 and s1[6] == 1 and s1[4] > 0        # counts folded into the totals by the one-thread kernel
+            # a launch with statistics words takes the same path per context as one without; a launch that sits out takes the standard softmax
+            # for EVERY context (another rounding of P where the optimistic path had passed its check): the same values to output rounding
+            eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+            assert torch.equal(first, plain) and torch.isfinite(first).all()
+            assert ((second.float() - first.float()).abs() <= 2 * eps * (1.0 + first.float().abs())).all()
+            rate = s1[5] / s1[4]
+            if hostile and dtype == torch.float16:
+                assert rate > 0.5 and s1[0] == 64 and s2[0] == 63 and s2[7] == 1 and s2[4] == s1[4], (s1, s2)    # the second launch evaluated nothing optimistically
+            else:                # (bf16's window ends near +65 nats: of the hostile case only the pixels that project > 4x the mean onto the key leave it)
+                assert (s1[5] == 0 or (hostile and rate < 0.05)) and s1[0] == 0 and s2[4] == 2 * s1[4] and s2[7] == 0, (s1, s2)
+    finally:
+        lib.set_option(lib.OPT_PROJ_PAIR, 0)
+
+
 def test_fwd_proj_rejects_what_it_cannot_hold():
     """Level 2 of SD-v1 (C = 1280: 400 KiB of Wq per head) does not fit one CU's LDS, and level 1 (C = 640: 100 KiB of Wq + 4
     contexts of 30 KiB) fits only with the local contexts left in L2 (STA_OPT_PROJ_LL2 = 2 refuses that variant): the C-ABI

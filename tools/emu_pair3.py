@@ -35,6 +35,14 @@ def vrow_dim(r, hp):
     return 8 * ((g + 3 * hp) & 3) + 4 * u + q
 
 
+def swz_big(g, row):      # csrc/sta_xattn_proj3.h: slot of lane row g's 16-byte chunk inside row `row`
+    return g ^ ((row >> 2) & 1)
+
+
+def swz_small(g, row):
+    return g ^ ((row >> 2) & 3)
+
+
 def pack_block(k, v, hp, M):
     """k, v: [M, 40] float16 of ONE head; hp = head parity inside its pair. Returns BLK bytes (as uint16 halves)."""
     blk = np.zeros(BLK // 2, dtype=np.float16)
@@ -49,10 +57,10 @@ def pack_block(k, v, hp, M):
                     lo, hi = 8 + 4 * g + j, 24 + 4 * g + j
                     sm = 4 * (g - 2) + j if g >= 2 else -1
                 if key < M:
-                    blk[row + 8 * g + j] = k[key, lo]
-                    blk[row + 8 * g + 4 + j] = k[key, hi]
+                    blk[row + 8 * swz_big(g, key) + j] = k[key, lo]
+                    blk[row + 8 * swz_big(g, key) + 4 + j] = k[key, hi]
                     if sm >= 0:
-                        blk[row + 32 + 4 * g + j] = k[key, sm]
+                        blk[row + 32 + 4 * swz_small(g, key) + j] = k[key, sm]
     vb = KBYTES // 2
     for r in range(VR):
         row = vb + r * (VROW // 2)
@@ -62,12 +70,12 @@ def pack_block(k, v, hp, M):
                 for j in range(8):
                     key = 32 * s + 16 * (j >> 2) + 4 * g + (j & 3)
                     if key < M:
-                        blk[row + 32 * s + 8 * g + j] = v[key, dim] if dim >= 0 else 1.0
+                        blk[row + 32 * s + 8 * swz_big(g, r) + j] = v[key, dim] if dim >= 0 else 1.0
         for g in range(4):
             for j in range(4):
                 key = 64 + 4 * g + j
                 if key < M:
-                    blk[row + 64 + 4 * g + j] = v[key, dim] if dim >= 0 else 1.0
+                    blk[row + 64 + 4 * swz_small(g, r) + j] = v[key, dim] if dim >= 0 else 1.0
     return blk
 
 
@@ -181,8 +189,8 @@ def emulate(seed=0, M=77, C=320):
             Abig = np.zeros((64, 8)); Asm = np.zeros((64, 4))
             for lane in range(64):
                 g, c = lane >> 4, lane & 15
-                Abig[lane] = lds_read(lds, c * KROW + 16 * g + t * 16 * KROW, 16)
-                Asm[lane] = lds_read(lds, c * KROW + 64 + 8 * g + t * 16 * KROW, 8)
+                Abig[lane] = lds_read(lds, c * KROW + 16 * swz_big(g, c) + t * 16 * KROW, 16)
+                Asm[lane] = lds_read(lds, c * KROW + 64 + 8 * swz_small(g, c) + t * 16 * KROW, 8)
             a = np.zeros((64, 4))
             if t == 4:
                 for lane in range(64):
@@ -218,12 +226,12 @@ def emulate(seed=0, M=77, C=320):
                 A = np.zeros((64, 8))
                 for lane in range(64):
                     g, c = lane >> 4, lane & 15
-                    A[lane] = lds_read(lds, KBYTES + (16 * u + c) * VROW + 64 * s + 16 * g, 16)
+                    A[lane] = lds_read(lds, KBYTES + (16 * u + c) * VROW + 64 * s + 16 * swz_big(g, c), 16)
                 a = mfma32(A, pbig[s], a)
             A = np.zeros((64, 4))
             for lane in range(64):
                 g, c = lane >> 4, lane & 15
-                A[lane] = lds_read(lds, KBYTES + (16 * u + c) * VROW + 128 + 8 * g, 8)
+                A[lane] = lds_read(lds, KBYTES + (16 * u + c) * VROW + 128 + 8 * swz_small(g, c), 8)
             a = mfma16(A, psm, a)
             o.append(a)
         den = o[2][32:48, 0]                           # ones row 40 = tile 2, row 8: lane row g = 2, register 0

@@ -140,6 +140,11 @@ def perm_probes():
                                   "v_mov_b32 v%d, v90\nv_mov_b32 v%d, v91" % (R0, R0 + 1))
         out[("perm%d_dst" % w, 0)] = ("v_mov_b32 v90, v%d" % (B0 + 1), "v_permlane%d_swap_b32 v90, v91" % w,
                                       "v_mov_b32 v%d, v90\nv_mov_b32 v%d, v91" % (R0, R0 + 1))
+        # round 6: the swap's RESULT read by the next vector instruction / by the other swap (csrc/sta_xattn_proj3.hip::bcast_row2 pads both)
+        out[("perm%d_rd" % w, 0)] = ("v_mov_b32 v91, v%d\ns_nop 4\nv_permlane%d_swap_b32 v90, v91" % (B0, w), "v_mov_b32 v%d, v91" % TMP,
+                                     "v_mov_b32 v%d, v%d\nv_mov_b32 v%d, v90" % (R0, TMP, R0 + 1))
+        out[("perm%d_sw" % w, 0)] = ("v_mov_b32 v91, v%d\ns_nop 4\nv_permlane%d_swap_b32 v90, v91" % (B0, w), "v_permlane%d_swap_b32 v91, v90" % (48 - w),
+                                     "v_mov_b32 v%d, v90\nv_mov_b32 v%d, v91" % (R0, R0 + 1))
     return setup, out
 
 
