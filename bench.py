@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the bounded side measurement after the headline run "
                                                                  "(3-epoch weight optimisation = BASELINE configs[2])")
+    ap.add_argument("--no-config5", action="store_true", help="skip the 768x768 / 4-object side leg (BASELINE configs[4] on one GPU)")
     ap.add_argument("--no-other-dtype", action="store_true", help="skip the side leg that times one step in the other 16-bit type "
                                                                    "(bf16 when the headline runs fp16; its convolution solvers are in the shipped MIOpen find-db)")
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16",
@@ -507,7 +508,8 @@ def hostile_logits_leg(dev, dtype_name, I, K, lat):
     return out
 
 
-def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps, K, checkpoint="auto", find=True, roofline=False, roofline_bwd=False):
+def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps, K, checkpoint="auto", find=True, roofline=False, roofline_bwd=False,
+             fp8_linears=False):
     """A bounded side measurement on rank 0 after the headline run: the same workload with another 16-bit type, or
     BASELINE configs[2] (3 weight-optimisation epochs: two tracked trajectories with backward + one fixed-weight one).
     Builds its own model, reports images/s over `steps` timed steps after `warmup` untimed ones."""
@@ -517,6 +519,9 @@ def side_run(dev, dtype_name, opt_epochs, images, steps, warmup, res, ddim_steps
     dt = torch.float16 if dtype_name == "fp16" else torch.bfloat16
     model = build_sd_v1(dev, dt, with_vae=True, init_weights=True, seed=0, channels_last=opt_epochs == 0, use_checkpoint=opt_epochs > 1)
     torch.backends.cudnn.benchmark = bool(find)
+    if fp8_linears:          # BASELINE configs[4]: e4m3 Linear weights in the transformer blocks (sta.fp8: a memory option, torch._scaled_mm)
+        from sta import fp8
+        fp8.convert_transformer_linears_(model.model.diffusion_model)
     mode = set_recompute(model, checkpoint, images) if opt_epochs > 1 else None
     loss_model = DCLIPLoss(SyntheticCLIP().to(dev)) if opt_epochs > 0 else None
     sampler = PLMSSampler(model, opt_epochs=opt_epochs, loss_model=loss_model, use_graph=True, save_images=False)
@@ -640,11 +645,22 @@ def dry_launch(a, rank, world, local):
     el = parallel.max_over_ranks(time.perf_counter() - t0, dev)
     I = a.images_per_step
     shard = [((0 * world + r) * I + i) % 64 for r in range(world) for i in range(min(I, 2))]
+    # what every rank would do next, gathered: the prompts of its step 0 (main()'s `mine(0)`), its MIOpen user-db copy, its device, the
+    # rendezvous it saw — the first 8-GPU run of the driver must not be the first execution of any of this
+    from sta.pipeline import use_shipped_miopen_db
+    db = use_shipped_miopen_db(local)
+    mine0 = [((0 * world + rank) * I + i) % 64 for i in range(I)]
+    info = {"rank": rank, "local_rank": local, "device": str(dev), "prompts_step0": mine0, "miopen_user_db": db,
+            "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT")), "pid": os.getpid()}
+    infos = [info]
+    if world > 1:
+        infos = [None] * world
+        dist.all_gather_object(infos, info)
     if rank == 0:
         print(json.dumps({"dry_launch": True, "n_gpus": world, "backend": dist.get_backend() if world > 1 else None, "scaling": a.scaling,
                           "images_per_step": I, "global_batch": world * I, "weights_identical_on_every_rank": bool(oks.item() == 1.0),
                           "weight_broadcast_bytes": nbytes, "weight_broadcast_s": round(t_bcast, 3), "elapsed_max_over_ranks_s": round(el, 3),
-                          "first_prompts_of_step0": shard, "device": str(dev.type)}), flush=True)
+                          "first_prompts_of_step0": shard, "device": str(dev.type), "ranks": infos}), flush=True)
     if world > 1:
         dist.destroy_process_group()
     if not bool(oks.item() == 1.0):
@@ -800,6 +816,16 @@ def main():
             out["config3_shard"] = guarded(lambda: side_run(dev, a.dtype, 0, 8, a.steps, a.warmup, a.res, a.ddim_steps, K, roofline=not a.no_roofline))
             out["config3_shard"]["config"] = ("BASELINE configs[3] per-GPU shard: 64 mscoco prompts / 8 GPUs = 8 prompts per step on this GPU "
                                               "(--scaling strong at world 8), %d PLMS steps, %d objects, fixed weights" % (a.ddim_steps, K))
+        if a.res == 512 and not a.no_config5:
+            # BASELINE configs[4] on ONE GPU (the per-GPU work of its 8-GPU line): VSR-style prompts at 768x768, 4 object boxes, 50 steps, in 16 bit
+            # and with e4m3 Linear weights; 4 prompts per step, 2 timed steps after 1 warm-up, MIOpen in immediate mode (no find-db for these
+            # shapes), each with its own cross-attention launch table (`roofline`). K = 4: level 0 takes the one-head-per-workgroup
+            # projection-fused kernel (the head-pair kernel holds K <= 2), level 1 the locals-from-L2 kernel.
+            torch.backends.cudnn.benchmark = False
+            out["config5"] = {"config": "BASELINE configs[4] on one GPU: 768x768, %d PLMS steps, 4 objects, fixed weights, 4 prompts per step" % a.ddim_steps,
+                              a.dtype: guarded(lambda: side_run(dev, a.dtype, 0, 4, 2, 1, 768, a.ddim_steps, 4, find=False, roofline=not a.no_roofline)),
+                              "fp8_linear_weights": guarded(lambda: side_run(dev, a.dtype, 0, 4, 2, 1, 768, a.ddim_steps, 4, find=False, fp8_linears=True))}
+            torch.backends.cudnn.benchmark = find
         out["weight_optimisation"] = guarded(lambda: side_run(dev, a.dtype, 3, 16 if a.res <= 512 else 2, 3, 1, a.res, a.ddim_steps, K, find=find,
                                                               roofline_bwd=not a.no_roofline))
         out["weight_optimisation"]["config"] = "BASELINE configs[2]: %dx%d, %d PLMS steps, %d objects, 3 epochs of per-step blend-weight optimisation" % (

@@ -292,6 +292,185 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
   STA_T_END();
 }
 
+// --------------------------------------------------------------------------------------------------------------------------------
+// The same launch for head dims whose Wq slice does NOT fit a CU (round 6; SD-v1 levels 2 and mid: C = 1280, d = 160: 400 KiB per head):
+// Wq is STREAMED — per pixel tile its 40 k-steps pass through a two-slot LDS ring in chunks of two k-steps (20 1-KiB fragments, the
+// pattern of csrc/sta_rowgemm.hip::to_out_ln_ofrag_kernel) — beside the two mandatory contexts (2 x 55 KiB resident); the local
+// contexts come from L2 as in the LL2 variant above. q never exists in HBM at any level with this.
+//   per chunk and wave: 2 k-steps x NDT tiles x 2 batch rows = 40 MFMAs behind 20 fragment reads, one barrier;
+//   the DMA of chunk c + 1 is issued before the MFMAs of chunk c; `s_waitcnt vmcnt(4)` at the end of a chunk leaves exactly the four
+//   y-ring refills of the chunk in flight (the ring is what keeps the vector-memory path busy) and covers the wave's three DMA pieces;
+//   the ring runs THROUGH the attention phase: the last chunk of a tile requests chunk 0 again (of the next tile; wasted once at the
+//   end of a workgroup's life), so every chunk iteration issues the same loads and the wait count is a constant.
+// Traffic: a workgroup re-reads the head's 400 KiB per 128-pixel tile from L2 (level 2 at 64 images: 1024 tiles = 410 MB per launch)
+// against the 2 x 84 MB HBM round trip of q and a library GEMM launch it replaces.
+constexpr int WQS_CH = 2;        // k-steps per Wq chunk
+constexpr int WQS_RING = 4;      // y k-steps in flight per batch row (divides nkc together with WQS_CH: C % 128 == 0)
+template <typename T, int NDT>
+__global__ __launch_bounds__(512, 1) void xattn_fwd_proj_wqs_kernel(const PParams p) {
+  using V8 = typename Tr<T>::V8;
+  constexpr int NWV = 8, RING = WQS_RING, CH = WQS_CH;
+  constexpr int NKS = nks_of(NDT);
+  constexpr int NFWD = fwd_frags(NDT);
+  constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
+  constexpr int TP = 16 * NWV;
+  constexpr int CF = CH * NDT;                    // fragments per chunk
+  constexpr int PIECES = (CF + NWV - 1) / NWV;    // DMA pieces per wave and chunk (the last ones may repeat a fragment: same bytes, same place)
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane >> 4, c16 = lane & 15;
+  const int lin = (int)blockIdx.x + (int)gridDim.x * (int)blockIdx.y;
+  const int Lg = xcd_remap(lin, (int)(gridDim.x * gridDim.y));
+  const int img = Lg / (int)gridDim.x;
+  const int L = Lg - img * (int)gridDim.x;
+  int wt, h;
+  if (p.H == 8) { wt = L >> 3; h = L & 7; } else { wt = L / p.H; h = L % p.H; }
+  const int N = p.N, C = p.C, d = p.d, K = p.K, nkc = p.nkc, W = p.W;
+  const int NC = nkc / CH;                        // chunks per tile
+  const unsigned row_bytes = (unsigned)C * (unsigned)sizeof(T);
+  const size_t act = (size_t)2 * N * row_bytes;
+  const char* yb = (const char*)p.y + img * act;
+  T* ob = (T*)((char*)p.out + img * act);
+  const size_t ctx_stride = (size_t)p.H * CB;
+  const char* kv = p.kv + ((size_t)img * (K + 2) * p.H + h) * CB;
+  const uint8_t* mask = p.mask + (size_t)img * N;
+  const float coef_lane = p.coef[(size_t)img * K + min(lane, K > 0 ? K - 1 : 0)];
+  const char* wq_h = p.wq + (size_t)h * NDT * nkc * FRAG;
+  char* lds_ring = smem;                          // 2 slots x CF fragments
+  char* lds_ctx = smem + 2 * CF * FRAG;
+
+  auto stage_chunk = [&](int c, int slot) {       // PIECES pieces per wave, always (constant wait counts)
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+      int f = wv + NWV * i;
+      f = f < CF ? f : CF - 1;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq_h + ((size_t)c * CF + f) * FRAG + lane * 16),
+                                       (__attribute__((address_space(3))) void*)(lds_ring + (slot * CF + f) * FRAG), 16, 0, 0);
+    }
+  };
+  stage_chunk(0, 0);
+  for (int c = 0; c < 2; ++c) stage_frags(kv + c * ctx_stride, lds_ctx + c * CB, NFWD, wv, NWV, lane);
+  SrdFrags<V8> gfr;
+  gfr.r = make_srd(p.kv + (size_t)img * (K + 2) * ctx_stride, (unsigned)((K + 2) * ctx_stride));
+  gfr.voff = (unsigned)lane * 16u;
+  gfr.soff = 0u;
+
+  const int mine = (p.tiles - wt + W - 1) / W;
+  const int iters = mine < p.iters ? mine : p.iters;
+  const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
+  const unsigned row1 = (unsigned)N * row_bytes;
+  auto tile_of = [&](int it) -> int { return wt + it * W; };
+  auto voff_of = [&](int it) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + c16;
+    return (it < iters && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
+  };
+  auto mask_of = [&](int it) -> unsigned {
+    const int px = tile_of(it) * TP + wv * 16 + c16;
+    return mask[(it < iters && px < N) ? px : 0];
+  };
+  V8 yr0[RING], yr1[RING];
+  unsigned voff = voff_of(0), voffn = voff_of(1);
+  unsigned mb = mask_of(0);
+#pragma unroll
+  for (int j = 0; j < RING; ++j) {
+    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
+    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
+  }
+  const f32x4 kb4 = last_tile_bias(g, p.M);
+  const float sl2e = p.sl2e;
+  const int sumrow = (d & 15) ? (d & 15) : -1;
+  const unsigned kmask = (1u << K) - 1u;
+  wait_dma_and_sync();
+
+  for (int it = 0; it < iters; ++it) {
+    f32x4 qa0[NDT], qa1[NDT];
+#pragma unroll
+    for (int u = 0; u < NDT; ++u) {
+      qa0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      qa1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const V8* wf = (const V8*)lds_ring + lane;
+    // RING k-steps = RING / CH chunks per trip: ring slots and LDS slots have compile-time indices
+    for (int s0 = 0; s0 < nkc; s0 += RING) {
+#pragma unroll
+      for (int cc = 0; cc < RING / CH; ++cc) {
+        const int c = s0 / CH + cc;               // this tile's chunk, in LDS slot cc & 1 (RING / CH is even)
+        stage_chunk(c + 1 < NC ? c + 1 : 0, (cc + 1) & 1);
+#pragma unroll
+        for (int jj = 0; jj < CH; ++jj) {
+          const int j = cc * CH + jj, s = s0 + j;
+          V8 a[NDT];
+#pragma unroll
+          for (int u = 0; u < NDT; ++u) a[u] = wf[(((cc & 1) * CH + jj) * NDT + u) * 64];
+#pragma unroll
+          for (int u = 0; u < NDT; ++u) {
+            qa0[u] = Tr<T>::mfma(a[u], yr0[j], qa0[u]);
+            qa1[u] = Tr<T>::mfma(a[u], yr1[j], qa1[u]);
+          }
+          const bool wrap = s + RING >= nkc;
+          const unsigned vo = wrap ? voffn : voff;
+          const unsigned so = 64u * (unsigned)(wrap ? s + RING - nkc : s + RING);
+          yr0[j] = srd_load16<V8>(y_srd, vo, so);
+          yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+        }
+        // the next chunk's pieces are older than this chunk's 2 * CH y refills: everything but those has landed
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * CH) : "memory");
+        __syncthreads();
+      }
+    }
+    const int px_own = tile_of(it) * TP + wv * 16 + c16;
+    const bool valid = px_own < N;
+    voff = voffn;
+    voffn = voff_of(it + 2);
+    const unsigned mbn = mask_of(it + 1);
+    V8 q0[1][NKS], q1[1][NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int t = 2 * s + (j >> 2);
+        q0[0][s][j] = (t < NDT) ? (T)qa0[t][j & 3] : (T)0.0f;
+        q1[0][s][j] = (t < NDT) ? (T)qa1[t][j & 3] : (T)0.0f;
+      }
+    f32x4 au[1][NDT], ac[1][NDT];
+    float w[1] = {0.f};
+    attend_staged<T, NDT, 1, 0>((const V8*)lds_ctx + lane, q0, kb4, sl2e, w, au, ac, sumrow);
+    attend_staged<T, NDT, 1, 1>((const V8*)(lds_ctx + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
+    const unsigned mbits = valid ? (mb & kmask) : 0u;
+    for (int i = 0; i < K; ++i) {
+      if (!__ballot((mbits >> i) & 1u)) continue;
+      const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+      w[0] = ((mbits >> i) & 1u) ? cw : 0.f;
+      gfr.soff = (unsigned)(((2 + i) * p.H + h) * CB);
+      attend_staged<T, NDT, 1, 2>(gfr, q1, kb4, sl2e, w, au, ac, sumrow);
+    }
+    if (valid) {
+      T* obase = ob + (size_t)px_own * C + h * d;
+      store_row16<T, NDT>(obase, au[0], g, d);
+      store_row16<T, NDT>(obase + (size_t)N * C, ac[0], g, d);
+    }
+    mb = mbn;
+  }
+}
+
+template <typename T, int NDT>
+int launch_proj_wqs(PParams p, int n_img, hipStream_t st) {
+  constexpr int TP = 128;
+  p.tiles = (p.N + TP - 1) / TP;
+  long wg_per_head = 256L / ((long)p.H * n_img);
+  if (wg_per_head < 1) wg_per_head = 1;
+  if (wg_per_head > p.tiles) wg_per_head = p.tiles;
+  p.iters = (int)((p.tiles + wg_per_head - 1) / wg_per_head);
+  if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) p.iters = v < p.tiles ? v : p.tiles;
+  p.W = (p.tiles + p.iters - 1) / p.iters;
+  const int lds = (2 * WQS_CH * NDT + 2 * fwd_frags(NDT)) * FRAG;
+  static StaLdsAttr attr;
+  if (!attr.ensure((const void*)xattn_fwd_proj_wqs_kernel<T, NDT>, 160 * 1024)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj, streamed Wq) failed");
+  hipLaunchKernelGGL((xattn_fwd_proj_wqs_kernel<T, NDT>), dim3(p.W * p.H, n_img), dim3(512), lds, st, p);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj (streamed Wq) launch: %s", hipGetErrorString(e));
+}
+
 template <typename T, int NDT, int NWV, int RING, bool LL2 = false, bool YFRAG = false>
 int launch_proj_cfg(PParams p, int n_img, int lds, hipStream_t st) {
   constexpr int TP = 16 * NWV;
@@ -343,8 +522,17 @@ int dispatch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
 // LDS plan of a launch: everything resident where that fits a CU (160 KiB); else, where the Wq slice and the two mandatory
 // contexts fit (and the kernel exists: d = 80), those stay resident and the local contexts come from L2 (`ll2`).
 constexpr int LDS_CU = 160 * 1024;
+// does the shape take the streamed-Wq kernel? (Wq slice + the two mandatory contexts do not fit a CU: d = 144 / 160 with C % 128 == 0)
+bool proj_streams_wq(int C, int heads) {
+  const int d = C / heads, ndt = (d + 15) / 16;
+  return ndt >= 9 && ndt <= 10 && C % (32 * WQS_RING) == 0 && (2 * WQS_CH * ndt + 2 * fwd_frags(ndt)) * FRAG <= LDS_CU;
+}
 int proj_lds_bytes(int C, int heads, int K, bool* ll2 = nullptr) {
   const int d = C / heads, ndt = (d + 15) / 16;
+  if (proj_streams_wq(C, heads)) {
+    if (ll2) *ll2 = false;
+    return (2 * WQS_CH * ndt + 2 * fwd_frags(ndt)) * FRAG;
+  }
   const int full = (ndt * (C / 32) + (K + 2) * fwd_frags(ndt)) * FRAG;
   const int two = (ndt * (C / 32) + 2 * fwd_frags(ndt)) * FRAG;
   const bool l = full > LDS_CU && two <= LDS_CU && ndt == 5 && g_sta_opt[STA_OPT_PROJ_LL2] != 2;
@@ -356,7 +544,8 @@ int check_proj_shape(int N, int C, int heads, int M, int K) {
   if (N <= 0 || C <= 0 || heads <= 0 || M <= 0 || K < 0) return sta_fail(STA_E_ARG, "non-positive dimension");
   if (C % heads) return sta_fail(STA_E_ARG, "C=%d not divisible by heads=%d", C, heads);
   const int d = C / heads;
-  if (d % 8 || d > 96) return sta_fail(STA_E_UNSUP, "head dim %d unsupported by the projection-fused forward (d %% 8 == 0, d <= 96)", d);
+  if (d % 8 || (d > 96 && !proj_streams_wq(C, heads)))
+    return sta_fail(STA_E_UNSUP, "head dim %d unsupported by the projection-fused forward (d %% 8 == 0; d <= 96, or 128 < d <= 160 with C %% 128 == 0: Wq streamed)", d);
   if (C % (32 * RING_MIN)) return sta_fail(STA_E_UNSUP, "C=%d unsupported by the projection-fused forward (need C %% %d == 0)", C, 32 * RING_MIN);
   if (M > STA_MAX_KEYS || M <= 16 * (NKT - 1)) return sta_fail(STA_E_UNSUP, "M=%d keys unsupported (65..%d)", M, STA_MAX_KEYS);
   if (K > STA_MAX_OBJECTS) return sta_fail(STA_E_UNSUP, "K=%d objects unsupported (max %d)", K, STA_MAX_OBJECTS);
@@ -527,6 +716,11 @@ static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packe
     const char* wq_pair = (const char*)packed_wq + (size_t)heads * ndt * (C / 32) * FRAG;
     const char* kv3 = (const char*)packed_kv + (size_t)n_img * (K + 2) * heads * fwd_frags(ndt) * FRAG;
     return sta_p3::forward(y, wq_pair, kv3, p.mask, p.coef, out, n_img, N, C, heads, M, K, p.sl2e, dtype, st, qfrag, ofrag, (unsigned*)stats);
+  }
+  if (proj_streams_wq(C, heads)) {      // SD-v1 levels 2 / mid: Wq streamed through an LDS ring, two contexts resident, locals from L2
+    if (qfrag || ofrag) return sta_fail(STA_E_UNSUP, "the streamed-Wq kernel reads y row-major");
+    if ((p.d + 15) / 16 == 10) return dtype == STA_BF16 ? launch_proj_wqs<__bf16, 10>(p, n_img, st) : launch_proj_wqs<_Float16, 10>(p, n_img, st);
+    return dtype == STA_BF16 ? launch_proj_wqs<__bf16, 9>(p, n_img, st) : launch_proj_wqs<_Float16, 9>(p, n_img, st);
   }
   if (ll2) {      // SD-v1 level 1: Wq + the two mandatory contexts resident, local contexts from L2
     if (qfrag && N % 16) return sta_fail(STA_E_UNSUP, "query-fragment order needs N %% 16 == 0 (N=%d)", N);

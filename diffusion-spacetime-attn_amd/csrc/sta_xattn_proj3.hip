@@ -31,8 +31,8 @@
 #include "sta_xattn_dev.h"
 #include "sta_xattn_proj3.h"
 
-// (The ablation / timeline / fragment-order-store experiment build of this kernel, which profiles/r03_level0.md and
-// profiles/r04_level0.md quote, lives in tools/experiments/sta_xattn_proj3_ablate.hip; tools/lib_ab.py swaps it in.)
+// (The ablation / timeline build of this kernel that profiles/r03_level0.md and profiles/r04_level0.md quote was a copy of the round-4
+// source; it no longer matched this file — optimistic softmax, swizzled operand slots — and was deleted in round 6: git history has it.)
 
 namespace {
 

@@ -769,6 +769,12 @@ PROJ_SHAPES = [
     (1000, 640, 8, 3, 2, 3, 0, True),        # ... ragged N, three objects, forced tile count
     (1024, 640, 8, 1, 3, None, 4, True),     # ... one object, 4-wave workgroups (falls back to 8: the variant is built for 8 waves)
     (2304, 640, 8, 4, 1, None, 0, True),     # BASELINE configs[4] level 1 (768^2, 4 objects)
+    (256, 1280, 8, 2, 4, None, 0, True),     # SD-v1 level 2 (d = 160): Wq STREAMED through an LDS ring, contexts 0 / 1 resident, locals from L2
+    (256, 1280, 8, 2, 16, 2, 0, True),       # ... 16 prompts, two tiles per workgroup (the ring runs through the attention phase)
+    (64, 1280, 8, 2, 8, None, 0, True),      # the middle block: half of the workgroup's waves have no pixels
+    (576, 1280, 8, 4, 2, None, 0, True),     # BASELINE configs[4] level 2 (768^2, 4 objects), ragged last tile
+    (100, 1152, 8, 1, 3, None, 0, True),     # d = 144 (9 head-dim tiles), ragged N
+    (144, 1280, 8, 0, 2, None, 0, True),     # 768^2 middle block, no objects
 ]
 
 

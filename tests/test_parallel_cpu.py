@@ -119,6 +119,26 @@ def test_bench_starts_its_own_ranks_dry_launch():
     assert out["global_batch"] == 64 and out["first_prompts_of_step0"] == [0, 1, 32, 33]
 
 
+def test_bench_eight_ranks_dry_launch_is_the_config3_split():
+    """`python bench.py --gpus 8 --scaling strong --dry-launch` — BASELINE configs[3] as the driver's 8-GPU run will start it, minus the
+    kernels: eight self-started ranks over gloo, one rendezvous on 127.0.0.1, rank 0's weights on every rank, and per rank its own eight
+    prompts of the 64 (disjoint, together all of them), its own local rank / device slot and its own MIOpen user-db copy."""
+    r, lines = _run_bench("--gpus", "8", "--dry-launch", "--scaling", "strong")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["backend"] == "gloo" and out["weights_identical_on_every_rank"]
+    assert out["scaling"] == "strong" and out["images_per_step"] == 8 and out["global_batch"] == 64
+    ranks = sorted(out["ranks"], key=lambda x: x["rank"])
+    assert [x["rank"] for x in ranks] == list(range(8)) and [x["local_rank"] for x in ranks] == list(range(8))
+    assert all(len(x["prompts_step0"]) == 8 for x in ranks)
+    assert sorted(p for x in ranks for p in x["prompts_step0"]) == list(range(64))            # disjoint and complete
+    assert len({x["master"] for x in ranks}) == 1 and ranks[0]["master"].startswith("127.0.0.1:")
+    assert len({x["pid"] for x in ranks}) == 8
+    dbs = [x["miopen_user_db"] for x in ranks]
+    assert all(d is None for d in dbs) or (len(set(dbs)) == 8 and all(d.endswith("rank%d" % i) for i, d in enumerate(dbs)))
+
+
 def test_bench_strong_scaling_split_and_world_mismatch():
     r, lines = _run_bench("--gpus", "2", "--dry-launch", "--scaling", "strong")
     assert r.returncode == 0, r.stderr[-2000:]

@@ -75,7 +75,9 @@ def test_rccl_broadcast_two_ranks(tmp_path):
     or more GPUs. On a one-GPU box two ranks would have to share the device — outside what RCCL supports — so the test
     is skipped there unless STA_TEST_RCCL_2RANK=1 asks for the attempt."""
     if torch.cuda.device_count() < 2 and os.environ.get("STA_TEST_RCCL_2RANK") != "1":
-        pytest.skip("needs 2 GPUs (one rank per GPU); STA_TEST_RCCL_2RANK=1 tries two ranks on one device")
+        pytest.skip("this box has %d GPU(s): the 2-rank RCCL broadcast needs one rank per GPU (STA_TEST_RCCL_2RANK=1 tries two ranks on one "
+                    "device); the N > 1 plumbing itself runs in test_bench_two_ranks_sharing_one_gpu_end_to_end and, without kernels, on 8 "
+                    "gloo ranks in tests/test_parallel_cpu.py" % torch.cuda.device_count())
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     res = [json.load(open(tmp_path / ("r%d.json" % r))) for r in range(2)]
     if torch.cuda.device_count() < 2 and any("error" in r for r in res):
@@ -107,7 +109,8 @@ def test_bench_two_ranks_end_to_end():
     """The whole N = 2 bench (weights over RCCL, per-rank MIOpen db copies, hipGraph capture in two processes, barrier + max over
     ranks) at a small size; needs two GPUs."""
     if torch.cuda.device_count() < 2:
-        pytest.skip("needs 2 GPUs (one rank per GPU)")
+        pytest.skip("this box has %d GPU(s): the 2-rank end-to-end bench over RCCL needs one rank per GPU; --share-gpu (next test) runs the "
+                    "same path with both ranks on GPU 0 and gloo collectives" % torch.cuda.device_count())
     r, lines = _bench("--gpus", "2", "--steps", "1", "--warmup", "1", "--images-per-step", "2", "--ddim_steps", "4", timeout=1500)
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
     out = json.loads(lines[0])

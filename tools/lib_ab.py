@@ -23,8 +23,8 @@ for v in variants:
         continue
     objs = []
     flag_list = [f for f in flags.split(",") if f]
-    # "src:<product file>=<path>" swaps one translation unit for an experiment build of it (tools/experiments/*.hip), e.g.
-    #   skel=-DSTA_P3_ABLATE=19,src:sta_xattn_proj3.hip=tools/experiments/sta_xattn_proj3_ablate.hip
+    # "src:<product file>=<path>" swaps one translation unit for an experiment build of it (a modified copy kept outside csrc/), e.g.
+    #   try=src:sta_xattn_proj3.hip=/tmp/sta_xattn_proj3_try.hip
     swaps = dict(f[4:].split("=", 1) for f in flag_list if f.startswith("src:"))
     flag_list = [f for f in flag_list if not f.startswith("src:")]
     import tempfile
