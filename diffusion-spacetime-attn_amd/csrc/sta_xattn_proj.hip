@@ -306,14 +306,14 @@ __global__ __launch_bounds__(64 * NWV, 2) void xattn_fwd_proj_kernel(const PPara
 // against the 2 x 84 MB HBM round trip of q and a library GEMM launch it replaces.
 constexpr int WQS_CH = 2;        // k-steps per Wq chunk
 constexpr int WQS_RING = 4;      // y k-steps in flight per batch row (divides nkc together with WQS_CH: C % 128 == 0)
-template <typename T, int NDT>
-__global__ __launch_bounds__(512, 1) void xattn_fwd_proj_wqs_kernel(const PParams p) {
+template <typename T, int NDT, int NWV, int QT>
+__global__ __launch_bounds__(64 * NWV, 1) void xattn_fwd_proj_wqs_kernel(const PParams p) {
   using V8 = typename Tr<T>::V8;
-  constexpr int NWV = 8, RING = WQS_RING, CH = WQS_CH;
+  constexpr int RING = WQS_RING, CH = WQS_CH;
   constexpr int NKS = nks_of(NDT);
   constexpr int NFWD = fwd_frags(NDT);
   constexpr int CB = NFWD * FRAG;                 // bytes of one staged context
-  constexpr int TP = 16 * NWV;
+  constexpr int TP = 16 * NWV * QT;               // pixels per tile: NWV waves x QT sub-tiles x 16
   constexpr int CF = CH * NDT;                    // fragments per chunk
   constexpr int PIECES = (CF + NWV - 1) / NWV;    // DMA pieces per wave and chunk (the last ones may repeat a fragment: same bytes, same place)
   const int lane = threadIdx.x & 63;
@@ -359,22 +359,27 @@ __global__ __launch_bounds__(512, 1) void xattn_fwd_proj_wqs_kernel(const PParam
   const int iters = mine < p.iters ? mine : p.iters;
   const __amdgpu_buffer_rsrc_t y_srd = make_srd(yb, (unsigned)act);
   const unsigned row1 = (unsigned)N * row_bytes;
-  auto tile_of = [&](int it) -> int { return wt + it * W; };
-  auto voff_of = [&](int it) -> unsigned {
-    const int px = tile_of(it) * TP + wv * 16 + c16;
+  auto px_of = [&](int it, int qt) -> int { return (wt + it * W) * TP + (wv * QT + qt) * 16 + c16; };
+  auto voff_of = [&](int it, int qt) -> unsigned {
+    const int px = px_of(it, qt);
     return (it < iters && px < N) ? (unsigned)px * row_bytes + (unsigned)g * 16u : 0xfffffff0u;
   };
-  auto mask_of = [&](int it) -> unsigned {
-    const int px = tile_of(it) * TP + wv * 16 + c16;
+  auto mask_of = [&](int it, int qt) -> unsigned {
+    const int px = px_of(it, qt);
     return mask[(it < iters && px < N) ? px : 0];
   };
-  V8 yr0[RING], yr1[RING];
-  unsigned voff = voff_of(0), voffn = voff_of(1);
-  unsigned mb = mask_of(0);
+  V8 yr0[QT][RING], yr1[QT][RING];
+  unsigned voff[QT], voffn[QT], mb[QT];
 #pragma unroll
-  for (int j = 0; j < RING; ++j) {
-    yr0[j] = srd_load16<V8>(y_srd, voff, 64u * j);
-    yr1[j] = srd_load16<V8>(y_srd, voff, row1 + 64u * j);
+  for (int qt = 0; qt < QT; ++qt) {
+    voff[qt] = voff_of(0, qt);
+    voffn[qt] = voff_of(1, qt);
+    mb[qt] = mask_of(0, qt);
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+      yr0[qt][j] = srd_load16<V8>(y_srd, voff[qt], 64u * j);
+      yr1[qt][j] = srd_load16<V8>(y_srd, voff[qt], row1 + 64u * j);
+    }
   }
   const f32x4 kb4 = last_tile_bias(g, p.M);
   const float sl2e = p.sl2e;
@@ -383,12 +388,14 @@ __global__ __launch_bounds__(512, 1) void xattn_fwd_proj_wqs_kernel(const PParam
   wait_dma_and_sync();
 
   for (int it = 0; it < iters; ++it) {
-    f32x4 qa0[NDT], qa1[NDT];
+    f32x4 qa0[QT][NDT], qa1[QT][NDT];
 #pragma unroll
-    for (int u = 0; u < NDT; ++u) {
-      qa0[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      qa1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+      for (int u = 0; u < NDT; ++u) {
+        qa0[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        qa1[qt][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     const V8* wf = (const V8*)lds_ring + lane;
     // RING k-steps = RING / CH chunks per trip: ring slots and LDS slots have compile-time indices
     for (int s0 = 0; s0 < nkc; s0 += RING) {
@@ -399,63 +406,78 @@ __global__ __launch_bounds__(512, 1) void xattn_fwd_proj_wqs_kernel(const PParam
 #pragma unroll
         for (int jj = 0; jj < CH; ++jj) {
           const int j = cc * CH + jj, s = s0 + j;
-          V8 a[NDT];
-#pragma unroll
-          for (int u = 0; u < NDT; ++u) a[u] = wf[(((cc & 1) * CH + jj) * NDT + u) * 64];
 #pragma unroll
           for (int u = 0; u < NDT; ++u) {
-            qa0[u] = Tr<T>::mfma(a[u], yr0[j], qa0[u]);
-            qa1[u] = Tr<T>::mfma(a[u], yr1[j], qa1[u]);
+            const V8 a = wf[(((cc & 1) * CH + jj) * NDT + u) * 64];      // one fragment read serves 2 QT MFMAs
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+              qa0[qt][u] = Tr<T>::mfma(a, yr0[qt][j], qa0[qt][u]);
+              qa1[qt][u] = Tr<T>::mfma(a, yr1[qt][j], qa1[qt][u]);
+            }
           }
           const bool wrap = s + RING >= nkc;
-          const unsigned vo = wrap ? voffn : voff;
           const unsigned so = 64u * (unsigned)(wrap ? s + RING - nkc : s + RING);
-          yr0[j] = srd_load16<V8>(y_srd, vo, so);
-          yr1[j] = srd_load16<V8>(y_srd, vo, row1 + so);
+#pragma unroll
+          for (int qt = 0; qt < QT; ++qt) {
+            const unsigned vo = wrap ? voffn[qt] : voff[qt];
+            yr0[qt][j] = srd_load16<V8>(y_srd, vo, so);
+            yr1[qt][j] = srd_load16<V8>(y_srd, vo, row1 + so);
+          }
         }
-        // the next chunk's pieces are older than this chunk's 2 * CH y refills: everything but those has landed
-        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * CH) : "memory");
+        // the next chunk's pieces are older than this chunk's 2 * CH * QT y refills: everything but those has landed
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * CH * QT) : "memory");
         __syncthreads();
       }
     }
-    const int px_own = tile_of(it) * TP + wv * 16 + c16;
-    const bool valid = px_own < N;
-    voff = voffn;
-    voffn = voff_of(it + 2);
-    const unsigned mbn = mask_of(it + 1);
-    V8 q0[1][NKS], q1[1][NKS];
+    bool valid[QT];
+    unsigned mbits[QT];
+    V8 q0[QT][NKS], q1[QT][NKS];
 #pragma unroll
-    for (int s = 0; s < NKS; ++s)
+    for (int qt = 0; qt < QT; ++qt) {
+      valid[qt] = px_of(it, qt) < N;
+      mbits[qt] = valid[qt] ? (mb[qt] & kmask) : 0u;
+      voff[qt] = voffn[qt];
+      voffn[qt] = voff_of(it + 2, qt);
+      mb[qt] = mask_of(it + 1, qt);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int t = 2 * s + (j >> 2);
-        q0[0][s][j] = (t < NDT) ? (T)qa0[t][j & 3] : (T)0.0f;
-        q1[0][s][j] = (t < NDT) ? (T)qa1[t][j & 3] : (T)0.0f;
-      }
-    f32x4 au[1][NDT], ac[1][NDT];
-    float w[1] = {0.f};
-    attend_staged<T, NDT, 1, 0>((const V8*)lds_ctx + lane, q0, kb4, sl2e, w, au, ac, sumrow);
-    attend_staged<T, NDT, 1, 1>((const V8*)(lds_ctx + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
-    const unsigned mbits = valid ? (mb & kmask) : 0u;
+      for (int s = 0; s < NKS; ++s)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int t = 2 * s + (j >> 2);
+          q0[qt][s][j] = (t < NDT) ? (T)qa0[qt][t][j & 3] : (T)0.0f;
+          q1[qt][s][j] = (t < NDT) ? (T)qa1[qt][t][j & 3] : (T)0.0f;
+        }
+    }
+    f32x4 au[QT][NDT], ac[QT][NDT];
+    float w[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) w[qt] = 0.f;
+    attend_staged<T, NDT, QT, 0>((const V8*)lds_ctx + lane, q0, kb4, sl2e, w, au, ac, sumrow);
+    attend_staged<T, NDT, QT, 1>((const V8*)(lds_ctx + CB) + lane, q1, kb4, sl2e, w, au, ac, sumrow);
     for (int i = 0; i < K; ++i) {
-      if (!__ballot((mbits >> i) & 1u)) continue;
+      bool any = false;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) any = any || __ballot((mbits[qt] >> i) & 1u) != 0;
+      if (!any) continue;                          // none of this wave's pixels inside disc i
       const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
-      w[0] = ((mbits >> i) & 1u) ? cw : 0.f;
+#pragma unroll
+      for (int qt = 0; qt < QT; ++qt) w[qt] = ((mbits[qt] >> i) & 1u) ? cw : 0.f;
       gfr.soff = (unsigned)(((2 + i) * p.H + h) * CB);
-      attend_staged<T, NDT, 1, 2>(gfr, q1, kb4, sl2e, w, au, ac, sumrow);
+      attend_staged<T, NDT, QT, 2>(gfr, q1, kb4, sl2e, w, au, ac, sumrow);
     }
-    if (valid) {
-      T* obase = ob + (size_t)px_own * C + h * d;
-      store_row16<T, NDT>(obase, au[0], g, d);
-      store_row16<T, NDT>(obase + (size_t)N * C, ac[0], g, d);
-    }
-    mb = mbn;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+      if (valid[qt]) {
+        T* obase = ob + (size_t)px_of(it, qt) * C + h * d;
+        store_row16<T, NDT>(obase, au[qt], g, d);
+        store_row16<T, NDT>(obase + (size_t)N * C, ac[qt], g, d);
+      }
   }
 }
 
-template <typename T, int NDT>
+template <typename T, int NDT, int NWV, int QT>
 int launch_proj_wqs(PParams p, int n_img, hipStream_t st) {
-  constexpr int TP = 128;
+  constexpr int TP = 16 * NWV * QT;
   p.tiles = (p.N + TP - 1) / TP;
   long wg_per_head = 256L / ((long)p.H * n_img);
   if (wg_per_head < 1) wg_per_head = 1;
@@ -465,8 +487,8 @@ int launch_proj_wqs(PParams p, int n_img, hipStream_t st) {
   p.W = (p.tiles + p.iters - 1) / p.iters;
   const int lds = (2 * WQS_CH * NDT + 2 * fwd_frags(NDT)) * FRAG;
   static StaLdsAttr attr;
-  if (!attr.ensure((const void*)xattn_fwd_proj_wqs_kernel<T, NDT>, 160 * 1024)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj, streamed Wq) failed");
-  hipLaunchKernelGGL((xattn_fwd_proj_wqs_kernel<T, NDT>), dim3(p.W * p.H, n_img), dim3(512), lds, st, p);
+  if (!attr.ensure((const void*)xattn_fwd_proj_wqs_kernel<T, NDT, NWV, QT>, 160 * 1024)) return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj, streamed Wq) failed");
+  hipLaunchKernelGGL((xattn_fwd_proj_wqs_kernel<T, NDT, NWV, QT>), dim3(p.W * p.H, n_img), dim3(64 * NWV), lds, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj (streamed Wq) launch: %s", hipGetErrorString(e));
 }
@@ -522,10 +544,10 @@ int dispatch_proj(const PParams& p, int n_img, int lds, hipStream_t st) {
 // LDS plan of a launch: everything resident where that fits a CU (160 KiB); else, where the Wq slice and the two mandatory
 // contexts fit (and the kernel exists: d = 80), those stay resident and the local contexts come from L2 (`ll2`).
 constexpr int LDS_CU = 160 * 1024;
-// does the shape take the streamed-Wq kernel? (Wq slice + the two mandatory contexts do not fit a CU: d = 144 / 160 with C % 128 == 0)
+// does the shape take the streamed-Wq kernel? (Wq slice + the two mandatory contexts do not fit a CU: 144 < d <= 160 with C % 128 == 0)
 bool proj_streams_wq(int C, int heads) {
   const int d = C / heads, ndt = (d + 15) / 16;
-  return ndt >= 9 && ndt <= 10 && C % (32 * WQS_RING) == 0 && (2 * WQS_CH * ndt + 2 * fwd_frags(ndt)) * FRAG <= LDS_CU;
+  return ndt == 10 && C % (32 * WQS_RING) == 0 && (2 * WQS_CH * ndt + 2 * fwd_frags(ndt)) * FRAG <= LDS_CU;
 }
 int proj_lds_bytes(int C, int heads, int K, bool* ll2 = nullptr) {
   const int d = C / heads, ndt = (d + 15) / 16;
@@ -719,8 +741,11 @@ static int fwd_proj_impl(const void* y, const void* packed_wq, const void* packe
   }
   if (proj_streams_wq(C, heads)) {      // SD-v1 levels 2 / mid: Wq streamed through an LDS ring, two contexts resident, locals from L2
     if (qfrag || ofrag) return sta_fail(STA_E_UNSUP, "the streamed-Wq kernel reads y row-major");
-    if ((p.d + 15) / 16 == 10) return dtype == STA_BF16 ? launch_proj_wqs<__bf16, 10>(p, n_img, st) : launch_proj_wqs<_Float16, 10>(p, n_img, st);
-    return dtype == STA_BF16 ? launch_proj_wqs<__bf16, 9>(p, n_img, st) : launch_proj_wqs<_Float16, 9>(p, n_img, st);
+    // STA_OPT_STAGED_QT = 2: four waves x two 16-pixel tiles per wave (one wave per SIMD, each Wq fragment read serves four MFMAs);
+    // default: eight waves x one tile
+    if (g_sta_opt[STA_OPT_STAGED_QT] == 2)
+      return dtype == STA_BF16 ? launch_proj_wqs<__bf16, 10, 4, 2>(p, n_img, st) : launch_proj_wqs<_Float16, 10, 4, 2>(p, n_img, st);
+    return dtype == STA_BF16 ? launch_proj_wqs<__bf16, 10, 8, 1>(p, n_img, st) : launch_proj_wqs<_Float16, 10, 8, 1>(p, n_img, st);
   }
   if (ll2) {      // SD-v1 level 1: Wq + the two mandatory contexts resident, local contexts from L2
     if (qfrag && N % 16) return sta_fail(STA_E_UNSUP, "query-fragment order needs N %% 16 == 0 (N=%d)", N);

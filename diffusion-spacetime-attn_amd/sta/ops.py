@@ -192,6 +192,16 @@ PROJ_LL2_IN_MODEL = True      # does the model take the locals-from-L2 variant (
                               # (measured in situ against the to_q GEMM + sta_xattn_fwd: profiles/r05_level1_proj.md)
 
 
+PROJ_WQS_IN_MODEL = False     # does the model take the STREAMED-Wq variant (SD-v1 levels 2 / mid, d = 160)? Built and oracle-exact in round 6, and measured
+                              # SLOWER than the library to_q GEMM + sta_xattn_fwd it would replace (64 images, N = 256: 241 vs 194 us warm, 292 vs 219 us from
+                              # HBM; N = 64: 91 vs 66): one Wq fragment read feeds two MFMAs and every chunk ends in a barrier (profiles/r06_level2_proj.md)
+
+
+def proj_streams_wq(C, heads):
+    """Shapes whose Wq slice does not fit a CU: sta_xattn_fwd_proj streams it through an LDS ring (csrc/sta_xattn_proj.hip)."""
+    return C % heads == 0 and 144 < C // heads <= 160 and C % 128 == 0
+
+
 def proj_locals_from_l2(C, heads, M, K):
     """Shapes sta_xattn_fwd_proj takes with only Wq + the two mandatory contexts resident (local contexts read from L2)."""
     return bool(_lib.load().sta_xattn_fwd_proj_locals_from_l2(C, heads, M, K))
@@ -205,6 +215,8 @@ def proj_supported(C, heads, M, K, N=None, n_img=1):
     if N is None:
         return True
     if proj_locals_from_l2(C, heads, M, K) and not PROJ_LL2_IN_MODEL:
+        return False
+    if proj_streams_wq(C, heads) and not PROJ_WQS_IN_MODEL:
         return False
     return ((N + 127) // 128) * heads * n_img >= PROJ_MIN_WORKGROUPS
 

@@ -773,7 +773,7 @@ PROJ_SHAPES = [
     (256, 1280, 8, 2, 16, 2, 0, True),       # ... 16 prompts, two tiles per workgroup (the ring runs through the attention phase)
     (64, 1280, 8, 2, 8, None, 0, True),      # the middle block: half of the workgroup's waves have no pixels
     (576, 1280, 8, 4, 2, None, 0, True),     # BASELINE configs[4] level 2 (768^2, 4 objects), ragged last tile
-    (100, 1152, 8, 1, 3, None, 0, True),     # d = 144 (9 head-dim tiles), ragged N
+    (100, 1280, 8, 1, 3, None, 0, True),     # ragged N (not a multiple of 16), one object
     (144, 1280, 8, 0, 2, None, 0, True),     # 768^2 middle block, no objects
 ]
 
