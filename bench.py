@@ -348,7 +348,7 @@ def roofline_leg(model, dev, dt, dtype_name, I, K, lat, rec, centres):
                          "mfma_tflops": all_flops / all_us / 1e6, "mfma_frac": all_flops / all_us / 1e6 / MFMA_PEAK_TFLOPS},
         "per_shape_us": {"%s_N%d_C%d" % k_: round(sum(r["us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])},
         "per_shape_warm_us": {"%s_N%d_C%d" % k_: round(sum(r["warm_us"] for r in v) / len(v), 2) for k_, v in sorted(by_shape.items(), key=lambda kv: -kv[0][1])}}
-    prof = os.path.join(REPO, "profiles", "r05_bench_kernel_stats.csv")
+    prof = os.path.join(REPO, "profiles", "r06_bench_kernel_stats.csv")
     if os.path.exists(prof) and dtype_name == "fp16":      # rocprofv3 --kernel-trace summary of this command, committed: the cross-check
         import csv
         want = "xattn_fwd_proj" if dom[0] == "proj" else "xattn_fwd_staged"      # xattn_fwd_proj_p3_kernel / xattn_fwd_proj_kernel

@@ -217,7 +217,7 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
                                         const typename Tr<T>::V8& qbig, const typename Tr<T>::V4& qsm, const f32x4 kb4,
                                         const float sl2e, const float w, f32x4 (&au)[3], f32x4 (&ac)[3],
                                         const char* kcb = nullptr, const char* kcs = nullptr, const bool opt_on = true,
-                                        unsigned* n_att = nullptr, unsigned* n_fb = nullptr) {
+                                        unsigned* cnt = nullptr) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   if constexpr (kOptimistic<T>) {
@@ -262,12 +262,11 @@ __device__ __forceinline__ void attend3(KFr<T>& kf, const char* vb, const char* 
     const bool row2 = (threadIdx.x & 48) == 32;
     const bool bad = row2 && (__float_as_uint(o[2][0]) - kDenLo<T>) >= (kDenHi<T> - kDenLo<T>);
     need_std = __builtin_amdgcn_ballot_w64(bad) != 0;
-    if (n_att) {                                     // (scalar counters of the wave: sta_xattn_fwd_proj_ex's statistics)
-      *n_att += 1u;
-      *n_fb += need_std ? 1u : 0u;
-    }
     }
     if (__builtin_expect(need_std, 0)) {
+      // sta_xattn_fwd_proj_ex's statistics: a fall-back (not a sit-out) adds one to the workgroup's LDS counter — here on the rare path,
+      // nothing in the common one (a lane-0 add per context evaluation there cost 2.7 % of the launch; the evaluations are counted per item)
+      if (cnt && opt_on && (threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       load_k<T>(kf, kcb, kcs);                      // kf doubles as the buffer: the next context's operands are requested again below
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
@@ -471,8 +470,14 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
   const int voffb = KBYTES + c16 * VROW + 16 * swz_big(g, c16), voffs = KBYTES + c16 * VROW + 128 + 8 * swz_small(g, c16);
   const V8* wf = (const V8*)lds_wq + lane;
   // optimistic softmax or not: the caller's state word (launches still to sit out; sta_xattn_fwd_proj_ex) — one value per launch
+#ifndef STA_P3_STATS
+#define STA_P3_STATS 1        // 0: no statistics / switch code in the kernel (same-box A/B builds: tools/lib_ab.py ... nostats=-DSTA_P3_STATS=0)
+#endif
+#if STA_P3_STATS
   const bool opt_on = p.stats == nullptr || __builtin_amdgcn_readfirstlane((int)__builtin_nontemporal_load(p.stats)) == 0;
-  unsigned n_att = 0, n_fb = 0;
+#else
+  constexpr bool opt_on = true;
+#endif
   if (threadIdx.x == 0) { qcount[1] = 0u; qcount[2] = 0u; }
   wait_dma_and_sync();
   if constexpr (kOptimistic<T>) {
@@ -487,8 +492,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     __syncthreads();
   }
 
-  unsigned* const cnt_a = p.stats ? &n_att : nullptr;
-  unsigned* const cnt_f = p.stats ? &n_fb : nullptr;
+  unsigned* const cnt_a = (STA_P3_STATS && p.stats) ? qcount + 1 : nullptr;      // LDS counters; every 8th workgroup reports them (tail)
   while (qcur < nitems) {
     // ---- projection: 5 column tiles x both batch rows; Wq fragments one k-step ahead -------------------------------
     f32x4 qa0[NT], qa1[NT];
@@ -562,13 +566,17 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
     const int px_own = px0_of(qcur) + c16;
     const bool valid = px_own < N;
     // the item after next: one LDS atomic by lane 0, consumed at the end of this item (its latency sits under the attention)
-    unsigned qtake = 0;
-    if (lane == 0) qtake = atomicAdd(qcount, 1u);
     const unsigned mbn = mask_of(qnext);
     const unsigned mbits = valid ? (mb & kmask) : 0u;
     // local contexts some pixel of this wave needs (wave-uniform bit set)
     unsigned wneed = 0;
     for (int i = 0; i < K; ++i) wneed |= __ballot((mbits >> i) & 1u) ? (1u << i) : 0u;
+    unsigned qtake = 0;
+    if (lane == 0) {
+      qtake = atomicAdd(qcount, 1u);
+      // statistics: this item's optimistic context evaluations (both heads), no return value, in the same masked region as the queue
+      if (STA_P3_STATS) __hip_atomic_fetch_add(qcount + 1, opt_on ? 2u * (2u + (unsigned)__builtin_popcount(wneed)) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 
     // accumulators -> S^T B operands (rounded to T once). Head A: tiles 0 | 1 (+ tile 2 rows g < 2), head B: tiles 3 | 4
     // (+ tile 2 rows g >= 2); the small operand (tile 2) serves both heads, the K images carry the zeros.
@@ -591,10 +599,10 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const unsigned rest = wneed >> first_local;
         return rest ? blk + (size_t)(2 + first_local + __builtin_ctz(rest)) * CTXB : other;
       };
-      attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sm_scale, 0.f, au, ac, blk + koffb, blk + koffs, opt_on, cnt_a, cnt_f);
+      attend3<T, 0>(kf, blk + voffb, blk + voffs, blk + CTXB + koffb, blk + CTXB + koffs, q0, qs0, kb4, sm_scale, 0.f, au, ac, blk + koffb, blk + koffs, opt_on, cnt_a);
       {
         const char* nx = next_of(0);
-        attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, 0.f, au, ac, blk + CTXB + koffb, blk + CTXB + koffs, opt_on, cnt_a, cnt_f);
+        attend3<T, 1>(kf, blk + CTXB + voffb, blk + CTXB + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, 0.f, au, ac, blk + CTXB + koffb, blk + CTXB + koffs, opt_on, cnt_a);
       }
       for (int i = 0; i < K; ++i) {
         if (!((wneed >> i) & 1u)) continue;
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
         const float w = ((mbits >> i) & 1u) ? cw : 0.f;
         const char* cb = blk + (size_t)(2 + i) * CTXB;
         const char* nx = next_of(i + 1);
-        attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, w, au, ac, cb + koffb, cb + koffs, opt_on, cnt_a, cnt_f);
+        attend3<T, 2>(kf, cb + voffb, cb + voffs, nx + koffb, nx + koffs, q1, qs1, kb4, sm_scale, w, au, ac, cb + koffb, cb + koffs, opt_on, cnt_a);
       }
       ou = pack_out<T>(au);
       oc = pack_out<T>(ac);
@@ -641,23 +649,35 @@ __global__ __launch_bounds__(512, 2) void xattn_fwd_proj_p3_kernel(const P3 p) {
       voffhn = voff_of(qnext, 1);
     }
   }
-  if (p.stats) {      // per-wave counts -> LDS -> one pair of global atomics per workgroup
-    if (lane == 0 && n_att) { atomicAdd(qcount + 1, n_att); atomicAdd(qcount + 2, n_fb); }
+  // Statistics: every 8th workgroup of the launch is a SAMPLE (all 2048 workgroups adding to three words cost 6 us of a 235 us launch:
+  // same-address atomics serialise in L2). Per sampled workgroup: LDS counters (attend3) -> one 64-bit atomic {evaluations, fall-backs}
+  // + one for the finished count.
+  if (STA_P3_STATS && p.stats && (lin & 7) == 0) {
     __syncthreads();
-    if (threadIdx.x == 0 && qcount[1]) { atomicAdd(p.stats + 1, qcount[1]); atomicAdd(p.stats + 2, qcount[2]); }
+    if (threadIdx.x == 0) {
+      unsigned long long* cnt = (unsigned long long*)(p.stats + 2);
+      if (qcount[1]) atomicAdd(cnt, (unsigned long long)qcount[1] | ((unsigned long long)qcount[2] << 32));
+      __threadfence();
+      // The LAST sampled workgroup to get here folds the launch's counts into the totals and decides whether the next launches sit the
+      // optimistic softmax out — more than an eighth of the sampled wave-level context evaluations fell back: the next 64 launches run
+      // the standard softmax only (every context through what is otherwise the fall-back: exact, ~4 % slower than the optimistic path
+      // on friendly logits instead of both paths per context on hostile ones). Every workgroup has read word 0 when it started, and
+      // the last sample cannot finish before... it may: workgroups that have not started yet then see the NEW word 0 — either value is a
+      // valid choice per workgroup (both paths are exact), so the launch stays correct.
+      const unsigned nsamp = (gridDim.x * gridDim.y + 7u) >> 3;
+      if (atomicAdd(p.stats + 1, 1u) == nsamp - 1u) {
+        __threadfence();
+        unsigned* s = p.stats;
+        const unsigned long long c = atomicAdd(cnt, 0ull);
+        const unsigned att = (unsigned)c, fb = (unsigned)(c >> 32);
+        s[4] += att; s[5] += fb; s[6] += 1u;
+        if (s[0] > 0u) { s[0] -= 1u; s[7] += 1u; }
+        else if (fb * 8u > att) s[0] = 64u;
+        s[1] = 0u; s[2] = 0u; s[3] = 0u;
+        __threadfence();
+      }
+    }
   }
-}
-
-// Behind every launch that was given statistics words: fold the launch's counts into the totals and decide whether the next launches sit
-// the optimistic softmax out — more than an eighth of the wave-level context evaluations fell back: the next 64 launches run the standard
-// softmax only (every context through what is otherwise the fall-back: exact, ~4 % slower than the optimistic path on friendly logits
-// instead of both paths per context on hostile ones). One thread; stream-ordered, works inside a replayed hipGraph.
-__global__ void p3_stats_kernel(unsigned* s) {
-  const unsigned att = s[1], fb = s[2];
-  s[4] += att; s[5] += fb; s[6] += 1u;
-  if (s[0] > 0u) { s[0] -= 1u; s[7] += 1u; }
-  else if (fb * 8u > att) s[0] = 64u;
-  s[1] = 0u; s[2] = 0u;
 }
 
 template <typename T, int NKC, int YL, bool OF = false>
@@ -676,7 +696,6 @@ int launch_p3(P3 p, int n_img, hipStream_t st) {
   if (!attr.ensure((const void*)xattn_fwd_proj_p3_kernel<T, NKC, YL, OF>, 160 * 1024))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(fwd proj p3) failed");
   hipLaunchKernelGGL((xattn_fwd_proj_p3_kernel<T, NKC, YL, OF>), dim3(p.W * pairs, n_img), dim3(512), lds, st, p);
-  if (p.stats && kOptimistic<T>) hipLaunchKernelGGL(p3_stats_kernel, dim3(1), dim3(1), 0, st, p.stats);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "fwd proj p3 launch: %s", hipGetErrorString(e));
 }

@@ -431,7 +431,7 @@ _PROJ_STATS = {}
 def proj_stats(device=None):
     """The statistics / adaptive-switch words the head-pair kernel keeps across launches (include/sta_xattn.h: sta_xattn_fwd_proj_ex), one
     buffer per device: int32 tensor of lib.P3_STATS_WORDS words — [0] launches still sitting the optimistic softmax out, [4] / [5]
-    wave-level context evaluations / fall-backs so far, [6] launches, [7] launches that sat out. The words only steer which of two exact
+    wave-level context evaluations / fall-backs so far IN THE SAMPLE (every 8th workgroup counts), [6] launches, [7] launches that sat out. The words only steer which of two exact
     softmax paths runs, so launches of several streams may share them. Never created while a stream is being captured (the zero-fill
     would become a node of the graph and wipe the words at every replay): a capture without a buffer runs without statistics."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -444,12 +444,13 @@ def proj_stats(device=None):
 
 
 def proj_stats_summary():
-    """{evaluations, fallbacks, rate, launches, launches_sat_out, sitting_out_now} over every statistics buffer of the process."""
+    """{evaluations, fallbacks (both in the 1-in-8 workgroup sample), rate, launches, launches_sat_out, sitting_out_now} over every
+    statistics buffer of the process."""
     tot = [0] * _lib.P3_STATS_WORDS
     for t in _PROJ_STATS.values():
         for i, v in enumerate(t.cpu().tolist()):
             tot[i] += v & 0xffffffff
-    return {"evaluations": tot[4], "fallbacks": tot[5], "fallback_rate": (tot[5] / tot[4]) if tot[4] else 0.0, "launches": tot[6],
+    return {"sampled_evaluations": tot[4], "sampled_fallbacks": tot[5], "sample": "every 8th workgroup", "fallback_rate": (tot[5] / tot[4]) if tot[4] else 0.0, "launches": tot[6],
             "launches_sat_out": tot[7], "sitting_out_now": tot[0]}
 
 

@@ -206,9 +206,10 @@ int sta_xattn_fwd_proj_qfrag_ofrag(const void* y_frag, const void* packed_wq, co
  * nats), which holds for the synthetic weights of the bench and is NOT known for real SD-v1-4 weights (a large BOS-token logit is typical).
  * `stats`: NULL (the three entry points above: always optimistic, nothing counted), or STA_P3_STATS_WORDS uint32 words in device memory,
  * zeroed once by the caller and then owned by the library across launches on one stream:
- *   [0] launches still to sit the optimistic softmax out     [1], [2] this launch's wave-level context evaluations / fall-backs
- *   [4], [5] totals of [1], [2]      [6] launches counted     [7] launches that sat out
- * After every launch a one-thread kernel folds the counts and, when more than an eighth of the evaluations fell back, makes the next 64
+ *   [0] launches still to sit the optimistic softmax out     [1] sampled workgroups of this launch that have finished
+ *   [2], [3] this launch's wave-level context evaluations / fall-backs in the SAMPLE (every 8th workgroup counts: 2048 workgroups adding
+ *   to the same words cost 6 us per launch)      [4], [5] totals of [2], [3]      [6] launches counted     [7] launches that sat out
+ * The last sampled workgroup of every launch folds the counts and, when more than an eighth of the evaluations fell back, makes the next 64
  * launches run the standard softmax only (device side: no host synchronisation, valid inside a captured graph) — hostile logits then cost
  * the standard kernel's time, not both paths per context. Shapes that do not take the pair kernel ignore `stats`.
  */
