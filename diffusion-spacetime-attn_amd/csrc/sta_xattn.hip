@@ -337,7 +337,12 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(const Params pin) {
 // MAXIT = 1 is the single-tile build for launches with few workgroups (one image): no mask bytes beyond the
 // tile's own, no prefetch code.
 constexpr int STAGED_MAXIT = 12;
-template <typename T, int NDT, int QT, int NWV, int MAXIT>
+// LL2 (round 6; d > 64 where the K + 2 contexts of a head exceed a CU's LDS: SD-v1 level 2 / mid at K >= 1, level 1 from K = 4):
+// only the two mandatory contexts are staged; a local context is read as MFMA operands straight from the packed image in L2
+// (SrdFrags: one coalesced 1-KiB buffer load per fragment) by the waves whose pixels a disc touches. No second staging group, no
+// barrier behind the first one, and the workgroup keeps its image for `iters` tiles — the grouped variant (LL2 = false) re-staged
+// 2 x 55 KiB per 128 pixels at d = 160 behind two barriers per tile.
+template <typename T, int NDT, int QT, int NWV, int MAXIT, bool LL2 = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_kernel(const Params pin) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
@@ -431,8 +436,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
       stage_frags(img_h + (size_t)(2 + i) * ctx_stride, smem + (first_slot + n) * CB, NFWD, wv, NWV, lane);
     }
   };
-  stage_locals(tile_bits, 2, G - 2);
-  const bool resident = 2 + __builtin_popcount(tile_bits) <= G;   // everything stays in LDS for all tiles
+  if (!LL2) stage_locals(tile_bits, 2, G - 2);
+  const bool resident = LL2 || 2 + __builtin_popcount(tile_bits) <= G;   // everything stays in LDS for all tiles
+  SrdFrags<V8> gfr;
+  if constexpr (LL2) {
+    gfr.r = make_srd(p.packed, (unsigned)((K + 2) * ctx_stride));
+    gfr.voff = (unsigned)lane * 16u;
+    gfr.soff = 0u;
+  }
   const f32x4 kb4 = last_tile_bias(g, p.M);
   const float sl2e = p.sl2e;
   const int sumrow = (d & 15) ? (d & 15) : -1;    // packed V^T carries a ones row at head-dim index d (pack_kv_kernel)
@@ -472,7 +483,17 @@ __global__ __launch_bounds__(64 * NWV, NWV == 12 ? 3 : 1) void xattn_fwd_staged_
         if (__ballot((mb[qt] >> i) & 1u)) wave_bits |= 1u << i;
       }
     }
-    unsigned rest = tile_bits;
+    unsigned rest = LL2 ? 0u : tile_bits;
+    if constexpr (LL2) {
+      for (unsigned bits = wave_bits; bits; bits &= bits - 1) {   // the discs that touch this wave's pixels, operands from L2
+        const int i = __builtin_ctz(bits);
+        const float cw = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(coef_lane), i));
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) w[qt] = ((mb[qt] >> i) & 1u) ? cw : 0.f;
+        gfr.soff = (unsigned)((size_t)(2 + i) * ctx_stride + (size_t)h * all_frags(NDT) * FRAG);
+        attend_staged<T, NDT, QT, 2>(gfr, q1, kb4, sl2e, w, au, ac, sumrow);
+      }
+    }
     for (int slot = 2; rest;) {
       if (slot == G) {              // next group: everyone is done reading the previous one
         __syncthreads();
@@ -568,6 +589,9 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   if (g_sta_opt[STA_OPT_HEAD_MAJOR]) p.head_major = g_sta_opt[STA_OPT_HEAD_MAJOR] == 1 ? 1 : 0;
   int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
   if (G > p.K + 2) G = p.K + 2;
+  // not every context fits: the two mandatory ones resident, locals from L2 (built for d > 64; STA_OPT_PROJ_LL2 = 2 keeps the grouped staging: A/B, tests)
+  const bool ll2 = NDT >= 5 && G < p.K + 2 && (size_t)(p.K + 2) * p.H * all_frags(NDT) * FRAG < (1ull << 32) && g_sta_opt[STA_OPT_PROJ_LL2] != 2;
+  if (ll2) G = 2;
   p.ntiles_aux = G;
   const int lds = G * CB;
   // Tiles per workgroup: enough that ONE round of workgroups (LDS-, wave- and register-limited residency on
@@ -581,7 +605,7 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   if (wg_per_head < 1) wg_per_head = 1;
   int iters = (int)((tiles + wg_per_head - 1) / wg_per_head);
   if (iters > STAGED_MAXIT) iters = STAGED_MAXIT;
-  if (iters < 1 || G < p.K + 2) iters = 1;
+  if (iters < 1 || (G < p.K + 2 && !ll2)) iters = 1;
   if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) { if (v >= 1 && v <= STAGED_MAXIT) iters = v; }
   p.iters = iters;
   p.tiles = tiles;
@@ -596,6 +620,10 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
     return e == hipSuccess ? STA_OK : fail(STA_E_LAUNCH, "fwd staged launch: %s", hipGetErrorString(e));
   };
   static StaLdsAttr attr1, attrn;
+  if constexpr (NDT >= 5) {
+    static StaLdsAttr attr1l, attrnl;
+    if (ll2) return iters == 1 ? launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, 1, true>, attr1l) : launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, STAGED_MAXIT, true>, attrnl);
+  }
   if (iters == 1) return launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, 1>, attr1);
   return launch(xattn_fwd_staged_kernel<T, NDT, QT, NWV, STAGED_MAXIT>, attrn);
 }

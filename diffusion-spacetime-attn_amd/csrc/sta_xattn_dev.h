@@ -350,6 +350,9 @@ __device__ __forceinline__ void attend_staged(const FR fr, const typename Tr<T>:
   // tiles in flight: 8*NKS + 24 fragment registers instead of 20*NKS + 12*NDT (220 at d = 160), which is what lets
   // EIGHT waves share one LDS image there (2 waves per SIMD need <= 256 registers each).
   constexpr bool JIT = NDT >= 7;
+  // operands through a buffer descriptor (locals from L2): nothing orders those loads, hipcc would hoist all 25 + 30 fragments of a
+  // d = 160 context to the top (107 - 410 spilled registers at 8 waves) — scheduling barriers keep the two-tiles-in-flight order
+  constexpr bool PIN = JIT && !std::is_pointer<FR>::value;
   f32x4 st[QT][NKT];
   V8 va[JIT ? 1 : NVF];
   if constexpr (JIT) {
@@ -362,6 +365,7 @@ __device__ __forceinline__ void attend_staged(const FR fr, const typename Tr<T>:
 #pragma unroll
         for (int s = 0; s < NKS; ++s) kt[(t + 1) & 1][s] = frag_at<V8>(fr, ((t + 1) * NKS + s));
       }
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         f32x4 acc = (t == NKT - 1) ? kb4 : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -369,6 +373,7 @@ __device__ __forceinline__ void attend_staged(const FR fr, const typename Tr<T>:
         for (int s = 0; s < NKS; ++s) acc = Tr<T>::mfma(kt[t & 1][s], q[qt][s], acc);
         st[qt][t] = acc;
       }
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     }
   } else {
     V8 ka[NKF];
@@ -405,6 +410,7 @@ __device__ __forceinline__ void attend_staged(const FR fr, const typename Tr<T>:
 #pragma unroll
         for (int s = 0; s < NPS; ++s) vt[(u + 1) & 1][s] = frag_at<V8>(fr, (NKF + s * NDT + u + 1));
       }
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -412,6 +418,7 @@ __device__ __forceinline__ void attend_staged(const FR fr, const typename Tr<T>:
         for (int s = 0; s < NPS; ++s) acc = Tr<T>::mfma(vt[u & 1][s], pb[qt][s], acc);
         o[qt][u] = acc;
       }
+      if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     }
   } else {
 #pragma unroll

@@ -291,6 +291,11 @@ def test_batched_images_match_oracle_per_image(N, C, heads, K, dtype):
     (1024, 640, 8, 2, 32, None),   # level 1
     (256, 1280, 8, 2, 32, None),   # level 2
     (64, 1280, 8, 2, 32, None),    # middle block
+    # locals from L2 (the K + 2 contexts of a head exceed a CU's LDS): level 1 at K = 4, d = 160 with forced tile counts / ragged N
+    (1024, 640, 8, 4, 8, None),
+    (256, 1280, 8, 3, 16, 2),
+    (250, 1280, 8, 2, 8, None),
+    (576, 1280, 8, 4, 8, None),    # level 2 of a 768 x 768 image, K = 4 (BASELINE configs[4])
 ])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_multi_tile_workgroups(N, C, heads, K, I, iters, dtype):
@@ -323,6 +328,38 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters, dtype):
             err = (a.cpu().double() - ref).abs()
             assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
     lib.set_option(lib.OPT_FWD_KERNEL, 0)
+
+
+@pytest.mark.parametrize("N,C,heads,K,I", [(256, 1280, 8, 2, 16), (64, 1280, 8, 2, 32), (1024, 640, 8, 4, 8), (576, 1280, 8, 4, 4), (256, 1152, 8, 1, 8), (256, 896, 8, 5, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_fwd_locals_from_l2_equals_grouped_staging(N, C, heads, K, I, dtype):
+    """Where a head's K + 2 contexts do not fit a CU's LDS (d > 64) the LDS-resident forward keeps the two mandatory contexts and reads the
+    local ones as MFMA operands from L2; STA_OPT_PROJ_LL2 = 2 keeps the round-1 variant (contexts staged in groups, re-staged per tile).
+    Same arithmetic in the same order: identical bits; and the oracle on the first / last image."""
+    from sta import lib, ops
+    dev = "cuda"
+    cases = [_case(N, C, heads, K, dtype, seed=300 + i) for i in range(I)]
+    q = torch.cat([c[0] for c in cases]).to(dev); k = torch.cat([c[1] for c in cases]).to(dev); v = torch.cat([c[2] for c in cases]).to(dev)
+    mb = torch.stack([ops.mask_bits(c[3]) for c in cases]).to(dev)
+    coef = torch.stack([c[4] for c in cases]).to(dev)
+    scale = (C // heads) ** -0.5
+    packed = ops.pack_kv(k, v, heads, n_img=I)
+    lib.set_option(lib.OPT_FWD_KERNEL, lib.FWD_STAGED)
+    try:
+        out, _ = ops.xattn_forward(q, packed, mb, coef, scale)
+        lib.set_option(lib.OPT_PROJ_LL2, 2)
+        grouped, _ = ops.xattn_forward(q, packed, mb, coef, scale)
+        torch.cuda.synchronize()
+    finally:
+        lib.set_option(lib.OPT_PROJ_LL2, 0)
+        lib.set_option(lib.OPT_FWD_KERNEL, 0)
+    assert torch.equal(out, grouped)
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    for i in (0, I - 1):
+        qi, ki, vi, mi, ci = cases[i]
+        ref = orc.fused_xattn(qi.double(), ki.double(), vi.double(), mi, ci.double(), heads, scale)
+        err = (out[2 * i:2 * i + 2].float().cpu().double() - ref).abs()
+        assert (err <= 4 * eps * (1.0 + ref.abs())).all(), (i, err.max().item())
 
 
 @pytest.mark.parametrize("B,N,C,heads", [(2, 4096, 320, 8), (4, 1024, 640, 8), (2, 144, 640, 8), (2, 576, 192, 4),
