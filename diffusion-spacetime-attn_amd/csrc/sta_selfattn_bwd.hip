@@ -57,22 +57,22 @@ __global__ __launch_bounds__(256) void selfattn_delta_kernel(const SBParams p) {
   p.delta[((size_t)b * p.H + h) * p.N + n] = s;
 }
 
-template <typename T, int NKS, int NDT, int QT>
-__global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const SBParams p) {
+template <typename T, int NKS, int NDT, int QT, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void selfattn_bwd_dq_kernel(const SBParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NKF = 4 * NKS;            // K (and V) row fragments per block: 4 key tiles x NKS head-dim steps
   constexpr int NTF = 2 * NDT;            // K^T fragments per block: 2 key steps x NDT head-dim tiles
   constexpr int NFR = 2 * NKF + NTF;      // [K | V | K^T]
-  constexpr int PER = (NFR + 3) / 4;
-  constexpr int BB = 4 * PER * FRAG;
+  constexpr int PER = (NFR + NW - 1) / NW;
+  constexpr int BB = NW * PER * FRAG;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
   const int N = p.N, d = p.d;
   const int b = blockIdx.y;
   const int tile = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const int px0 = (tile * 4 + wv) * 16 * QT;
+  const int px0 = (tile * NW + wv) * 16 * QT;
 
   const T* qb = (const T*)p.q + (size_t)b * N * p.ld + h * d;
   const T* kb = (const T*)p.k + (size_t)b * N * p.ld + h * d;
@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const SBParams p) 
   int step[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int f = wv + 4 * i;
+    const int f = wv + NW * i;
     const int fs = f < NFR ? f : 0;
     if (fs < 2 * NKF) {
       const int f1 = fs < NKF ? fs : fs - NKF;
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const SBParams p) 
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                       (__attribute__((address_space(3))) void*)(dst + (wv + 4 * i) * FRAG), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + (wv + NW * i) * FRAG), 16, 0, 0);
       src[i] += step[i];
     }
   };
@@ -219,22 +219,22 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dq_kernel(const SBParams p) 
   }
 }
 
-template <typename T, int NKS, int NDT, int KT_>
-__global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const SBParams p) {
+template <typename T, int NKS, int NDT, int KT_, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void selfattn_bwd_dkv_kernel(const SBParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
   constexpr int NQF = 4 * NKS;            // Q (and dO) row fragments per block: 4 pixel tiles x NKS head-dim steps
   constexpr int NTF = 2 * NDT;            // Q^T (and dO^T) fragments per block: 2 pixel steps x NDT head-dim tiles
   constexpr int NFR = 2 * NQF + 2 * NTF + 1;   // [Q | dO | Q^T | dO^T | (lse, delta)]
-  constexpr int PER = (NFR + 3) / 4;
-  constexpr int BB = 4 * PER * FRAG;
+  constexpr int PER = (NFR + NW - 1) / NW;
+  constexpr int BB = NW * PER * FRAG;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane >> 4, c16 = lane & 15;
   const int N = p.N, d = p.d;
   const int b = blockIdx.y;
   const int tile = blockIdx.x / p.H, h = blockIdx.x % p.H;
-  const int key0 = (tile * 4 + wv) * 16 * KT_;
+  const int key0 = (tile * NW + wv) * 16 * KT_;
 
   const T* qb = (const T*)p.q + (size_t)b * N * p.ld + h * d;
   const T* kb = (const T*)p.k + (size_t)b * N * p.ld + h * d;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const SBParams p)
   int step[PER];
 #pragma unroll
   for (int i = 0; i < PER; ++i) {
-    const int f = wv + 4 * i;
+    const int f = wv + NW * i;
     const int fs = f < NFR ? f : 0;
     if (fs < 2 * NQF) {
       const int f1 = fs < NQF ? fs : fs - NQF;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const SBParams p)
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
-                                       (__attribute__((address_space(3))) void*)(dst + (wv + 4 * i) * FRAG), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + (wv + NW * i) * FRAG), 16, 0, 0);
       src[i] += step[i];
     }
   };
@@ -427,20 +427,20 @@ __global__ __launch_bounds__(256) void selfattn_bwd_dkv_kernel(const SBParams p)
   }
 }
 
-template <typename T, int NKS, int NDT, int QT>
+template <typename T, int NKS, int NDT, int QT, int NW = 4>
 int launch_sb(const SBParams& p, hipStream_t st) {
-  constexpr int lds_q = 2 * 4 * ((2 * 4 * NKS + 2 * NDT + 3) / 4) * FRAG;
-  constexpr int bb_kv = 4 * ((2 * 4 * NKS + 4 * NDT + 1 + 3) / 4) * FRAG;
+  constexpr int lds_q = 2 * NW * ((2 * 4 * NKS + 2 * NDT + NW - 1) / NW) * FRAG;
+  constexpr int bb_kv = NW * ((2 * 4 * NKS + 4 * NDT + 1 + NW - 1) / NW) * FRAG;
   constexpr int lds_kv = (2 * bb_kv <= 160 * 1024 ? 2 : 1) * bb_kv;
   static StaLdsAttr attr_q, attr_kv;
-  if (!attr_q.ensure((const void*)selfattn_bwd_dq_kernel<T, NKS, NDT, QT>, lds_q) ||
-      !attr_kv.ensure((const void*)selfattn_bwd_dkv_kernel<T, NKS, NDT, QT>, lds_kv))
+  if (!attr_q.ensure((const void*)selfattn_bwd_dq_kernel<T, NKS, NDT, QT, NW>, lds_q) ||
+      !attr_kv.ensure((const void*)selfattn_bwd_dkv_kernel<T, NKS, NDT, QT, NW>, lds_kv))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn backward) failed");
   const long total = (long)p.B * p.N * p.H;
   hipLaunchKernelGGL((selfattn_delta_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
-  const int tiles = (p.N + 64 * QT - 1) / (64 * QT);
-  hipLaunchKernelGGL((selfattn_bwd_dkv_kernel<T, NKS, NDT, QT>), dim3(tiles * p.H, p.B), dim3(256), lds_kv, st, p);
-  hipLaunchKernelGGL((selfattn_bwd_dq_kernel<T, NKS, NDT, QT>), dim3(tiles * p.H, p.B), dim3(256), lds_q, st, p);
+  const int tiles = (p.N + 16 * NW * QT - 1) / (16 * NW * QT);
+  hipLaunchKernelGGL((selfattn_bwd_dkv_kernel<T, NKS, NDT, QT, NW>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds_kv, st, p);
+  hipLaunchKernelGGL((selfattn_bwd_dq_kernel<T, NKS, NDT, QT, NW>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds_q, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn backward launch: %s", hipGetErrorString(e));
 }
@@ -450,7 +450,11 @@ int dispatch_sb(const SBParams& p, hipStream_t st) {
   switch ((p.d + 15) / 16) {
     case 1: return launch_sb<T, 1, 1, 2>(p, st);
     case 2: return launch_sb<T, 1, 2, 2>(p, st);
-    case 3: return launch_sb<T, 2, 3, 2>(p, st);
+    case 3:
+      // d = 40 (SD-v1 level 0: N = 4096): both kernels are bound by the 64-row blocks they stream L2 -> LDS (22 / 29 KiB per block and
+      // workgroup); eight waves share one block where four did — same waves per SIMD, half the stream. STA_OPT_SELFATTN_WAVES = 4 keeps four.
+      if (p.N >= 1024 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 4) return launch_sb<T, 2, 3, 2, 8>(p, st);
+      return launch_sb<T, 2, 3, 2>(p, st);
     case 4: return launch_sb<T, 2, 4, 2>(p, st);
     case 5: return launch_sb<T, 3, 5, 1>(p, st);
     case 6: return launch_sb<T, 3, 6, 1>(p, st);

@@ -76,7 +76,10 @@ enum {
                                  slower, kept for tests / tools), anything else = four waves x two tiles */
   STA_OPT_SELFATTN_PIPE = 9, /* sta_selfattn_fwd at d = 40, 8 heads, log2-domain q, N % 64 == 0: 2 = the plain loop instead of the software-pipelined one; 3 = three query tiles per wave (192 queries per workgroup), 4 / 8 = four / eight waves x two tiles */
   STA_OPT_PROJ_LL2 = 10,    /* sta_xattn_fwd_proj where Wq + every context do not fit a CU's LDS but Wq + the two mandatory ones do (SD-v1 level 1,
-                               C = 640, d = 80): 2 = refuse (the block then takes the GEMM + sta_xattn_fwd); default: local contexts from L2 */
+                               C = 640, d = 80): 2 = refuse (the block then takes the GEMM + sta_xattn_fwd); default: local contexts from L2.
+                               Also sta_xattn_fwd's LDS-resident kernel at d > 64 when a head's K + 2 contexts exceed a CU's LDS (levels 2 / mid,
+                               level 1 from K = 4): 2 = contexts staged in groups per tile (the round-1 variant); default: the two mandatory
+                               contexts resident, local ones as MFMA operands from L2, several tiles per workgroup */
   STA_OPT_BWD_KERNEL = 11,  /* unused since 0.5.0 (one backward kernel) */
   STA_OPT_BWD_SLOTS = 12,   /* sta_xattn_bwd: at most this many contexts in LDS (>= 2), the other local ones from L2 */
   STA_OPT_BWD_WAVES = 13,   /* experiment builds only (-DSTA_EXPERIMENT_BWD_WIDE): 8 = eight waves per workgroup */

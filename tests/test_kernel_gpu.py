@@ -1060,7 +1060,10 @@ def test_fwd_proj_rejects_what_it_cannot_hold():
     says so instead of launching, and the block then takes the GEMM + sta_xattn_fwd."""
     from sta import lib, ops
     assert ops.proj_supported(640, 8, 77, 2) and ops.proj_supported(640, 8, 77, 0)
-    assert not ops.proj_supported(1280, 8, 77, 2)
+    # C = 1280 (d = 160) is held by the streamed-Wq kernel (built, measured slower than the GEMM + sta_xattn_fwd, not used by the model:
+    # sta.ops.PROJ_WQS_IN_MODEL); d = 144 has no kernel
+    assert ops.proj_supported(1280, 8, 77, 2) and ops.proj_streams_wq(1280, 8) and not ops.PROJ_WQS_IN_MODEL
+    assert not ops.proj_supported(1152, 8, 77, 2)
     assert not ops.proj_supported(320, 8, 77, 5)
     L = lib.load()
     y = torch.zeros(2, 64, 640, device="cuda", dtype=torch.float16)
