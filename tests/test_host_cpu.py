@@ -497,7 +497,11 @@ def test_projection_fused_forward_lds_plan():
     assert S(320, 8, 77, 4) and not S(320, 8, 77, 5)              # 6 contexts fit, 7 do not
     assert S(640, 8, 77, 0) and not LL2(640, 8, 77, 0)            # level 1 without objects: 100 + 2 x 30 KiB = the whole LDS
     assert S(640, 8, 77, 2) and LL2(640, 8, 77, 2) and LL2(640, 8, 77, 4)
-    assert not S(1280, 8, 77, 2) and not LL2(1280, 8, 77, 2)      # level 2: 400 KiB of Wq per head
+    # level 2: 400 KiB of Wq per head — held by the streamed-Wq kernel (2-slot LDS ring), which the model does not ask for (measured slower
+    # than the GEMM + sta_xattn_fwd: profiles/r06_level2_proj.md); d = 144 (C = 1152) has no kernel
+    assert S(1280, 8, 77, 2) and not LL2(1280, 8, 77, 2) and ops.proj_streams_wq(1280, 8)
+    assert not S(1152, 8, 77, 2) and not ops.proj_streams_wq(1152, 8)
+    assert not ops.PROJ_WQS_IN_MODEL and not ops.proj_supported(1280, 8, 77, 2, N=256, n_img=64) and ops.proj_supported(1280, 8, 77, 2)
     assert not S(640, 8, 64, 2)                                   # M <= 64 keys: refused by every forward of this family
     lib.set_option(lib.OPT_PROJ_LL2, 2)
     try:
