@@ -589,23 +589,30 @@ int launch_fwd_staged_cfg(const Params& p0, hipStream_t st) {
   if (g_sta_opt[STA_OPT_HEAD_MAJOR]) p.head_major = g_sta_opt[STA_OPT_HEAD_MAJOR] == 1 ? 1 : 0;
   int G = (150 * 1024) / CB;                     // leave room: 160 KiB LDS per CU
   if (G > p.K + 2) G = p.K + 2;
-  // not every context fits: the two mandatory ones resident, locals from L2 (built for d > 64; STA_OPT_PROJ_LL2 = 2 keeps the grouped staging: A/B, tests)
-  const bool ll2 = NDT >= 5 && G < p.K + 2 && (size_t)(p.K + 2) * p.H * all_frags(NDT) * FRAG < (1ull << 32) && g_sta_opt[STA_OPT_PROJ_LL2] != 2;
+  // Tiles per workgroup: enough that ONE round of workgroups (LDS-, wave- and register-limited residency on
+  // the 256 CUs) covers the launch, at most STAGED_MAXIT; 1 when the contexts do not fit LDS together and are staged in groups.
+  const int tiles = (p.N + TP - 1) / TP;
+  auto iters_for = [&](int lds_bytes) {
+    int per_cu = (160 * 1024) / lds_bytes;
+    if (per_cu > 32 / NWV) per_cu = 32 / NWV;
+    if (NWV == 12) per_cu = 1;                   // 3 waves per SIMD by register budget
+    if (per_cu < 1) per_cu = 1;
+    long wg_per_head = (256L * per_cu) / ((long)p.H * p.n_img);   // workgroups per (head, image) in one round
+    if (wg_per_head < 1) wg_per_head = 1;
+    int it = (int)((tiles + wg_per_head - 1) / wg_per_head);
+    return it > STAGED_MAXIT ? STAGED_MAXIT : (it < 1 ? 1 : it);
+  };
+  // Not every context fits: the two mandatory ones resident, locals from L2 — where a workgroup then walks at least two tiles with its
+  // image (level 2 at 64 images: 74.7 -> 68.4 us; level 1 at K = 4, 16 images: -6.5 %). One-tile launches keep the grouped staging: the
+  // second group's LDS-DMA beats per-fragment L2 latency there (level 2 at 16 images: 20.1 against 24.1 us in situ).
+  // Built for d > 64; STA_OPT_PROJ_LL2 = 2 keeps the grouped staging everywhere (A/B, tests), STA_OPT_STAGED_TILES forces a tile count.
+  bool ll2 = NDT >= 5 && G < p.K + 2 && (size_t)(p.K + 2) * p.H * all_frags(NDT) * FRAG < (1ull << 32) && g_sta_opt[STA_OPT_PROJ_LL2] != 2;
+  if (ll2 && !g_sta_opt[STA_OPT_STAGED_TILES] && iters_for(2 * CB) < 2) ll2 = false;
   if (ll2) G = 2;
   p.ntiles_aux = G;
   const int lds = G * CB;
-  // Tiles per workgroup: enough that ONE round of workgroups (LDS-, wave- and register-limited residency on
-  // the 256 CUs) covers the launch, at most STAGED_MAXIT; 1 when the contexts do not fit LDS together.
-  const int tiles = (p.N + TP - 1) / TP;
-  int per_cu = (160 * 1024) / lds;
-  if (per_cu > 32 / NWV) per_cu = 32 / NWV;
-  if (NWV == 12) per_cu = 1;                     // 3 waves per SIMD by register budget
-  if (per_cu < 1) per_cu = 1;
-  long wg_per_head = (256L * per_cu) / ((long)p.H * p.n_img);   // workgroups per (head, image) in one round
-  if (wg_per_head < 1) wg_per_head = 1;
-  int iters = (int)((tiles + wg_per_head - 1) / wg_per_head);
-  if (iters > STAGED_MAXIT) iters = STAGED_MAXIT;
-  if (iters < 1 || (G < p.K + 2 && !ll2)) iters = 1;
+  int iters = iters_for(lds);
+  if (G < p.K + 2 && !ll2) iters = 1;
   if (const int v = g_sta_opt[STA_OPT_STAGED_TILES]) { if (v >= 1 && v <= STAGED_MAXIT) iters = v; }
   p.iters = iters;
   p.tiles = tiles;

@@ -330,11 +330,13 @@ def test_multi_tile_workgroups(N, C, heads, K, I, iters, dtype):
     lib.set_option(lib.OPT_FWD_KERNEL, 0)
 
 
-@pytest.mark.parametrize("N,C,heads,K,I", [(256, 1280, 8, 2, 16), (64, 1280, 8, 2, 32), (1024, 640, 8, 4, 8), (576, 1280, 8, 4, 4), (256, 1152, 8, 1, 8), (256, 896, 8, 5, 8)])
+@pytest.mark.parametrize("N,C,heads,K,I,tiles", [(256, 1280, 8, 2, 32, 0), (256, 1280, 8, 2, 16, 1), (64, 1280, 8, 2, 32, 1), (1024, 640, 8, 4, 8, 0),
+                                                   (576, 1280, 8, 4, 4, 0), (256, 1152, 8, 1, 8, 2), (256, 896, 8, 5, 8, 1)])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-def test_fwd_locals_from_l2_equals_grouped_staging(N, C, heads, K, I, dtype):
-    """Where a head's K + 2 contexts do not fit a CU's LDS (d > 64) the LDS-resident forward keeps the two mandatory contexts and reads the
-    local ones as MFMA operands from L2; STA_OPT_PROJ_LL2 = 2 keeps the round-1 variant (contexts staged in groups, re-staged per tile).
+def test_fwd_locals_from_l2_equals_grouped_staging(N, C, heads, K, I, tiles, dtype):
+    """Where a head's K + 2 contexts do not fit a CU's LDS (d > 64) and a workgroup walks at least two tiles, the LDS-resident forward keeps
+    the two mandatory contexts and reads the local ones as MFMA operands from L2; STA_OPT_PROJ_LL2 = 2 keeps the round-1 variant (contexts
+    staged in groups, re-staged per tile), which one-tile launches take anyway (`tiles` > 0 forces the L2 variant with that tile count there).
     Same arithmetic in the same order: identical bits; and the oracle on the first / last image."""
     from sta import lib, ops
     dev = "cuda"
@@ -346,11 +348,14 @@ def test_fwd_locals_from_l2_equals_grouped_staging(N, C, heads, K, I, dtype):
     packed = ops.pack_kv(k, v, heads, n_img=I)
     lib.set_option(lib.OPT_FWD_KERNEL, lib.FWD_STAGED)
     try:
+        lib.set_option(lib.OPT_STAGED_TILES, tiles)
         out, _ = ops.xattn_forward(q, packed, mb, coef, scale)
+        lib.set_option(lib.OPT_STAGED_TILES, 0)
         lib.set_option(lib.OPT_PROJ_LL2, 2)
         grouped, _ = ops.xattn_forward(q, packed, mb, coef, scale)
         torch.cuda.synchronize()
     finally:
+        lib.set_option(lib.OPT_STAGED_TILES, 0)
         lib.set_option(lib.OPT_PROJ_LL2, 0)
         lib.set_option(lib.OPT_FWD_KERNEL, 0)
     assert torch.equal(out, grouped)
