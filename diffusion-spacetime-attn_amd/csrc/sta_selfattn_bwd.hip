@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256) void selfattn_delta_kernel(const SBParams p) {
   p.delta[((size_t)b * p.H + h) * p.N + n] = s;
 }
 
-template <typename T, int NKS, int NDT, int QT, int NW = 4>
+// PRE (q in log2 units: scale * log2 e == 1, what the model's pre-scaled W_q gives): S - lse and dP - delta come out of the MFMAs — the
+// accumulators START at -lse / -delta (per query: a lane scalar) — so the vector work per score is exp2, one multiply and the
+// conversion instead of fma, exp2, subtract, multiply, conversion (matrix and vector cycles add up in these loops: SQ counters, 45 % + 49 %).
+template <typename T, int NKS, int NDT, int QT, int NW = 4, bool PRE = false>
 __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dq_kernel(const SBParams p) {
   using V8 = typename Tr<T>::V8;
   using V4 = typename Tr<T>::V4;
@@ -152,7 +155,8 @@ __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dq_kernel(const SBParams
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          st[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float i0 = PRE ? -L[qt] : 0.f;
+          st[qt][t] = f32x4{i0, i0, i0, i0};
 #pragma unroll
           for (int s = 0; s < NKS; ++s) st[qt][t] = Tr<T>::mfma(ka[t * NKS + s], qf[qt][s], st[qt][t]);
         }
@@ -167,7 +171,8 @@ __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dq_kernel(const SBParams
       for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          dp[qt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float i0 = PRE ? -dl[qt] : 0.f;
+          dp[qt][t] = f32x4{i0, i0, i0, i0};
 #pragma unroll
           for (int s = 0; s < NKS; ++s) dp[qt][t] = Tr<T>::mfma(va[t * NKS + s], gf[qt][s], dp[qt][t]);
         }
@@ -183,8 +188,12 @@ __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dq_kernel(const SBParams
       for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][t][r], p.sl2e, -L[qt]));
-          st[qt][t][r] = e * (dp[qt][t][r] - dl[qt]);
+          if constexpr (PRE) {
+            st[qt][t][r] = __builtin_amdgcn_exp2f(st[qt][t][r]) * dp[qt][t][r];
+          } else {
+            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(st[qt][t][r], p.sl2e, -L[qt]));
+            st[qt][t][r] = e * (dp[qt][t][r] - dl[qt]);
+          }
         }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
@@ -219,6 +228,9 @@ __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dq_kernel(const SBParams
   }
 }
 
+// (The dq kernel's accumulator-start trick was built here too — resident K / V negated once, accumulators starting at +lse / +delta read as row
+// scalars from LDS, 19 % fewer vector instructions in the loop — and measured equal, as did operand reads issued a phase ahead of their MFMAs
+// and eight waves sharing a block in situ: this loop is 45 % matrix-pipe busy and answers to none of the three. Left in the plain form.)
 template <typename T, int NKS, int NDT, int KT_, int NW = 4>
 __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dkv_kernel(const SBParams p) {
   using V8 = typename Tr<T>::V8;
@@ -319,6 +331,9 @@ __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dkv_kernel(const SBParam
     }
     const V8* fr = (const V8*)cur + lane;
     f32x4 st[KT_][4], dp[KT_][4];
+    // row scalars of this lane's 16 pixels: tile t, rows 4g..4g+3 <-> 4 consecutive pixels tile_key(t, 4g) ..
+    const float* ld_ = (const float*)(cur + (2 * NQF + 2 * NTF) * FRAG);
+    f32x4 L4[4], D4[4];
     {
       V8 qa[NQF];
 #pragma unroll
@@ -349,9 +364,6 @@ __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dkv_kernel(const SBParam
         }
       __builtin_amdgcn_s_setprio(0);
     }
-    // row scalars of this lane's 16 pixels: tile t, rows 4g..4g+3 <-> 4 consecutive pixels tile_key(t, 4g) ..
-    const float* ld_ = (const float*)(cur + (2 * NQF + 2 * NTF) * FRAG);
-    f32x4 L4[4], D4[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       L4[t] = *(const f32x4*)(ld_ + tile_key(t, 4 * g));
@@ -427,41 +439,43 @@ __global__ __launch_bounds__(64 * NW) void selfattn_bwd_dkv_kernel(const SBParam
   }
 }
 
-template <typename T, int NKS, int NDT, int QT, int NW = 4>
+template <typename T, int NKS, int NDT, int QT, int NW = 4, bool PRE = false>
 int launch_sb(const SBParams& p, hipStream_t st) {
   constexpr int lds_q = 2 * NW * ((2 * 4 * NKS + 2 * NDT + NW - 1) / NW) * FRAG;
   constexpr int bb_kv = NW * ((2 * 4 * NKS + 4 * NDT + 1 + NW - 1) / NW) * FRAG;
   constexpr int lds_kv = (2 * bb_kv <= 160 * 1024 ? 2 : 1) * bb_kv;
   static StaLdsAttr attr_q, attr_kv;
-  if (!attr_q.ensure((const void*)selfattn_bwd_dq_kernel<T, NKS, NDT, QT, NW>, lds_q) ||
+  if (!attr_q.ensure((const void*)selfattn_bwd_dq_kernel<T, NKS, NDT, QT, NW, PRE>, lds_q) ||
       !attr_kv.ensure((const void*)selfattn_bwd_dkv_kernel<T, NKS, NDT, QT, NW>, lds_kv))
     return sta_fail(STA_E_LAUNCH, "hipFuncSetAttribute(selfattn backward) failed");
   const long total = (long)p.B * p.N * p.H;
   hipLaunchKernelGGL((selfattn_delta_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
   const int tiles = (p.N + 16 * NW * QT - 1) / (16 * NW * QT);
   hipLaunchKernelGGL((selfattn_bwd_dkv_kernel<T, NKS, NDT, QT, NW>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds_kv, st, p);
-  hipLaunchKernelGGL((selfattn_bwd_dq_kernel<T, NKS, NDT, QT, NW>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds_q, st, p);
+  hipLaunchKernelGGL((selfattn_bwd_dq_kernel<T, NKS, NDT, QT, NW, PRE>), dim3(tiles * p.H, p.B), dim3(64 * NW), lds_q, st, p);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? STA_OK : sta_fail(STA_E_LAUNCH, "selfattn backward launch: %s", hipGetErrorString(e));
 }
 
 template <typename T>
 int dispatch_sb(const SBParams& p, hipStream_t st) {
+  // q in log2 units (scale = ln 2: the model's attn1 with its pre-scaled W_q): the PRE kernels, built for the head dims of SD-v1 (40, 80, 160)
+  const bool pre = fabsf(p.sl2e - 1.0f) < 1e-6f;
   switch ((p.d + 15) / 16) {
     case 1: return launch_sb<T, 1, 1, 2>(p, st);
     case 2: return launch_sb<T, 1, 2, 2>(p, st);
     case 3:
-      // d = 40 (SD-v1 level 0: N = 4096): both kernels are bound by the 64-row blocks they stream L2 -> LDS (22 / 29 KiB per block and
-      // workgroup); eight waves share one block where four did — same waves per SIMD, half the stream. STA_OPT_SELFATTN_WAVES = 4 keeps four.
-      if (p.N >= 1024 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 4) return launch_sb<T, 2, 3, 2, 8>(p, st);
-      return launch_sb<T, 2, 3, 2>(p, st);
+      // d = 40 (SD-v1 level 0: N = 4096): eight waves share a streamed 64-row block where four did (22 / 29 KiB per block and workgroup
+      // through L2 -> LDS) — same waves per SIMD, half the stream; -4 % stand-alone. STA_OPT_SELFATTN_WAVES = 4 keeps four.
+      if (p.N >= 1024 && g_sta_opt[STA_OPT_SELFATTN_WAVES] != 4) return pre ? launch_sb<T, 2, 3, 2, 8, true>(p, st) : launch_sb<T, 2, 3, 2, 8>(p, st);
+      return pre ? launch_sb<T, 2, 3, 2, 4, true>(p, st) : launch_sb<T, 2, 3, 2>(p, st);
     case 4: return launch_sb<T, 2, 4, 2>(p, st);
-    case 5: return launch_sb<T, 3, 5, 1>(p, st);
+    case 5: return pre ? launch_sb<T, 3, 5, 1, 4, true>(p, st) : launch_sb<T, 3, 5, 1>(p, st);
     case 6: return launch_sb<T, 3, 6, 1>(p, st);
     case 7: return launch_sb<T, 4, 7, 1>(p, st);
     case 8: return launch_sb<T, 4, 8, 1>(p, st);
     case 9: return launch_sb<T, 5, 9, 1>(p, st);
-    case 10: return launch_sb<T, 5, 10, 1>(p, st);
+    case 10: return pre ? launch_sb<T, 5, 10, 1, 4, true>(p, st) : launch_sb<T, 5, 10, 1>(p, st);
   }
   return sta_fail(STA_E_UNSUP, "self-attention backward: head dim %d unsupported (d <= 160)", p.d);
 }

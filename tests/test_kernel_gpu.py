@@ -677,6 +677,46 @@ def test_self_attention_backward_matches_fp64(B, N, C, heads, dtype):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("B,N,C,heads", [(1, 4096, 320, 8), (2, 256, 320, 8), (2, 1024, 640, 8), (2, 256, 1280, 8), (2, 64, 1280, 8), (3, 320, 320, 8)])
+def test_self_attention_backward_log2_domain_q(B, N, C, heads, dtype):
+    """What the model's tracked attn1 calls: scale = ln 2 on a q that carries d^-1/2 log2 e already (pre-scaled W_q) — the kernels whose
+    S - lse and dP - delta come out of the MFMAs (accumulators start at -lse / -delta). Against the fp64 autograd of the same function of
+    the same 16-bit buffer; eight- and four-wave workgroups give identical bits at d = 40."""
+    from sta import lib, ops
+    g = torch.Generator().manual_seed(B + N + C)
+    d = C // heads
+    qkv = torch.randn(B, N, 3 * C, generator=g)
+    qkv[..., :C] *= d ** -0.5 * 1.4426950408889634          # q in log2 units
+    qkv = qkv.to(dtype)
+    dout = torch.randn(B, N, C, generator=g).to(dtype)
+    x = qkv.cuda().requires_grad_(True)
+    out = ops.SelfAttentionQKV.apply(x, heads, ops.LN2)
+    out.backward(dout.cuda())
+    got = x.grad.double().cpu()
+    if d == 40 and N >= 1024:
+        lib.set_option(lib.OPT_SELFATTN_WAVES, 4)
+        try:
+            x4 = qkv.cuda().requires_grad_(True)
+            ops.SelfAttentionQKV.apply(x4, heads, ops.LN2).backward(dout.cuda())
+        finally:
+            lib.set_option(lib.OPT_SELFATTN_WAVES, 0)
+        assert torch.equal(x4.grad, x.grad)
+    dev64 = "cuda" if N > 1024 else "cpu"
+    r = qkv.double().to(dev64).requires_grad_(True)
+    q64, k64, v64 = (r[..., i * C:(i + 1) * C].view(B, N, heads, d).transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q64 @ k64.transpose(-1, -2) * ops.LN2, -1) @ v64).transpose(1, 2).reshape(B, N, C)
+    ref.backward(dout.double().to(dev64))
+    eps = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (out.detach().double().cpu() - ref.detach().cpu()).abs()
+    assert (err <= 4 * eps * (1.0 + ref.detach().cpu().abs())).all(), err.max()
+    gref = r.grad.cpu()
+    for i, name in enumerate(("dq", "dk", "dv")):
+        a, b_ = got[..., i * C:(i + 1) * C], gref[..., i * C:(i + 1) * C]
+        assert (a - b_).abs().max() <= 6 * eps * b_.abs().max(), (name, (a - b_).abs().max(), b_.abs().max())
+        assert ((a - b_).norm() / b_.norm()) < 2 * eps, (name, (a - b_).norm() / b_.norm())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_self_attention_backward_768_level0(dtype):
     """BASELINE configs[4] size (768x768: N = 9216 at level 0, d = 40): the HIP backward against fp32 autograd of the explicit
     softmax on the GPU (the fp64 form would need 22 GB per tensor), plus linearity in dout — a size-independent property of

@@ -5,10 +5,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, os.path.join(ROOT, "diffusion-spacetime-attn_amd"))
 from sta import lib, ops
 B, N, C, heads = int(os.environ.get("SA_B", 32)), 4096, 320, 8
-scale = (C // heads) ** -0.5
+scale = ops.LN2 if os.environ.get('SA_PRE', '1') == '1' else (C // heads) ** -0.5
 res = {}
 for dt in (torch.float16, torch.bfloat16):
-    qkv = torch.randn(B, N, 3 * C, device="cuda").to(dt).requires_grad_(True)
+    qkv = torch.randn(B, N, 3 * C, device="cuda"); qkv[..., :C] *= 0.228; qkv = qkv.to(dt).requires_grad_(True)
     dout = torch.randn(B, N, C, device="cuda").to(dt)
     out = ops.SelfAttentionQKV.apply(qkv, heads, scale)
     grads = {}
