@@ -338,6 +338,8 @@ def roofline_leg(model, dev, dt, dtype_name, I, K, lat, rec, centres):
         "bytes_per_launch": d_bytes, "flops_per_launch": d_flops, "avg_launch_us": d_us,
         "flop_per_byte": d_flops / d_bytes, "ridge_flop_per_byte": MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS,
         "hbm_gbps": d_bytes / d_us / 1e3, "hbm_frac": t_hbm / d_us, "mfma_tflops": d_flops / d_us / 1e6, "mfma_frac": t_mfma / d_us,
+        "peak_note": "the MFMA peak (%.0f TFLOP/s dense) is the 2.4 GHz figure; under the level-0 launch the chip sustains 1.95 - 1.97 GHz in fp16 and "
+                     "2.06 GHz in bf16 with identical busy cycles (tools/p3_clock.py, profiles/r06_p3_clock.json)" % MFMA_PEAK_TFLOPS,
         "how": "in situ: 4 real eager CFG UNet calls, one HIP-event pair per launch on the launch stream, RAW event times "
                "(an empty pair measures ~4.6 us here; nothing subtracted)",
         "warm_launch_us": sum(r["warm_us"] for r in by_shape[dom]) / len(by_shape[dom]),
@@ -477,19 +479,25 @@ def hostile_logits_leg(dev, dtype_name, I, K, lat):
     kh = k.clone(); kh[:, 0] = (qm * lead).reshape(C).cpu()
     out = {}
 
-    def timed(kvp, stats, reps=20):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            ops.xattn_forward_proj(yq, wqf, kvp, mask, coef, scale, qfrag=True, ofrag=True, stats=stats)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) * 1e3 / reps
+    def timed(kvp, stats, reps=20, rounds=3):
+        # the smallest of `rounds` event-pair averages: a box now and then stalls one launch of a back-to-back series by ~1 ms (seen as
+        # 302 against 255 us for the same binary and operands on two boxes), which a single average of 20 carries as +50 us
+        best = None
+        for _ in range(rounds if reps > 1 else 1):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                ops.xattn_forward_proj(yq, wqf, kvp, mask, coef, scale, qfrag=True, ofrag=True, stats=stats)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / reps
+            best = t if best is None else min(best, t)
+        return best
 
     for name, kk in (("friendly", k), ("hostile", kh)):
         kvp = ops.pack_kv_proj(kk.to(dt).to(dev), v, heads, n_img=I)
         stats = torch.zeros(lib.P3_STATS_WORDS, dtype=torch.int32, device=dev)
-        for _ in range(3):
+        for _ in range(200):     # ~50 ms: the chip's clocks settle (the first series behind 3 launches read 10 % slower than the ones after it)
             ops.xattn_forward_proj(yq, wqf, kvp, mask, coef, scale, qfrag=True, ofrag=True, stats=None)      # warm, no switch: always optimistic
         out[name + "_always_optimistic_us"] = round(timed(kvp, None), 2)
         first = timed(kvp, stats, reps=1)
@@ -497,13 +505,13 @@ def hostile_logits_leg(dev, dtype_name, I, K, lat):
         steady = timed(kvp, stats)
         s2 = stats.cpu().tolist()
         out[name] = {"first_launch_us": round(first, 2), "steady_us": round(steady, 2), "fallback_rate_first_launch": round(s1[5] / max(s1[4], 1), 4),
-                     "sitting_out_after_first": s1[0], "launches_sat_out_of_21": s2[7]}
+                     "sitting_out_after_first": s1[0], "launches_sat_out_of_61": s2[7]}
         if name == "friendly":      # the standard softmax alone on the friendly operands: force the switch
             stats[0] = 1 << 20
             out["friendly_standard_softmax_us"] = round(timed(kvp, stats), 2)
     out["what"] = ("head-pair kernel (to_q + attention + blend, query fragments in, out fragments out), N=%d C=%d K=%d, %d images, %s, warm back-to-back launches; "
-                   "hostile = key 0 of every context leads by ~ +16 nats; steady = 20 launches behind the first (the switch engaged where the fall-back rate "
-                   "was above 1/8)" % (N, C, K, I, dtype_name))
+                   "hostile = key 0 of every context leads by ~ +16 nats; steady = the smallest 20-launch average of three series behind the first launch (the switch engaged where the "
+                   "fall-back rate was above 1/8: it holds for 64 launches and is renewed by the first optimistic launch after them)" % (N, C, K, I, dtype_name))
     out["worst_case_over_standard"] = round(out["hostile"]["steady_us"] / out["friendly_standard_softmax_us"], 4)
     return out
 
