@@ -336,6 +336,10 @@ def roofline_leg(model, dev, dt, dtype_name, I, K, lat, rec, centres):
         "kernel": "%s, N=%d C=%d, %d image(s) per launch, %d of the %d launches of a UNet call (%.0f %% of their time)"
                   % (kname, dom[1], dom[2], I, len(by_shape[dom]), len(rows), 100.0 * d_us * len(by_shape[dom]) / all_us),
         "bytes_per_launch": d_bytes, "flops_per_launch": d_flops, "avg_launch_us": d_us,
+        # the samples behind the average (it is a plain mean: one stalled launch among them would show here, not be dropped)
+        "launch_us_samples": {"n": len(by_shape[dom]), "min": round(min(r["us"] for r in by_shape[dom]), 2),
+                              "median": round(sorted(r["us"] for r in by_shape[dom])[len(by_shape[dom]) // 2], 2),
+                              "max": round(max(r["us"] for r in by_shape[dom]), 2)},
         "flop_per_byte": d_flops / d_bytes, "ridge_flop_per_byte": MFMA_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS,
         "hbm_gbps": d_bytes / d_us / 1e3, "hbm_frac": t_hbm / d_us, "mfma_tflops": d_flops / d_us / 1e6, "mfma_frac": t_mfma / d_us,
         "peak_note": "the MFMA peak (%.0f TFLOP/s dense) is the 2.4 GHz figure; under the level-0 launch the chip sustains 1.95 - 1.97 GHz in fp16 and "
