@@ -65,6 +65,8 @@ def parse():
                          "above (sta.pipeline.set_recompute)")
     ap.add_argument("--nchw", action="store_true", help="keep the UNet trunk in NCHW (2.6%% slower at 8 prompts per step)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-hostile", action="store_true", help="skip the hostile_logits leg (tools/profile_bench.sh: its ~700 launches of the dominant "
+                    "kernel on other operands would be averaged into the committed trace's figure for that kernel)")
     ap.add_argument("--no-side-runs", action="store_true", help="skip the bounded side measurement after the headline run "
                                                                  "(3-epoch weight optimisation = BASELINE configs[2])")
     ap.add_argument("--no-config5", action="store_true", help="skip the 768x768 / 4-object side leg (BASELINE configs[4] on one GPU)")
@@ -798,7 +800,7 @@ def main():
         out["roofline"] = roofline_leg(model, dev, dt, a.dtype, I, K, lat, prompts[mine(0)[0]], centres)
     if not a.no_roofline and a.opt_epochs > 1 and K > 0:
         out["roofline_bwd"] = roofline_bwd_leg(model, dev, dt, a.dtype, I, K, lat, prompts[mine(0)[0]], centres)
-    if not a.no_roofline and a.opt_epochs == 0 and a.res == 512:
+    if not a.no_roofline and not a.no_hostile and a.opt_epochs == 0 and a.res == 512:
         try:
             out["hostile_logits"] = hostile_logits_leg(dev, a.dtype, I, K, lat)
         except Exception as e:          # noqa: BLE001

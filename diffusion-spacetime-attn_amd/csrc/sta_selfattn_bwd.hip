@@ -460,7 +460,7 @@ int launch_sb(const SBParams& p, hipStream_t st) {
 template <typename T>
 int dispatch_sb(const SBParams& p, hipStream_t st) {
   // q in log2 units (scale = ln 2: the model's attn1 with its pre-scaled W_q): the PRE kernels, built for the head dims of SD-v1 (40, 80, 160)
-  const bool pre = fabsf(p.sl2e - 1.0f) < 1e-6f;
+  const bool pre = p.sl2e == 1.0f;
   switch ((p.d + 15) / 16) {
     case 1: return launch_sb<T, 1, 1, 2>(p, st);
     case 2: return launch_sb<T, 1, 2, 2>(p, st);
@@ -494,8 +494,9 @@ extern "C" int sta_selfattn_bwd(const void* q, const void* k, const void* v, con
   if (N % 64 || d % 8 || d > 160 || ld < C || ldg < C || ld % 8 || ldg % 4)
     return sta_fail(STA_E_UNSUP, "self-attention backward needs N %% 64 == 0, d %% 8 == 0, d <= 160, row strides >= C (N=%d d=%d)", N, d);
   if (dtype != STA_BF16 && dtype != STA_F16) return sta_fail(STA_E_UNSUP, "dtype %d", dtype);
-  SBParams p{q, k, v, qt, kt, doutt, dout, out, lse, delta, dq, dk, dv, B, N, C, heads, d, ld, ldg,
-             scale * 1.4426950408889634f, scale};
+  float sl2e = scale * 1.4426950408889634f;
+  if (fabsf(sl2e - 1.0f) < 1e-6f) sl2e = 1.0f;       // scale = ln 2: q in log2 units — the same snap as the forward that wrote `lse`
+  SBParams p{q, k, v, qt, kt, doutt, dout, out, lse, delta, dq, dk, dv, B, N, C, heads, d, ld, ldg, sl2e, scale};
   hipStream_t st = (hipStream_t)stream;
   return dtype == STA_BF16 ? dispatch_sb<__bf16>(p, st) : dispatch_sb<_Float16>(p, st);
 }
