@@ -132,3 +132,18 @@ def test_bench_two_ranks_sharing_one_gpu_end_to_end():
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
     d = json.loads(lines[0])
     assert d["weights_identical_on_every_rank"] and d["backend"] == "gloo" and d["device"] == "cuda" and d["n_gpus"] == 2
+
+
+def test_bench_eight_ranks_sharing_one_gpu_strong_scaling_split():
+    """The driver's N = 8 launch as far as one GPU can execute it: eight ranks on GPU 0 (gloo carries the collectives), BASELINE configs[3]'s
+    64 prompts split 8 x 8 (`--scaling strong`), weights from rank 0 to seven peers, eight MIOpen user-db copies, eight hipGraph captures at
+    once, barrier + max over ranks, ONE JSON line. Reduced schedule (4 PLMS steps); the full 50-step run of the same command is
+    profiles/r06_share8.json."""
+    r, lines = _bench("--gpus", "8", "--share-gpu", "--scaling", "strong", "--steps", "1", "--warmup", "1", "--ddim_steps", "4",
+                      "--no-cpu-baseline", "--no-side-runs", "--no-roofline", timeout=1500)
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["config"]["global_batch"] == 64 and out["config"]["images_per_step"] == 8
+    assert out["config"]["weight_broadcast_bytes"] > 1.5e9 and "TEST MODE" in out["config"]["parallelism"]
+
