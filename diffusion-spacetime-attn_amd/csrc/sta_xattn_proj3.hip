@@ -134,6 +134,13 @@ __device__ __forceinline__ float bcast_row2(float x) {
   // registers" — what was really wrong there was the mixed-shape MFMA chain (profiles/r05_hazard_table.md), and the measured table
   // (tools/hazard_probe.py ^perm: vector write -> swap 1 state by ANY filler, swap -> vector read 0, swap -> swap 1) says the compiler's
   // own padding (2 states, filled with whatever it can schedule there) is enough; sta/isa_lint.py re-checks every site.
+#ifdef STA_P3_ASM_BCAST     // rounds 3 - 5's form, for same-box A/B builds only (tools/lib_ab.py ... asm=-DSTA_P3_ASM_BCAST)
+  unsigned t0, t1;
+  asm volatile("s_nop 1\n\tv_mov_b32 %0, %2\n\tv_mov_b32 %1, %2\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1\n\t"
+               "v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane16_swap_b32 %1, %0\n\ts_nop 1"
+               : "=&v"(t0), "=&v"(t1) : "v"(x));
+  return __uint_as_float(t1);
+#endif
   const unsigned u = __float_as_uint(x);
   auto a = __builtin_amdgcn_permlane32_swap(u, u, false, false);        // second operand: lane rows (2, 3, 2, 3)
   auto b = __builtin_amdgcn_permlane16_swap(a[1], a[1], false, false);  // first operand: lane rows (2, 2, 2, 2)
